@@ -1,0 +1,343 @@
+"""Result data model of the CMVM path: ``QInterval``, ``Op``, ``CombLogic``, ``Pipeline``.
+
+Field-for-field compatible with the reference's ``da4ml.types`` (reference
+``src/da4ml/types.py:21-64`` for QInterval/Precision/Op, ``:176-215`` CombLogic fields,
+``:584-633`` Pipeline) so that solver results can be swapped, JSON-dumped and diffed.
+Only what the CMVM solver emits is executable here: opcodes -1 (input copy), 0 (add) and
+1 (subtract); the tracer-only opcodes (relu, quantize, mux, lookup ...) are outside this
+path and raise.
+
+Unlike the reference's per-sample Python replay (``types.py:217-370``) the numeric replay
+here is vectorised over a batch, so ``CombLogic.kernel`` of a 1e5-op solution costs one
+pass over the op list instead of ``n_in`` passes.
+"""
+
+from __future__ import annotations
+
+import json
+from functools import reduce
+from math import ceil, log2
+from pathlib import Path
+from typing import NamedTuple
+
+import numpy as np
+
+__all__ = ['QInterval', 'Precision', 'Op', 'Pair', 'CombLogic', 'Pipeline', 'minimal_kif']
+
+
+class QInterval(NamedTuple):
+    """Quantised interval ``[min, max]`` with resolution ``step``."""
+
+    min: float
+    max: float
+    step: float
+
+
+class Precision(NamedTuple):
+    keep_negative: bool
+    integers: int
+    fractional: int
+
+
+class Op(NamedTuple):
+    """``buf[i] = buf[id0] (+|-) buf[id1] * 2**data`` for opcode 0|1; opcode -1 copies input ``id0``."""
+
+    id0: int
+    id1: int
+    opcode: int
+    data: int
+    qint: QInterval
+    latency: float
+    cost: float
+
+
+class Pair(NamedTuple):
+    """A candidate two-term subexpression ``row[id0] +/- row[id1] << shift``."""
+
+    id0: int
+    id1: int
+    sub: bool
+    shift: int
+
+
+def minimal_kif(qi: QInterval, symmetric: bool = False) -> Precision:
+    """Smallest (sign, integer, fraction) fixed-point format holding ``qi`` (reference ``types.py:86-114``)."""
+    if qi.min == qi.max == 0:
+        return Precision(False, 0, 0)
+    frac = int(-log2(qi.step))
+    lo, hi = round(qi.min / qi.step), round(qi.max / qi.step)
+    mag = max(abs(lo), hi) + 1 if symmetric else max(abs(lo), hi + 1)
+    return Precision(qi.min < 0, int(ceil(log2(mag))) - frac, frac)
+
+
+class _Encoder(json.JSONEncoder):
+    def default(self, o):
+        if hasattr(o, 'to_dict'):
+            return o.to_dict()
+        return super().default(o)
+
+
+def _is_numeric(a: np.ndarray) -> bool:
+    return a.dtype != object
+
+
+class CombLogic(NamedTuple):
+    """One combinational adder graph: ``ops`` executed in order on a buffer, then ``out_idxs`` read out."""
+
+    shape: tuple[int, int]
+    inp_shifts: list[int]
+    out_idxs: list[int]
+    out_shifts: list[int]
+    out_negs: list[bool]
+    ops: list[Op]
+    carry_size: int
+    adder_size: int
+    lookup_tables: tuple | None = None
+
+    # ------------------------------------------------------------------ replay
+    def _replay(self, x):
+        """x: [n_in] or [batch, n_in]; returns the whole buffer [n_ops] / [batch, n_ops]."""
+        x = np.asarray(x)
+        single = x.ndim == 1
+        if single:
+            x = x[None]
+        numeric = _is_numeric(x)
+        x = x * (2.0 ** np.asarray(self.inp_shifts, dtype=np.float64))
+        n_ops = len(self.ops)
+        buf = np.empty((n_ops, x.shape[0]), dtype=np.float64 if numeric else object)
+        for i, op in enumerate(self.ops):
+            code = op.opcode
+            if code == -1:
+                buf[i] = x[:, op.id0]
+            elif code == 0:
+                buf[i] = buf[op.id0] + buf[op.id1] * 2.0**op.data
+            elif code == 1:
+                buf[i] = buf[op.id0] - buf[op.id1] * 2.0**op.data
+            else:
+                raise NotImplementedError(f'opcode {code} is outside the CMVM path implemented by da4ml_amd ({op})')
+        buf = buf.T
+        return buf[0] if single else buf
+
+    def __call__(self, inp, quantize=False, debug=False, dump=False):
+        if quantize:
+            raise NotImplementedError('input quantisation belongs to the tracer, not to the CMVM path')
+        buf = self._replay(inp)
+        if debug:
+            flat = np.asarray(buf)
+            flat = flat[0] if flat.ndim == 2 else flat
+            for i, (op, v) in enumerate(zip(self.ops, flat)):
+                desc = 'inp' if op.opcode == -1 else f'buf[{op.id0}] {"+-"[op.opcode]} buf[{op.id1}]<<{op.data}'
+                print(f'{desc:<32} |-> buf[{i}] = {v}')
+        if dump:
+            return buf
+        idx = np.asarray(self.out_idxs, dtype=np.int64)
+        if len(self.ops) == 0:
+            return np.zeros(buf.shape[:-1] + (len(idx),))
+        scale = 2.0 ** np.asarray(self.out_shifts, dtype=np.float64)
+        scale = scale * np.where(np.asarray(self.out_negs, dtype=bool), -1.0, 1.0) * (idx >= 0)
+        return buf[..., np.where(idx < 0, 0, idx)] * scale
+
+    @property
+    def kernel(self) -> np.ndarray:
+        """The matrix this graph implements (rows = responses to one-hot inputs)."""
+        n_in = self.shape[0]
+        out = np.empty(self.shape, dtype=np.float32)
+        chunk = max(1, min(n_in, (1 << 25) // max(len(self.ops), 1)))
+        eye = np.identity(n_in)
+        for lo in range(0, n_in, chunk):
+            out[lo : lo + chunk] = self(eye[lo : lo + chunk])
+        return out
+
+    # ------------------------------------------------------------------ summaries
+    @property
+    def cost(self) -> float:
+        return float(sum(op.cost for op in self.ops))
+
+    @property
+    def n_adders(self) -> int:
+        """Number of two-input adders/subtractors (opcode 0 or 1)."""
+        return sum(1 for op in self.ops if op.opcode in (0, 1))
+
+    @property
+    def latency(self) -> tuple[float, float]:
+        lat = [self.ops[i].latency for i in self.out_idxs]
+        return (min(lat), max(lat)) if lat else (0.0, 0.0)
+
+    @property
+    def out_latency(self) -> list[float]:
+        return [self.ops[i].latency if i >= 0 else 0.0 for i in self.out_idxs]
+
+    @property
+    def out_qint(self) -> list[QInterval]:
+        res = []
+        for i, idx in enumerate(self.out_idxs):
+            lo, hi, st = self.ops[idx].qint
+            sf = 2.0 ** self.out_shifts[i]
+            lo, hi, st = lo * sf, hi * sf, st * sf
+            if self.out_negs[i]:
+                lo, hi = -hi, -lo
+            res.append(QInterval(lo, hi, st))
+        return res
+
+    @property
+    def out_kifs(self):
+        return np.array([minimal_kif(q) for q in self.out_qint]).T
+
+    @property
+    def inp_latency(self) -> list[float]:
+        return [op.latency for op in self.ops if op.opcode == -1]
+
+    @property
+    def inp_qint(self) -> list[QInterval]:
+        q = [QInterval(0.0, 0.0, 1.0)] * self.shape[0]
+        for op in self.ops:
+            if op.opcode == -1:
+                q[op.id0] = op.qint
+        return q
+
+    @property
+    def inp_kifs(self):
+        return np.array([minimal_kif(q) for q in self.inp_qint]).T
+
+    @property
+    def ref_count(self) -> np.ndarray:
+        cnt = np.zeros(len(self.ops), dtype=np.uint64)
+        for op in self.ops:
+            if op.opcode == -1:
+                continue
+            for j in (op.id0, op.id1):
+                if j != -1:
+                    cnt[j] += 1
+        for i in self.out_idxs:
+            if i >= 0:
+                cnt[i] += 1
+        return cnt
+
+    def __repr__(self):
+        lo, hi = self.latency
+        return f'Solution([{self.shape[0]} -> {self.shape[1]}], cost={self.cost}, latency={lo}-{hi})'
+
+    # ------------------------------------------------------------------ serialisation (reference types.py:442-477, 500-541)
+    def save(self, path: str | Path):
+        with open(path, 'w') as f:
+            json.dump(self, f, cls=_Encoder, separators=(',', ':'))
+
+    @classmethod
+    def deserialize(cls, data: list):
+        assert len(data) in (8, 9), len(data)
+        ops = [Op(*o[:4], QInterval(*o[4]), *o[5:]) for o in data[5]]
+        if len(data) > 8 and data[8] is not None:
+            raise NotImplementedError('lookup tables are outside the CMVM path')
+        return cls(tuple(data[0]), data[1], data[2], data[3], data[4], ops, data[6], data[7], None)
+
+    @classmethod
+    def load(cls, path: str | Path):
+        with open(path) as f:
+            return cls.deserialize(json.load(f))
+
+    def to_binary(self, version: int = 0) -> np.ndarray:
+        """int32 DAIS program (layout: reference ``docs/dais.md:70-95``, ``types.py:500-541``)."""
+        n_in, n_out = self.shape
+        head = np.concatenate(
+            [[1, version, n_in, n_out, len(self.ops), 0], self.inp_shifts, self.out_idxs, self.out_shifts, self.out_negs]
+        ).astype(np.int32)
+        code = np.zeros((len(self.ops), 8), dtype=np.int32)
+        for i, op in enumerate(self.ops):
+            code[i, 0:3] = (op.opcode, op.id0, op.id1)
+            code[i, 3:5].view(np.uint64)[0] = np.uint64(op.data & 0xFFFFFFFFFFFFFFFF)
+            code[i, 5:8] = minimal_kif(op.qint)
+        return np.concatenate([head, code.ravel()])
+
+    def save_binary(self, path: str | Path, version: int = 0):
+        self.to_binary(version).tofile(str(path))
+
+    def predict(self, data, n_threads: int = 0):
+        """Integer-exact batch execution of the adder graph (the reference routes this to its C++ DAIS
+        interpreter, ``types.py:549-581``); for the add/sub-only graphs of the CMVM path the float64 replay is exact."""
+        data = np.asarray(data, dtype=np.float64).reshape(-1, self.shape[0])
+        return np.asarray(self(data), dtype=np.float64)
+
+
+class Pipeline(NamedTuple):
+    """Cascade of CombLogic stages; ``solve`` returns the two stages ``x @ m0`` then ``@ m1``."""
+
+    solutions: tuple[CombLogic, ...]
+
+    def __call__(self, inp, quantize=False, debug=False):
+        out = np.asarray(inp)
+        for sol in self.solutions:
+            out = sol(out, quantize=quantize, debug=debug)
+        return out
+
+    @property
+    def kernel(self):
+        return reduce(lambda a, b: a @ b, [s.kernel for s in self.solutions])
+
+    @property
+    def cost(self):
+        return sum(s.cost for s in self.solutions)
+
+    @property
+    def n_adders(self) -> int:
+        return sum(s.n_adders for s in self.solutions)
+
+    @property
+    def latency(self):
+        return self.solutions[-1].latency
+
+    @property
+    def inp_qint(self):
+        return self.solutions[0].inp_qint
+
+    @property
+    def inp_latency(self):
+        return self.solutions[0].inp_latency
+
+    @property
+    def out_qint(self):
+        return self.solutions[-1].out_qint
+
+    @property
+    def out_latencies(self):
+        return self.solutions[-1].out_latency
+
+    @property
+    def shape(self):
+        return self.solutions[0].shape[0], self.solutions[-1].shape[1]
+
+    @property
+    def inp_shifts(self):
+        return self.solutions[0].inp_shifts
+
+    @property
+    def out_shift(self):
+        return self.solutions[-1].out_shifts
+
+    @property
+    def out_neg(self):
+        return self.solutions[-1].out_negs
+
+    def __repr__(self):
+        dims = ' -> '.join(str(s.shape[0]) for s in self.solutions) + f' -> {self.shape[1]}'
+        lo, hi = self.latency
+        return f'CascatedSolution([{dims}], cost={self.cost}, latency={lo}-{hi})'
+
+    def save(self, path: str | Path):
+        with open(path, 'w') as f:
+            json.dump(self, f, cls=_Encoder, separators=(',', ':'))
+
+    @classmethod
+    def deserialize(cls, data):
+        return cls(tuple(CombLogic.deserialize(s) for s in data[0]))
+
+    @classmethod
+    def load(cls, path: str | Path):
+        with open(path) as f:
+            return cls.deserialize(json.load(f))
+
+    @property
+    def reg_bits(self):
+        bits = sum(sum(minimal_kif(q)) for q in self.inp_qint)
+        for s in self.solutions:
+            bits += sum(sum(minimal_kif(q)) for q in s.out_qint)
+        return bits

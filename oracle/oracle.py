@@ -1,0 +1,153 @@
+"""ctypes front-end of the CPU oracle -- TEST INFRASTRUCTURE ONLY.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s cpu_baseline leg may import this module;
+the product package ``da4ml_amd`` never does.
+
+Two back-ends share one C ABI shape:
+  * ``Oracle('port')``  -> oracle/liboracle.so   (plain-C++ restatement, prefix ``orc_``)
+  * ``Oracle('ref')``   -> oracle/_ref/libref.so (the real reference sources built against the shim, prefix ``ref_``)
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+from da4ml_amd._marshal import pipeline_from_stages, stage_from_arrays
+
+HERE = Path(__file__).resolve().parent
+_f32p = np.ctypeslib.ndpointer(np.float32, flags='C_CONTIGUOUS')
+_i64p = np.ctypeslib.ndpointer(np.int64, flags='C_CONTIGUOUS')
+_i8p = np.ctypeslib.ndpointer(np.int8, flags='C_CONTIGUOUS')
+_i32p = np.ctypeslib.ndpointer(np.int32, flags='C_CONTIGUOUS')
+
+STAT_NAMES = ('iterations', 'p_init', 'd0', 'f_first', 'f_sum', 'f_max', 'live_sum', 'match_sum', 'regen_pairs', 'tree_ops')
+
+
+def build(targets=('liboracle.so', 'ref')):
+    subprocess.run(['make', '-C', str(HERE), *targets], check=True, stdout=subprocess.DEVNULL)
+
+
+class Oracle:
+    def __init__(self, kind: str = 'port'):
+        self.kind = kind
+        path, self.p = {'port': (HERE / 'liboracle.so', 'orc_'), 'ref': (HERE / '_ref' / 'libref.so', 'ref_')}[kind]
+        if not path.exists():
+            build(('liboracle.so',) if kind == 'port' else ('ref',))
+        if not path.exists():
+            raise FileNotFoundError(f'{path} is not built (kind={kind})')
+        self.lib = L = C.CDLL(str(path))
+        g = lambda n: getattr(L, self.p + n)  # noqa: E731
+        g('last_error').restype = C.c_char_p
+        g('get_lsb_loc').argtypes = [C.c_float]
+        g('iceil_log2').argtypes = [C.c_float]
+        g('cost_add').argtypes = [_f32p, _f32p, C.c_int64, C.c_int, C.c_int, C.c_int, _f32p]
+        g('int_arr_to_csd').argtypes = [_i32p, C.c_int64, C.c_void_p]
+        g('csd_decompose').argtypes = [_f32p, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        g('kernel_decompose').argtypes = [_f32p, C.c_int64, C.c_int64, C.c_int, _f32p, _f32p]
+        g('solve').restype = C.c_void_p
+        g('solve').argtypes = [_f32p, C.c_int64, C.c_int64, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]  # fmt: skip
+        g('n_stages').argtypes = [C.c_void_p]
+        g('picked').argtypes = [C.c_void_p]
+        g('stage_info').argtypes = [C.c_void_p, C.c_int, _i64p]
+        g('stage_copy').argtypes = [C.c_void_p, C.c_int, _i64p, _i64p, _i64p, _i64p, _i64p, _f32p]
+        g('free').argtypes = [C.c_void_p]
+        if kind == 'port':
+            g('solve_single').restype = C.c_void_p
+            g('solve_single').argtypes = [_f32p, C.c_int64, C.c_int64, C.c_char_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+            g('stage_stats').argtypes = [C.c_void_p, C.c_int, _i64p]
+        self.g = g
+
+    # ---- scalar helpers -------------------------------------------------
+    def get_lsb_loc(self, x: float) -> int:
+        return int(self.g('get_lsb_loc')(x))
+
+    def iceil_log2(self, x: float) -> int:
+        return int(self.g('iceil_log2')(x))
+
+    def cost_add(self, q0, q1, shift: int, sub: bool, adder_size: int, carry_size: int):
+        out = np.zeros(2, np.float32)
+        self.g('cost_add')(np.asarray(q0, np.float32), np.asarray(q1, np.float32), shift, int(sub), adder_size, carry_size, out)
+        return float(out[0]), float(out[1])
+
+    # ---- decompositions -------------------------------------------------
+    def int_arr_to_csd(self, x):
+        x = np.ascontiguousarray(x, dtype=np.int32)
+        N = self.g('int_arr_to_csd')(x.ravel(), x.size, None)
+        out = np.zeros(x.shape + (N,), np.int8)
+        self.g('int_arr_to_csd')(x.ravel(), x.size, out.ctypes.data)
+        return out
+
+    def csd_decompose(self, kernel, center: bool = True):
+        k = np.ascontiguousarray(kernel, dtype=np.float32)
+        n_in, n_out = k.shape
+        N = self.g('csd_decompose')(k, n_in, n_out, int(center), None, None, None)
+        csd = np.zeros((n_in, n_out, N), np.int8)
+        s0, s1 = np.zeros(n_in, np.int8), np.zeros(n_out, np.int8)
+        self.g('csd_decompose')(k, n_in, n_out, int(center), csd.ctypes.data, s0.ctypes.data, s1.ctypes.data)
+        return csd, s0, s1
+
+    def kernel_decompose(self, kernel, dc: int = -2):
+        k = np.ascontiguousarray(kernel, dtype=np.float32)
+        n_in, n_out = k.shape
+        m0, m1 = np.zeros((n_in, n_out), np.float32), np.zeros((n_out, n_out), np.float32)
+        self.g('kernel_decompose')(k, n_in, n_out, dc, m0, m1)
+        return m0, m1
+
+    # ---- solve ----------------------------------------------------------
+    def _collect(self, h, stats=False):
+        if not h:
+            raise RuntimeError(self.g('last_error')().decode())
+        try:
+            stages, st = [], []
+            for s in range(self.g('n_stages')(h)):
+                info = np.zeros(5, np.int64)
+                self.g('stage_info')(h, s, info)
+                n_in, n_out, n_ops, carry, adder = (int(v) for v in info)
+                a = [np.zeros(n, np.int64) for n in (n_in, n_out, n_out, n_out)]
+                oi, of = np.zeros((n_ops, 4), np.int64), np.zeros((n_ops, 5), np.float32)
+                self.g('stage_copy')(h, s, *a, oi, of)
+                stages.append(stage_from_arrays(n_in, n_out, *a, oi, of, carry, adder))
+                if stats and self.kind == 'port':
+                    sv = np.zeros(10, np.int64)
+                    self.g('stage_stats')(h, s, sv)
+                    st.append(dict(zip(STAT_NAMES, sv.tolist())))
+            picked = int(self.g('picked')(h))
+        finally:
+            self.g('free')(h)
+        pipe = pipeline_from_stages(stages)
+        return (pipe, st, picked) if stats else pipe
+
+    @staticmethod
+    def _opt(qintervals, latencies, n_in):
+        q = None if qintervals is None else np.ascontiguousarray(np.asarray(qintervals, np.float32).reshape(n_in, 3))
+        l = None if latencies is None else np.ascontiguousarray(np.asarray(latencies, np.float32).reshape(n_in))
+        return q, l
+
+    def solve(self, kernel, method0='wmc', method1='auto', hard_dc=-1, decompose_dc=-2, qintervals=None, latencies=None,
+              adder_size=-1, carry_size=-1, search_all_decompose_dc=True, stats=False):  # fmt: skip
+        k = np.ascontiguousarray(kernel, dtype=np.float32)
+        n_in, n_out = k.shape
+        q, l = self._opt(qintervals, latencies, n_in)
+        h = self.g('solve')(k, n_in, n_out, method0.encode(), method1.encode(), hard_dc, decompose_dc,
+                            None if q is None else q.ctypes.data, None if l is None else l.ctypes.data,
+                            adder_size, carry_size, int(search_all_decompose_dc))  # fmt: skip
+        return self._collect(h, stats)
+
+    def solve_single(self, kernel, method='wmc', qintervals=None, latencies=None, adder_size=-1, carry_size=-1, stats=False):
+        """One greedy chain + adder tree on ``kernel`` (reference cmvm_core.cc:227-237); 'port' only."""
+        k = np.ascontiguousarray(kernel, dtype=np.float32)
+        n_in, n_out = k.shape
+        q, l = self._opt(qintervals, latencies, n_in)
+        h = self.g('solve_single')(k, n_in, n_out, method.encode(), None if q is None else q.ctypes.data,
+                                   None if l is None else l.ctypes.data, adder_size, carry_size)  # fmt: skip
+        r = self._collect(h, stats)
+        return (r[0].solutions[0], r[1][0]) if stats else r.solutions[0]
+
+
+def set_threads(n: int):
+    os.environ['OMP_NUM_THREADS'] = str(n)
