@@ -1,0 +1,264 @@
+"""ctypes binding of ``libda4ml_hip.so`` -- the counterpart of the reference's ``da4ml._binary``
+(src/da4ml/_binary/__init__.py:4-19), which imports the nanobind module ``cmvm_bin``.
+
+Same names, argument meaning, defaults and exception classes as the reference's bindings
+(src/da4ml/_binary/cmvm/bindings.cc:227-264).  There is deliberately no CPU implementation behind these
+functions: if the HIP library or a GPU is missing they raise.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+from types import SimpleNamespace
+
+import numpy as np
+
+from .._marshal import pipeline_from_stages, stage_from_arrays
+
+_LIB_PATH = Path(__file__).resolve().parent.parent / 'libda4ml_hip.so'
+_lib = None
+
+_f32p = np.ctypeslib.ndpointer(np.float32, flags='C_CONTIGUOUS')
+_i64p = np.ctypeslib.ndpointer(np.int64, flags='C_CONTIGUOUS')
+_i32p = np.ctypeslib.ndpointer(np.int32, flags='C_CONTIGUOUS')
+
+EXPORTS = (
+    'da_last_error da_version da_device_count da_set_device da_get_lsb_loc da_iceil_log2 da_cost_add da_int_arr_to_csd '
+    'da_csd_decompose da_kernel_decompose da_solve da_solve_batch da_n_stages da_picked da_stage_info da_stage_copy '
+    'da_result_stats da_free da_timings'
+).split()
+
+
+def lib():
+    """Load (once) and return the C-ABI library; raises ImportError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not _LIB_PATH.exists():
+        raise ImportError(f'{_LIB_PATH} is missing: build it with `python -c "import __graft_entry__ as g; g.build()"` or `make -C da4ml_amd/csrc`')
+    L = C.CDLL(str(_LIB_PATH))
+    L.da_last_error.restype = C.c_char_p
+    L.da_version.restype = C.c_char_p
+    L.da_set_device.argtypes = [C.c_int]
+    L.da_get_lsb_loc.argtypes = [C.c_float]
+    L.da_iceil_log2.argtypes = [C.c_float]
+    L.da_cost_add.argtypes = [_f32p, _f32p, C.c_int64, C.c_int, C.c_int, C.c_int, _f32p]
+    L.da_int_arr_to_csd.argtypes = [_i32p, C.c_int64, C.c_void_p]
+    L.da_csd_decompose.argtypes = [_f32p, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.da_kernel_decompose.argtypes = [_f32p, C.c_int64, C.c_int64, C.c_int, _f32p, _f32p]
+    L.da_solve.restype = C.c_void_p
+    L.da_solve.argtypes = [_f32p, C.c_int64, C.c_int64, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
+    L.da_solve_batch.argtypes = [C.c_int, C.c_void_p, _i64p, _i64p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]  # fmt: skip
+    L.da_n_stages.argtypes = [C.c_void_p]
+    L.da_picked.argtypes = [C.c_void_p]
+    L.da_stage_info.argtypes = [C.c_void_p, C.c_int, _i64p]
+    L.da_stage_copy.argtypes = [C.c_void_p, C.c_int, _i64p, _i64p, _i64p, _i64p, _i64p, _f32p]
+    L.da_result_stats.argtypes = [C.c_void_p, _i64p]
+    L.da_free.argtypes = [C.c_void_p]
+    L.da_timings.argtypes = [np.ctypeslib.ndpointer(np.float64, flags='C_CONTIGUOUS'), C.c_int]
+    _lib = L
+    return L
+
+
+def _raise(rc: int):
+    msg = lib().da_last_error().decode()
+    if rc == -2:
+        raise ValueError(msg)
+    raise RuntimeError(msg)
+
+
+def _kernel(kernel) -> np.ndarray:
+    # the reference binds `kernel` as nb::ndarray<float>.noconvert(): anything but float32 is a TypeError
+    if not isinstance(kernel, np.ndarray) or kernel.dtype != np.float32:
+        raise TypeError('kernel must be a numpy.ndarray of dtype float32 (no implicit conversion)')
+    return np.ascontiguousarray(kernel)
+
+
+def device_count() -> int:
+    return int(lib().da_device_count())
+
+
+def set_device(device: int) -> None:
+    if lib().da_set_device(int(device)) != 0:
+        _raise(-1)
+
+
+def get_lsb_loc(x: float) -> int:
+    return int(lib().da_get_lsb_loc(float(x)))
+
+
+def iceil_log2(x: float) -> int:
+    return int(lib().da_iceil_log2(float(x)))
+
+
+def cost_add(q0, q1, shift: int, sub: bool, adder_size: int, carry_size: int) -> tuple[float, float]:
+    out = np.zeros(2, np.float32)
+    lib().da_cost_add(np.asarray(q0, np.float32), np.asarray(q1, np.float32), int(shift), int(bool(sub)), int(adder_size), int(carry_size), out)
+    return float(out[0]), float(out[1])
+
+
+def int_arr_to_csd(inp) -> np.ndarray:
+    if not isinstance(inp, np.ndarray) or inp.dtype != np.int32:
+        raise TypeError('inp must be a numpy.ndarray of dtype int32 (no implicit conversion)')
+    x = np.ascontiguousarray(inp)
+    N = lib().da_int_arr_to_csd(x.ravel(), x.size, None)
+    if N < 0:
+        _raise(N)
+    out = np.zeros(x.shape + (N,), np.int8)
+    rc = lib().da_int_arr_to_csd(x.ravel(), x.size, out.ctypes.data)
+    if rc < 0:
+        _raise(rc)
+    return out
+
+
+def csd_decompose(inp, center: bool = True):
+    k = _kernel(inp)
+    if k.ndim != 2:
+        raise RuntimeError('csd_decompose only supports 2D arrays.')
+    n_in, n_out = k.shape
+    N = lib().da_csd_decompose(k, n_in, n_out, int(center), None, None, None)
+    if N < 0:
+        _raise(N)
+    csd = np.zeros((n_in, n_out, N), np.int8)
+    s0, s1 = np.zeros(n_in, np.int8), np.zeros(n_out, np.int8)
+    rc = lib().da_csd_decompose(k, n_in, n_out, int(center), csd.ctypes.data, s0.ctypes.data, s1.ctypes.data)
+    if rc < 0:
+        _raise(rc)
+    return csd, s0, s1
+
+
+def kernel_decompose(kernel, dc: int = -2):
+    k = _kernel(kernel)
+    if k.ndim != 2:
+        raise RuntimeError('csd_decompose only supports 2D arrays.')
+    n_in, n_out = k.shape
+    m0, m1 = np.zeros((n_in, n_out), np.float32), np.zeros((n_out, n_out), np.float32)
+    rc = lib().da_kernel_decompose(k, n_in, n_out, int(dc), m0, m1)
+    if rc < 0:
+        _raise(rc)
+    return m0, m1
+
+
+def _collect(h, with_stats=False):
+    L = lib()
+    try:
+        stages = []
+        for s in range(L.da_n_stages(h)):
+            info = np.zeros(5, np.int64)
+            L.da_stage_info(h, s, info)
+            n_in, n_out, n_ops, carry, adder = (int(v) for v in info)
+            arr = [np.zeros(n, np.int64) for n in (n_in, n_out, n_out, n_out)]
+            oi, of = np.zeros((n_ops, 4), np.int64), np.zeros((n_ops, 5), np.float32)
+            L.da_stage_copy(h, s, *arr, oi, of)
+            stages.append(stage_from_arrays(n_in, n_out, *arr, oi, of, carry, adder))
+        pipe = pipeline_from_stages(stages)
+        if not with_stats:
+            return pipe
+        st = np.zeros(8, np.int64)
+        L.da_result_stats(h, st)
+        names = ('iterations', 'digits0', 'blocks0', 'select_rounds', 'table_peak', 'scan_slots', 'partners', 'matches')
+        return pipe, dict(zip(names, st.tolist()), picked=int(L.da_picked(h)))
+    finally:
+        L.da_free(h)
+
+
+def _opt_arrays(qintervals, latencies, n_in):
+    q = l = None
+    if qintervals is not None:
+        q = np.ascontiguousarray(np.asarray([tuple(float(v) for v in t) for t in qintervals], np.float32).reshape(n_in, 3))
+    if latencies is not None:
+        l = np.ascontiguousarray(np.asarray([float(v) for v in latencies], np.float32).reshape(n_in))
+    return q, l
+
+
+def solve(
+    kernel,
+    method0: str = 'wmc',
+    method1: str = 'auto',
+    hard_dc: int = -1,
+    decompose_dc: int = -2,
+    qintervals=None,
+    latencies=None,
+    adder_size: int = -1,
+    carry_size: int = -1,
+    search_all_decompose_dc: bool = True,
+    _stats: bool = False,
+):
+    """Optimise ``x @ kernel`` into a two-stage shift-add adder graph (reference ``cmvm_bin.solve``)."""
+    k = _kernel(kernel)
+    if k.ndim != 2:
+        raise RuntimeError('csd_decompose only supports 2D arrays.')
+    n_in, n_out = k.shape
+    q, l = _opt_arrays(qintervals, latencies, n_in)
+    h = lib().da_solve(k, n_in, n_out, method0.encode(), method1.encode(), int(hard_dc), int(decompose_dc),
+                       None if q is None else q.ctypes.data, None if l is None else l.ctypes.data,
+                       int(adder_size), int(carry_size), int(bool(search_all_decompose_dc)))  # fmt: skip
+    if not h:
+        _raise(-2 if 'must' in lib().da_last_error().decode() else -1)
+    return _collect(h, _stats)
+
+
+def solve_many(
+    kernels,
+    method0: str = 'wmc',
+    method1: str = 'auto',
+    hard_dc: int = -1,
+    decompose_dc: int = -2,
+    qintervals=None,
+    latencies=None,
+    adder_size: int = -1,
+    carry_size: int = -1,
+    search_all_decompose_dc: bool = True,
+    _stats: bool = False,
+):
+    """Solve independent matrices concurrently on the GPU (addition to the reference API; same options as ``solve``).
+
+    ``qintervals`` / ``latencies`` are ``None`` or per-kernel lists (entries may be ``None``).
+    """
+    ks = [_kernel(k) for k in kernels]
+    n = len(ks)
+    if n == 0:
+        return []
+    n_in = np.array([k.shape[0] for k in ks], np.int64)
+    n_out = np.array([k.shape[1] for k in ks], np.int64)
+    kptr = (C.c_void_p * n)(*[k.ctypes.data for k in ks])
+    keep, qptr, lptr = [], None, None
+    if qintervals is not None or latencies is not None:
+        qs, ls = [], []
+        for i in range(n):
+            q, l = _opt_arrays(None if qintervals is None else qintervals[i], None if latencies is None else latencies[i], int(n_in[i]))
+            keep += [q, l]
+            qs.append(None if q is None else q.ctypes.data)
+            ls.append(None if l is None else l.ctypes.data)
+        qptr, lptr = (C.c_void_p * n)(*qs), (C.c_void_p * n)(*ls)
+    res = (C.c_void_p * n)()
+    rc = lib().da_solve_batch(n, kptr, n_in, n_out, method0.encode(), method1.encode(), int(hard_dc), int(decompose_dc), qptr, lptr,
+                              int(adder_size), int(carry_size), int(bool(search_all_decompose_dc)), res)  # fmt: skip
+    if rc != 0:
+        _raise(rc)
+    return [_collect(res[i], _stats) for i in range(n)]
+
+
+def timings(reset: bool = False) -> dict:
+    """Accumulated device-side timings / counters of the greedy loops (benchmark instrumentation)."""
+    t = np.zeros(10, np.float64)
+    rc = lib().da_timings(t, int(reset))
+    if rc != 0:
+        _raise(rc)
+    names = ('loop_ms', 'dist_ms', 'total_ms', 'lockstep_iters', 'iterations', 'rescans', 'partners', 'chains', 'table_bytes', 'arena_bytes')
+    return dict(zip(names, t.tolist()))
+
+
+def dais_interp_run(bin_logic, data, n_threads: int = 1):
+    """The DAIS interpreter (reference ``dais_bin.run_interp``) is outside the CMVM path; use ``CombLogic.predict``."""
+    raise NotImplementedError('da4ml_amd implements the CMVM solver path only; use CombLogic.predict / __call__ to execute a solution')
+
+
+# the reference exposes the raw extension module as `da4ml._binary.cmvm_bin` (imported by trace/fixed_variable.py:15)
+cmvm_bin = SimpleNamespace(
+    solve=solve, kernel_decompose=kernel_decompose, csd_decompose=csd_decompose, int_arr_to_csd=int_arr_to_csd,
+    get_lsb_loc=get_lsb_loc, iceil_log2=iceil_log2, cost_add=cost_add,
+)  # fmt: skip
+
+__all__ = ['dais_interp_run', 'int_arr_to_csd', 'csd_decompose', 'get_lsb_loc', 'kernel_decompose', 'solve', 'iceil_log2', 'solve_many', 'cost_add']

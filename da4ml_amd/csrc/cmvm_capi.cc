@@ -1,0 +1,215 @@
+// cmvm_capi.cc -- the C ABI of libda4ml_hip.so (declared in include/da4ml_hip.h).
+// Every compute entry point goes through the HIP backend; there is no CPU fallback: without a usable
+// device the calls fail with DA_ERR_NO_DEVICE / NULL and a message.
+
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/da4ml_hip.h"
+#include "cmvm_gpu.h"
+#include "cmvm_host.h"
+
+namespace {
+
+thread_local std::string g_err;
+std::mutex g_mutex;
+int g_device = 0;
+std::unique_ptr<da::gpu::HipBackend> g_backend;
+int g_backend_device = -1;
+
+da::gpu::HipBackend &backend() {
+    if (!g_backend || g_backend_device != g_device) {
+        if (da::gpu::device_count() <= g_device) throw std::runtime_error("no HIP device " + std::to_string(g_device) + " available (libda4ml_hip has no CPU path)");
+        g_backend.reset(new da::gpu::HipBackend(g_device));
+        g_backend_device = g_device;
+    }
+    return *g_backend;
+}
+
+int fail(const std::exception &e) {
+    g_err = e.what();
+    if (dynamic_cast<const std::invalid_argument *>(&e)) return DA_ERR_VALUE;
+    if (g_err.rfind("no HIP device", 0) == 0) return DA_ERR_NO_DEVICE;
+    return DA_ERR_RUNTIME;
+}
+
+void check_dyadic_steps(const float *q, int64_t n_in) {
+    if (!q) return;
+    for (int64_t i = 0; i < n_in; ++i) {
+        float lo = q[3 * i], hi = q[3 * i + 1], st = q[3 * i + 2];
+        if (lo == 0.0f && hi == 0.0f) continue;  // constant-zero input: its digits are dropped, the step is never used
+        uint32_t b;
+        std::memcpy(&b, &st, 4);
+        bool pow2 = (b >> 31) == 0 && (b & 0x7FFFFFu) == 0 && ((b >> 23) & 0xFF) != 0 && ((b >> 23) & 0xFF) != 255;
+        if (!pow2) throw std::invalid_argument("qintervals[" + std::to_string(i) + "].step must be a positive power of two");
+    }
+}
+
+}  // namespace
+
+struct da_result {
+    da::PipeResult pipe;
+    da::ChainStats stats;
+};
+
+extern "C" {
+
+const char *da_last_error(void) { return g_err.c_str(); }
+const char *da_version(void) { return "da4ml_hip 0.1 (gfx950)"; }
+int da_device_count(void) { return da::gpu::device_count(); }
+int da_set_device(int device) {
+    std::lock_guard<std::mutex> lk(g_mutex);
+    if (device < 0 || device >= da::gpu::device_count()) {
+        g_err = "invalid device index " + std::to_string(device);
+        return DA_ERR_NO_DEVICE;
+    }
+    g_device = device;
+    return DA_OK;
+}
+
+int da_get_lsb_loc(float x) { return da::lsb_loc(x); }
+int da_iceil_log2(float x) { return da::iceil_log2(x); }
+int da_cost_add(const float *q0, const float *q1, int64_t shift, int sub, int adder_size, int carry_size, float *out2) {
+    da::cost_add(da::QInt{q0[0], q0[1], q0[2]}, da::QInt{q1[0], q1[1], q1[2]}, shift, sub != 0, adder_size, carry_size, out2[0], out2[1]);
+    return DA_OK;
+}
+
+int da_int_arr_to_csd(const int32_t *x, int64_t n, int8_t *out) {
+    std::lock_guard<std::mutex> lk(g_mutex);
+    try {
+        std::vector<int8_t> csd;
+        int N = backend().int_to_csd(x, n, csd);
+        if (out) std::memcpy(out, csd.data(), csd.size());
+        return N;
+    } catch (const std::exception &e) {
+        return fail(e);
+    }
+}
+
+int da_csd_decompose(const float *kernel, int64_t n_in, int64_t n_out, int center, int8_t *csd, int8_t *shift0, int8_t *shift1) {
+    std::lock_guard<std::mutex> lk(g_mutex);
+    try {
+        std::vector<int8_t> c, a, b;
+        int N = backend().csd_decompose(kernel, (int)n_in, (int)n_out, center != 0, c, a, b);
+        if (csd) std::memcpy(csd, c.data(), c.size());
+        if (shift0) std::memcpy(shift0, a.data(), a.size());
+        if (shift1) std::memcpy(shift1, b.data(), b.size());
+        return N;
+    } catch (const std::exception &e) {
+        return fail(e);
+    }
+}
+
+int da_kernel_decompose(const float *kernel, int64_t n_in, int64_t n_out, int dc, float *m0, float *m1) {
+    std::lock_guard<std::mutex> lk(g_mutex);
+    try {
+        std::vector<float> a, b;
+        da::kernel_decompose(backend(), kernel, (int)n_in, (int)n_out, dc, a, b);
+        std::memcpy(m0, a.data(), a.size() * 4);
+        std::memcpy(m1, b.data(), b.size() * 4);
+        return DA_OK;
+    } catch (const std::exception &e) {
+        return fail(e);
+    }
+}
+
+int da_solve_batch(int count, const float *const *kernels, const int64_t *n_in, const int64_t *n_out, const char *method0,
+                   const char *method1, int hard_dc, int decompose_dc, const float *const *qintervals,
+                   const float *const *latencies, int adder_size, int carry_size, int search_all_decompose_dc,
+                   da_result **results) {
+    std::lock_guard<std::mutex> lk(g_mutex);
+    try {
+        std::vector<da::Problem> probs((size_t)count);
+        for (int i = 0; i < count; ++i) {
+            da::Problem &p = probs[i];
+            p.kernel = kernels[i];
+            p.n_in = (int)n_in[i];
+            p.n_out = (int)n_out[i];
+            if (p.n_in <= 0 || p.n_out <= 0) throw std::invalid_argument("kernel must be a non-empty 2-D matrix");
+            p.opt.method0 = method0;
+            p.opt.method1 = method1;
+            p.opt.hard_dc = hard_dc;
+            p.opt.decompose_dc = decompose_dc;
+            const float *q = qintervals ? qintervals[i] : nullptr;
+            const float *l = latencies ? latencies[i] : nullptr;
+            check_dyadic_steps(q, p.n_in);
+            if (q)
+                for (int r = 0; r < p.n_in; ++r) p.opt.qints.push_back(da::QInt{q[3 * r], q[3 * r + 1], q[3 * r + 2]});
+            if (l) p.opt.lats.assign(l, l + p.n_in);
+            p.opt.adder_size = adder_size;
+            p.opt.carry_size = carry_size;
+            p.opt.search_all = search_all_decompose_dc != 0;
+        }
+        std::vector<da::ChainStats> stats;
+        std::vector<da::PipeResult> res = da::solve_batch(backend(), probs, &stats);
+        for (int i = 0; i < count; ++i) results[i] = new da_result{std::move(res[i]), i < (int)stats.size() ? stats[i] : da::ChainStats{}};
+        return DA_OK;
+    } catch (const std::exception &e) {
+        return fail(e);
+    }
+}
+
+da_result *da_solve(const float *kernel, int64_t n_in, int64_t n_out, const char *method0, const char *method1, int hard_dc,
+                    int decompose_dc, const float *qintervals, const float *latencies, int adder_size, int carry_size,
+                    int search_all_decompose_dc) {
+    da_result *r = nullptr;
+    const float *q[1] = {qintervals}, *l[1] = {latencies};
+    int rc = da_solve_batch(1, &kernel, &n_in, &n_out, method0, method1, hard_dc, decompose_dc, qintervals ? q : nullptr,
+                            latencies ? l : nullptr, adder_size, carry_size, search_all_decompose_dc, &r);
+    return rc == DA_OK ? r : nullptr;
+}
+
+int da_n_stages(const da_result *r) { return (int)r->pipe.stages.size(); }
+int da_picked(const da_result *r) { return r->pipe.picked; }
+int da_stage_info(const da_result *r, int stage, int64_t *info) {
+    const da::StageResult &s = r->pipe.stages[stage];
+    info[0] = s.n_in;
+    info[1] = s.n_out;
+    info[2] = (int64_t)s.ops.size();
+    info[3] = s.carry_size;
+    info[4] = s.adder_size;
+    return DA_OK;
+}
+int da_stage_copy(const da_result *r, int stage, int64_t *inp_shifts, int64_t *out_idxs, int64_t *out_shifts, int64_t *out_negs,
+                  int64_t *ops_i, float *ops_f) {
+    const da::StageResult &s = r->pipe.stages[stage];
+    std::memcpy(inp_shifts, s.inp_shifts.data(), s.inp_shifts.size() * 8);
+    std::memcpy(out_idxs, s.out_idxs.data(), s.out_idxs.size() * 8);
+    std::memcpy(out_shifts, s.out_shifts.data(), s.out_shifts.size() * 8);
+    std::memcpy(out_negs, s.out_negs.data(), s.out_negs.size() * 8);
+    for (size_t k = 0; k < s.ops.size(); ++k) {
+        const da::OpRec &o = s.ops[k];
+        int64_t *oi = ops_i + 4 * k;
+        float *of = ops_f + 5 * k;
+        oi[0] = o.id0, oi[1] = o.id1, oi[2] = o.opcode, oi[3] = o.data;
+        of[0] = o.q.lo, of[1] = o.q.hi, of[2] = o.q.step, of[3] = o.latency, of[4] = o.cost;
+    }
+    return DA_OK;
+}
+int da_result_stats(const da_result *r, int64_t *s) {
+    const da::ChainStats &t = r->stats;
+    int64_t v[8] = {t.iterations, t.digits0, t.blocks0, t.rebuilds, t.table_peak, t.scan_slots, t.partners, t.matches};
+    std::memcpy(s, v, sizeof v);
+    return DA_OK;
+}
+void da_free(da_result *r) { delete r; }
+
+int da_timings(double *t, int reset) {
+    std::lock_guard<std::mutex> lk(g_mutex);
+    try {
+        da::gpu::HipBackend &be = backend();
+        const da::gpu::GpuTimings &g = be.timings();
+        double v[10] = {g.loop_ms,          g.dist_ms,         g.total_ms,         (double)g.lockstep_iters, (double)g.iterations,
+                        (double)g.rescans, (double)g.partners, (double)g.chains, g.table_bytes,            g.arena_bytes};
+        std::memcpy(t, v, sizeof v);
+        if (reset) be.reset_timings();
+        return DA_OK;
+    } catch (const std::exception &e) {
+        return fail(e);
+    }
+}
+
+}  // extern "C"

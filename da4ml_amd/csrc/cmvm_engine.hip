@@ -1,0 +1,1367 @@
+// cmvm_engine.hip -- hand-written HIP kernels (gfx950 / CDNA4, wave64) for the CMVM greedy engine and
+// the HIP implementation of da::Backend.  No CUDA compatibility layer, no dual paths: this file only
+// targets MI355X.
+//
+// Reference loops replaced:
+//   k_prepare        _center + global digit width            bit_decompose.hh:25-34, bit_decompose.cc:22-27
+//   k_init_cells     CSD recoding + SparseExpr build          bit_decompose.cc:28-42, state_opr.cc:93-112
+//   k_init_pairs     all-pairs enumeration / FreqMap::initialize   state_opr.cc:117-143, types.hh:73-100
+//   k_iter_select    idx_mc / idx_mc_dc / idx_wmc / idx_wmc_dc + update_expr   indexers.cc:6-90, state_opr.cc:227-283
+//   k_iter_update    update_stats (purge + regenerate) as an exact incremental update   state_opr.cc:285-345
+//   k_extract        digit gather of to_solution             cmvm_core.cc:103-113
+//   k_col_dist       stage-1 CSD Hamming distances           mat_decompose.cc:75-93
+//
+// Data layout in HBM, per chain (all arrays carved from one arena, see HipBackend::run_group):
+//   cells   [rcap][n_out]  Cell    digits of (row, column) as two position bitmasks (cmvm_core.h)
+//   rows    [rcap]         RowInfo interval + latency of every row
+//   collist [n_out][lcap]  u32     ascending ids of rows that have (had) digits in a column
+//   table   C slots (power of two), open addressing on (id0,id1):
+//             hkey[C] u64, hrank[C] u32 (selection rank of the block's best key, 0 = none), hidx[C] u8,
+//             hstat[C] {n_overlap, |dlat|}, hcnt[C][Kpad] u16 exact occurrence counts of all keys
+//   ub      [C / GS]       u64     upper bound of (rank << 32 | tie_word >> 23) over a group of GS consecutive slots
+//
+// The reference keeps a sorted table of all pairs with count >= 2, purges every entry touching the two
+// substituted rows and regenerates their pairs against ALL rows every iteration.  Here the counts are
+// maintained exactly by subtracting, for every "partner" row that shares a substituted column, the pair
+// occurrences of the consumed digits, and by creating the blocks of the new row -- O(consumed digits x
+// column population) instead of O(row digits x all rows) per iteration.  Selection never scans the table:
+// it keeps per-group upper bounds of the rank, which only ever need tightening for the top groups.
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <numeric>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "cmvm_core.h"
+#include "cmvm_gpu.h"
+#include "cmvm_host.h"
+
+namespace da {
+namespace gpu {
+
+#define HIP_CHECK(expr)                                                                                          \
+    do {                                                                                                         \
+        hipError_t _e = (expr);                                                                                  \
+        if (_e != hipSuccess)                                                                                    \
+            throw std::runtime_error(std::string("HIP error: ") + hipGetErrorString(_e) + " at " #expr);         \
+    } while (0)
+
+constexpr uint64_t KEY_EMPTY = ~0ull;
+constexpr uint64_t KEY_TOMB = ~0ull - 1;
+constexpr int WAVE = 64;
+constexpr int SEL_THREADS = 1024;  // k_iter_select block (16 waves)
+constexpr int UPD_THREADS = 256;   // k_iter_update block
+constexpr int UPD_WAVES = UPD_THREADS / WAVE;
+constexpr int MAX_GROUPS = 8192;   // ub[] copy held in LDS by k_iter_select (64 KiB of u64)
+constexpr int UNIT = 256;          // list entries per update work unit
+
+struct HStat {
+    int ov;
+    float dl;
+};
+
+// Per-chain descriptor in device memory.  Pointers are raw device addresses into the arena.
+struct ChainDev {
+    // geometry (constant after set-up)
+    int n_in, n_out, n_bits, K, Kpad, method, adder_size, carry_size;
+    int rcap, lcap, gs_log2, n_groups;
+    uint32_t C, cmask;
+    // inputs
+    const float *kernel;
+    const float *qints;
+    const float *lats;
+    int32_t *xint;  // centred integer matrix [n_in][n_out]
+    int8_t *shift0, *shift1;
+    // state
+    void *cells;
+    RowInfo *rows;
+    uint32_t *stamp;
+    uint32_t *collist;
+    int *collen;
+    unsigned long long *hkey;
+    uint32_t *hrank;
+    uint8_t *hidx;
+    HStat *hstat;
+    uint16_t *hcnt;
+    unsigned long long *ub;
+    // per-iteration hand-off select -> update
+    int *mcol;
+    void *mA, *mB;
+    int *unit_off;
+    int m, n_units;
+    unsigned int work_ctr;
+    uint32_t A, B, Nw;
+    // progress
+    int n_rows, iter, done, error, unknown_hit;
+    unsigned int n_live, n_used, live_peak;
+    int4 *picks;
+    // results of k_prepare
+    int prep_nbits, prep_maxdcol;
+    long long prep_digits, prep_pairs;
+    // extraction
+    uint32_t *fin_row;
+    unsigned long long *fin_cell;
+    uint32_t *fin_count;
+    // statistics
+    unsigned long long st_rescans, st_partners, st_matches, st_rounds;
+};
+
+__constant__ Log2Table c_log2;
+
+// ------------------------------------------------------------------------------------------------ wave helpers
+__device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE - 1); }
+__device__ __forceinline__ int wave_id() { return threadIdx.x / WAVE; }
+
+__device__ __forceinline__ int wave_min_i32(int v) {
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+    for (int o = 32; o > 0; o >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, o));
+    return v;
+}
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+    for (int o = 32; o > 0; o >>= 1) {
+        unsigned long long t = __shfl_xor(v, o);
+        v = t > v ? t : v;
+    }
+    return v;
+}
+__device__ __forceinline__ long long wave_sum_i64(long long v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ void lds_fence() { __threadfence_block(); }
+
+__device__ __forceinline__ uint32_t hash_pair(uint32_t lo, uint32_t hi) {
+    unsigned long long k = ((unsigned long long)hi << 32) | lo;
+    k ^= k >> 33;
+    k *= 0xff51afd7ed558ccdULL;
+    k ^= k >> 33;
+    k *= 0xc4ceb9fe1a85ec53ULL;
+    k ^= k >> 33;
+    return (uint32_t)k;
+}
+__device__ __forceinline__ unsigned long long pack_pair(uint32_t lo, uint32_t hi) {
+    return ((unsigned long long)hi << 32) | lo;
+}
+// group bound word: selection rank in the high half, the 32 most significant bits of the tie word below it, so
+// that among equal ranks only groups holding the newest rows have to be inspected
+__device__ __forceinline__ unsigned long long bound_word(uint32_t rank, unsigned long long tie) {
+    return ((unsigned long long)rank << 32) | (tie >> 23);
+}
+
+// ------------------------------------------------------------------------------------------------ table ops
+// All table operations are executed by one full wavefront; lane order == probe order inside a 64-slot window.
+
+// returns slot or -1
+__device__ int table_find(const ChainDev &ch, unsigned long long key, uint32_t h) {
+    int lane = lane_id();
+    uint32_t windows = ch.C / WAVE ? ch.C / WAVE : 1;
+    for (uint32_t w = 0; w < windows; ++w) {
+        uint32_t s = (h + w * WAVE + lane) & ch.cmask;
+        unsigned long long kk = ch.hkey[s];
+        unsigned long long hit = __ballot(kk == key);
+        unsigned long long emp = __ballot(kk == KEY_EMPTY);
+        if (hit) {
+            int l = __ffsll((long long)hit) - 1;
+            if (emp && (__ffsll((long long)emp) - 1) < l) return -1;
+            return (int)((h + w * WAVE + l) & ch.cmask);
+        }
+        if (emp) return -1;
+    }
+    return -1;
+}
+
+// claim a slot for a key that is known to be absent; returns slot or -1 (table full)
+__device__ int table_claim(ChainDev &ch, unsigned long long key, uint32_t h) {
+    int lane = lane_id();
+    uint32_t windows = ch.C / WAVE ? ch.C / WAVE : 1;
+    for (uint32_t w = 0; w < windows; ++w) {
+        uint32_t s = (h + w * WAVE + lane) & ch.cmask;
+        unsigned long long kk = ch.hkey[s];
+        unsigned long long avail = __ballot(kk == KEY_EMPTY || kk == KEY_TOMB);
+        while (avail) {
+            int l = __ffsll((long long)avail) - 1;
+            avail &= avail - 1;
+            int ok = 0;
+            if (lane == l) {
+                ok = atomicCAS(&ch.hkey[s], kk, key) == kk;
+                if (ok && kk == KEY_EMPTY) atomicAdd(&ch.n_used, 1u);
+            }
+            ok = __shfl(ok, l);
+            if (ok) return (int)((h + w * WAVE + l) & ch.cmask);
+        }
+    }
+    return -1;
+}
+
+// Store a complete block.  cnt_of(k) gives the count of key k; returns false when the table is full.
+// Precondition: at least one count >= 2 (checked by the caller), key absent.
+template <class CntFn>
+__device__ bool table_insert(ChainDev &ch, uint32_t lo, uint32_t hi, CntFn cnt_of) {
+    int lane = lane_id();
+    unsigned long long key = pack_pair(lo, hi);
+    int slot = table_claim(ch, key, hash_pair(lo, hi));
+    if (slot < 0) {
+        if (lane == 0) ch.error = E_TABLE_CAPACITY;
+        return false;
+    }
+    RowInfo ra = ch.rows[lo], rb = ch.rows[hi];
+    int ov = n_overlap(ra, rb);
+    float dl = fabsf(ra.lat - rb.lat);
+    unsigned long long best = 0;
+    for (int k = lane; k < ch.Kpad; k += WAVE) {
+        uint32_t c = k < ch.K ? cnt_of(k) : 0u;
+        if (c > 65535u) ch.error = E_COUNT_OVERFLOW;
+        ch.hcnt[(size_t)slot * ch.Kpad + k] = (uint16_t)c;
+        uint32_t r = entry_rank(c, ov, dl, ch.method);
+        unsigned long long cand = r ? (((unsigned long long)r << 8) | (unsigned)k) : 0ull;
+        best = cand > best ? cand : best;
+    }
+    best = wave_max_u64(best);
+    if (lane == 0) {
+        uint32_t rank = (uint32_t)(best >> 8);
+        ch.hstat[slot] = HStat{ov, dl};
+        ch.hrank[slot] = rank;
+        ch.hidx[slot] = (uint8_t)(best & 0xFF);
+        if (rank) atomicMax(&ch.ub[slot >> ch.gs_log2], bound_word(rank, tie_word(lo, hi, (int)(best & 0xFF))));
+        unsigned int live = atomicAdd(&ch.n_live, 1u) + 1;
+        atomicMax(&ch.live_peak, live);
+    }
+    return true;
+}
+
+// Re-evaluate a block after its counts changed (new_cnt(k, old) -> new count); deletes it when no count >= 2.
+template <class CntFn>
+__device__ void table_update(ChainDev &ch, int slot, CntFn new_cnt) {
+    int lane = lane_id();
+    HStat st = ch.hstat[slot];
+    unsigned long long best = 0;
+    int alive = 0;
+    for (int k = lane; k < ch.K; k += WAVE) {
+        uint32_t old = ch.hcnt[(size_t)slot * ch.Kpad + k];
+        uint32_t c = new_cnt(k, old);
+        if (c != old) ch.hcnt[(size_t)slot * ch.Kpad + k] = (uint16_t)c;
+        alive |= c >= 2;
+        uint32_t r = entry_rank(c, st.ov, st.dl, ch.method);
+        unsigned long long cand = r ? (((unsigned long long)r << 8) | (unsigned)k) : 0ull;
+        best = cand > best ? cand : best;
+    }
+    best = wave_max_u64(best);
+    alive = __any(alive);
+    if (lane == 0) {
+        if (!alive) {
+            ch.hrank[slot] = 0;
+            ch.hkey[slot] = KEY_TOMB;
+            atomicSub(&ch.n_live, 1u);
+        } else {
+            uint32_t rank = (uint32_t)(best >> 8);
+            uint32_t prev = ch.hrank[slot];
+            ch.hrank[slot] = rank;
+            ch.hidx[slot] = (uint8_t)(best & 0xFF);
+            if (rank > prev) {
+                unsigned long long kk = ch.hkey[slot];
+                atomicMax(&ch.ub[slot >> ch.gs_log2], bound_word(rank, tie_word((uint32_t)kk, (uint32_t)(kk >> 32), (int)(best & 0xFF))));
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ k_prepare
+// One block per chain: centring shifts, centred integer matrix, digit width, digit statistics.
+__global__ void __launch_bounds__(256) k_prepare(ChainDev *chains) {
+    ChainDev &ch = chains[blockIdx.x];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int *s_dcol = reinterpret_cast<int *>(smem);  // [n_out]
+    __shared__ unsigned int s_max;
+    __shared__ unsigned long long s_digits, s_pairs;
+    __shared__ int s_maxd;
+    const int n_in = ch.n_in, n_out = ch.n_out;
+    const float *k = ch.kernel;
+    if (threadIdx.x == 0) {
+        s_max = 0;
+        s_digits = 0;
+        s_pairs = 0;
+        s_maxd = 0;
+    }
+    for (int j = threadIdx.x; j < n_out; j += blockDim.x) {
+        int low = 127;
+        for (int i = 0; i < n_in; ++i) low = min(low, lsb_loc(k[(size_t)i * n_out + j]));
+        ch.shift1[j] = (int8_t)low;
+        s_dcol[j] = 0;
+    }
+    __syncthreads();
+    int nw = blockDim.x / WAVE;
+    for (int i = wave_id(); i < n_in; i += nw) {
+        int low = 127;
+        for (int j = lane_id(); j < n_out; j += WAVE) low = min(low, lsb_loc(ldexpf(k[(size_t)i * n_out + j], -(int)ch.shift1[j])));
+        low = wave_min_i32(low);
+        if (lane_id() == 0) ch.shift0[i] = (int8_t)low;
+        bool dead = ch.qints[3 * i] == 0.0f && ch.qints[3 * i + 1] == 0.0f;
+        unsigned int mx = 0;
+        for (int j = lane_id(); j < n_out; j += WAVE) {
+            float v = ldexpf(ldexpf(k[(size_t)i * n_out + j], -(int)ch.shift1[j]), -low);
+            int32_t x = (int32_t)v;
+            ch.xint[(size_t)i * n_out + j] = x;
+            mx = max(mx, (unsigned int)(x < 0 ? -x : x));
+            if (!dead && x != 0) atomicAdd(&s_dcol[j], naf_weight(x));
+        }
+        mx = wave_max_u32(mx);
+        if (lane_id() == 0) atomicMax(&s_max, mx);
+    }
+    __syncthreads();
+    unsigned long long dig = 0, pairs = 0;
+    int maxd = 0;
+    for (int j = threadIdx.x; j < n_out; j += blockDim.x) {
+        int d = s_dcol[j];
+        dig += d;
+        pairs += (unsigned long long)d * (d > 0 ? d - 1 : 0) / 2;
+        maxd = max(maxd, d);
+    }
+    atomicAdd(&s_digits, dig);
+    atomicAdd(&s_pairs, pairs);
+    atomicMax(&s_maxd, maxd);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        ch.prep_nbits = csd_width(s_max);
+        ch.prep_digits = (long long)s_digits;
+        ch.prep_pairs = (long long)s_pairs;
+        ch.prep_maxdcol = s_maxd;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ k_init_cells
+// grid (ceil(n_out / 4), n_chains): one wave per column builds the cells of that column and its row list.
+template <class Cell> __global__ void __launch_bounds__(256) k_init_cells(ChainDev *chains) {
+    using O = CellOps<Cell>;
+    ChainDev &ch = chains[blockIdx.y];
+    int j = blockIdx.x * (blockDim.x / WAVE) + wave_id();
+    if (j >= ch.n_out) return;
+    Cell *cells = reinterpret_cast<Cell *>(ch.cells);
+    int lane = lane_id(), len = 0;
+    for (int base = 0; base < ch.n_in; base += WAVE) {
+        int i = base + lane;
+        Cell c = 0;
+        if (i < ch.n_in) {
+            bool dead = ch.qints[3 * i] == 0.0f && ch.qints[3 * i + 1] == 0.0f;
+            uint32_t p, m;
+            naf_masks(ch.xint[(size_t)i * ch.n_out + j], p, m);
+            c = dead ? (Cell)0 : O::make(p, m);
+            cells[(size_t)i * ch.n_out + j] = c;
+        }
+        unsigned long long nz = __ballot(c != 0);
+        if (c != 0) ch.collist[(size_t)j * ch.lcap + len + __popcll(nz & ((1ull << lane) - 1))] = (uint32_t)i;
+        len += __popcll(nz);
+    }
+    if (lane == 0) ch.collen[j] = len;
+    if (j == 0)
+        for (int i = lane; i < ch.n_in; i += WAVE)
+            ch.rows[i] = RowInfo{ch.qints[3 * i], ch.qints[3 * i + 1], ch.qints[3 * i + 2], ch.lats[i]};
+}
+
+// exact pair counts of one row pair over all columns into LDS counters (one wave)
+template <class Cell>
+__device__ __forceinline__ void count_row_pair(const ChainDev &ch, const Cell *cells, uint32_t lo, uint32_t hi, uint32_t *cnt) {
+    int lane = lane_id();
+    for (int k = lane; k < ch.Kpad; k += WAVE) cnt[k] = 0;
+    lds_fence();
+    const Cell *rl = cells + (size_t)lo * ch.n_out, *rh = cells + (size_t)hi * ch.n_out;
+    for (int j = lane; j < ch.n_out; j += WAVE) {
+        Cell a = rl[j];
+        if (!a) continue;
+        if (lo == hi)
+            for_pairs_self<Cell>(a, ch.n_bits, [&](int k) { atomicAdd(&cnt[k], 1u); });
+        else {
+            Cell b = rh[j];
+            if (b) for_pairs_cross<Cell>(a, b, ch.n_bits, [&](int k) { atomicAdd(&cnt[k], 1u); });
+        }
+    }
+    lds_fence();
+}
+__device__ __forceinline__ bool wave_any_ge2(const uint32_t *cnt, int K) {
+    int f = 0;
+    for (int k = lane_id(); k < K; k += WAVE) f |= cnt[k] >= 2;
+    return __any(f);
+}
+
+// ------------------------------------------------------------------------------------------------ k_init_pairs
+// grid (ceil(n_pairs / 4), n_chains): one wave per initial row pair (i0 <= i1).
+template <class Cell> __global__ void __launch_bounds__(256) k_init_pairs(ChainDev *chains) {
+    ChainDev &ch = chains[blockIdx.y];
+    if (ch.method == M_DUMMY) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t *cnt = reinterpret_cast<uint32_t *>(smem) + (size_t)wave_id() * ch.Kpad;
+    long long n_pairs = (long long)ch.n_in * (ch.n_in + 1) / 2;
+    long long p = (long long)blockIdx.x * (blockDim.x / WAVE) + wave_id();
+    if (p >= n_pairs) return;
+    // p = i1 (i1 + 1) / 2 + i0
+    long long i1 = (long long)((sqrt(8.0 * (double)p + 1.0) - 1.0) * 0.5);
+    while (i1 * (i1 + 1) / 2 > p) --i1;
+    while ((i1 + 1) * (i1 + 2) / 2 <= p) ++i1;
+    uint32_t hi = (uint32_t)i1, lo = (uint32_t)(p - i1 * (i1 + 1) / 2);
+    const auto *cells = reinterpret_cast<const Cell *>(ch.cells);
+    count_row_pair<Cell>(ch, cells, lo, hi, cnt);
+    if (!wave_any_ge2(cnt, ch.K)) return;
+    if (ch.method < 0) {  // unknown method string with a non-empty table: the reference throws here
+        if (lane_id() == 0) ch.unknown_hit = 1;
+        return;
+    }
+    table_insert(ch, lo, hi, [&](int k) { return cnt[k]; });
+}
+
+// ------------------------------------------------------------------------------------------------ k_iter_select
+// One block per chain: (1) arg-max of the pair table via lazily tightened group upper bounds, (2) substitution
+// of the chosen pair in every column, (3) exact recount of the pairs among the modified rows {A, B, new},
+// (4) publication of the matched-column list for k_iter_update.
+template <class Cell> __global__ void __launch_bounds__(SEL_THREADS) k_iter_select(ChainDev *chains, unsigned int *n_done) {
+    using O = CellOps<Cell>;
+    ChainDev &ch = chains[blockIdx.x];
+    if (ch.done) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // dynamic LDS carve: bound copy | verified flags | special-pair counters | unit scratch
+    unsigned long long *s_ub = reinterpret_cast<unsigned long long *>(smem);   // [n_groups]
+    uint8_t *s_seen = reinterpret_cast<uint8_t *>(s_ub + ch.n_groups);         // [n_groups] (padded to 8)
+    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_seen + ((ch.n_groups + 7) & ~7));  // [6][Kpad]
+    int *s_scan = reinterpret_cast<int *>(s_cnt + 6 * ch.Kpad);                // [n_out + 1]
+    constexpr int NW = SEL_THREADS / WAVE;
+    __shared__ uint32_t s_red_rank[NW];
+    __shared__ unsigned long long s_red_tie[NW];
+    __shared__ unsigned long long s_floor;  // lower bound (bound-word form) of the best verified entry
+    __shared__ uint32_t s_best_rank;
+    __shared__ unsigned long long s_best_tie;
+    __shared__ int s_m;
+    __shared__ RowInfo s_new;
+
+    const int tid = threadIdx.x, lane = lane_id(), wid = wave_id();
+    const int n_groups = ch.n_groups, gs = 1 << ch.gs_log2;
+
+    if (ch.error != E_OK) {  // a capacity error poisons the chain: stop it (the host retries with a larger arena)
+        if (tid == 0) {
+            ch.done = 1;
+            ch.m = 0;
+            ch.n_units = 0;
+            atomicAdd(n_done, 1u);
+        }
+        return;
+    }
+
+    // ---------------- (1) selection: every wave owns the groups g == wid (mod NW) and repeatedly verifies its
+    // highest unverified bound until that bound falls below the best verified entry of the whole block.
+    for (int g = tid; g < n_groups; g += SEL_THREADS) {
+        s_ub[g] = ch.ub[g];
+        s_seen[g] = 0;
+    }
+    if (tid == 0) s_floor = 0;
+    __syncthreads();
+    {
+        uint32_t wrank = 0;
+        unsigned long long wtie = 0;
+        unsigned int rescans = 0;
+        while (true) {
+            unsigned long long top = 0;
+            int top_g = -1;
+            for (int g = wid + lane * NW; g < n_groups; g += NW * WAVE) {
+                unsigned long long v = s_seen[g] ? 0ull : s_ub[g];
+                if (v > top) {
+                    top = v;
+                    top_g = g;
+                }
+            }
+            unsigned long long wtop = wave_max_u64(top);
+            if (wtop == 0) break;
+            unsigned long long floor_now = *(volatile unsigned long long *)&s_floor;
+            if (wtop < floor_now) break;  // nothing left in this partition can beat or tie the best verified entry
+            unsigned long long who = __ballot(top == wtop && top_g >= 0);
+            int g = __shfl(top_g, __ffsll((long long)who) - 1);
+            uint32_t base = (uint32_t)g * gs;
+            uint32_t grank = 0;
+            for (int o = lane; o < gs; o += WAVE) grank = max(grank, ch.hrank[base + o]);
+            grank = wave_max_u32(grank);
+            unsigned long long gtie = 0;
+            if (grank) {
+                for (int o = lane; o < gs; o += WAVE) {
+                    uint32_t sl = base + o;
+                    if (ch.hrank[sl] == grank) {
+                        unsigned long long kk = ch.hkey[sl];
+                        unsigned long long tw = tie_word((uint32_t)kk, (uint32_t)(kk >> 32), ch.hidx[sl]);
+                        gtie = tw > gtie ? tw : gtie;
+                    }
+                }
+                gtie = wave_max_u64(gtie);
+            }
+            unsigned long long exact = grank ? bound_word(grank, gtie) : 0ull;
+            if (lane == 0) {
+                s_ub[g] = exact;
+                s_seen[g] = 1;
+                ch.ub[g] = exact;  // no writer races with this kernel: the bound is now tight
+                if (exact) atomicMax(&s_floor, exact);
+            }
+            lds_fence();
+            if (grank > wrank || (grank == wrank && gtie > wtie)) {
+                wrank = grank;
+                wtie = gtie;
+            }
+            ++rescans;
+        }
+        if (lane == 0) {
+            s_red_rank[wid] = wrank;
+            s_red_tie[wid] = wtie;
+            if (rescans) atomicAdd(&ch.st_rescans, (unsigned long long)rescans);
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t br = 0;
+        unsigned long long bt = 0;
+        for (int w = 0; w < NW; ++w)
+            if (s_red_rank[w] > br || (s_red_rank[w] == br && s_red_tie[w] > bt)) {
+                br = s_red_rank[w];
+                bt = s_red_tie[w];
+            }
+        s_best_rank = br;
+        s_best_tie = bt;
+    }
+    __syncthreads();
+    const uint32_t best_rank = s_best_rank;
+    const unsigned long long best_tie = s_best_tie;
+    if (best_rank == 0 || ch.n_rows >= ch.rcap) {
+        if (tid == 0) {
+            if (best_rank != 0) ch.error = E_ROW_CAPACITY;
+            ch.done = 1;
+            ch.m = 0;
+            ch.n_units = 0;
+            atomicAdd(n_done, 1u);
+        }
+        return;
+    }
+    const uint32_t A = (uint32_t)((best_tie >> 7) & 0xFFFFFFu), B = (uint32_t)(best_tie >> 31);
+    const int idx = (int)(best_tie & 0x7F);
+    int shift, sub;
+    key_decode(idx, ch.n_bits, shift, sub);
+    const uint32_t Nw = (uint32_t)ch.n_rows;
+    const bool same = A == B;
+
+    // ---------------- (2) new row record + substitution
+    if (tid == 0) {
+        RowInfo ra = ch.rows[A], rb = ch.rows[B], rn;
+        int derr = 0;
+        qint_add_pair(ra, rb, shift, sub, rn.lo, rn.hi, rn.step);
+        float dlat = adder_dlat(ra, rb, shift, sub, ch.adder_size, ch.carry_size, c_log2, derr);
+        rn.lat = (ra.lat < rb.lat ? rb.lat : ra.lat) + dlat;
+        if (derr) ch.error = E_FLOAT_DOMAIN;
+        ch.rows[Nw] = rn;
+        s_new = rn;
+        ch.picks[ch.iter] = make_int4((int)A, (int)B, sub, shift);
+        s_m = 0;
+    }
+    for (int k = tid; k < 6 * ch.Kpad; k += SEL_THREADS) s_cnt[k] = 0;
+    __syncthreads();
+    Cell *cells = reinterpret_cast<Cell *>(ch.cells);
+    Cell *rowA = cells + (size_t)A * ch.n_out, *rowB = cells + (size_t)B * ch.n_out, *rowN = cells + (size_t)Nw * ch.n_out;
+    Cell *mA = reinterpret_cast<Cell *>(ch.mA), *mB = reinterpret_cast<Cell *>(ch.mB);
+    uint32_t *cAA = s_cnt, *cAB = s_cnt + ch.Kpad, *cBB = s_cnt + 2 * ch.Kpad, *cAN = s_cnt + 3 * ch.Kpad,
+             *cBN = s_cnt + 4 * ch.Kpad, *cNN = s_cnt + 5 * ch.Kpad;
+    const int nb = ch.n_bits;
+    unsigned int my_matches = 0;
+    for (int j = tid; j < ch.n_out; j += SEL_THREADS) {
+        Cell a = rowA[j], b = same ? a : rowB[j], ma = 0, mb = 0;
+        if (a && b) substitute_column<Cell>(a, b, same, shift, sub, ma, mb);
+        Cell na = a & ~ma, nbv = b & ~mb;
+        if (same) na = a & ~ma & ~mb;
+        if (ma) {
+            rowA[j] = na;
+            if (!same) rowB[j] = nbv;
+            int at = atomicAdd(&s_m, 1);
+            ch.mcol[at] = j;
+            mA[at] = ma;
+            mB[at] = mb;
+            int len = ch.collen[j];
+            s_scan[at] = (len + UNIT - 1) / UNIT;  // update work units of this column (the new row is not a partner)
+            if (len < ch.lcap) {
+                ch.collist[(size_t)j * ch.lcap + len] = Nw;
+                ch.collen[j] = len + 1;
+            } else
+                ch.error = E_LIST_CAPACITY;
+            my_matches += popc32(O::plus(ma) | O::minus(ma));
+        }
+        rowN[j] = ma;
+        // ---------------- (3) exact recount of the pairs among {A, B, new} (their old blocks are replaced)
+        if (na) for_pairs_self<Cell>(na, nb, [&](int k) { atomicAdd(&cAA[k], 1u); });
+        if (!same) {
+            if (na && nbv) for_pairs_cross<Cell>(na, nbv, nb, [&](int k) { atomicAdd(&cAB[k], 1u); });
+            if (nbv) for_pairs_self<Cell>(nbv, nb, [&](int k) { atomicAdd(&cBB[k], 1u); });
+            if (nbv && ma) for_pairs_cross<Cell>(nbv, ma, nb, [&](int k) { atomicAdd(&cBN[k], 1u); });
+        }
+        if (na && ma) for_pairs_cross<Cell>(na, ma, nb, [&](int k) { atomicAdd(&cAN[k], 1u); });
+        if (ma) for_pairs_self<Cell>(ma, nb, [&](int k) { atomicAdd(&cNN[k], 1u); });
+    }
+    if (my_matches) atomicAdd(&ch.st_matches, (unsigned long long)my_matches);
+    __syncthreads();
+    const int m = s_m;
+    // prefix sum of the per-column unit counts (m <= n_out; serial for short lists, they are short)
+    if (tid == 0) {
+        int acc = 0;
+        for (int q = 0; q < m; ++q) {
+            ch.unit_off[q] = acc;
+            acc += s_scan[q];
+        }
+        ch.unit_off[m] = acc;
+        ch.m = m;
+        ch.n_units = acc;
+        ch.work_ctr = 0;
+        ch.A = A;
+        ch.B = B;
+        ch.Nw = Nw;
+        ch.n_rows = (int)Nw + 1;
+        ch.iter = ch.iter + 1;
+        ch.stamp[A] = ch.stamp[B] = ch.stamp[Nw] = 0;
+    }
+    // six special pairs, one wave each
+    if (wid < 6) {
+        uint32_t lo, hi;
+        const uint32_t *cnt = s_cnt + wid * ch.Kpad;
+        bool active = true, existed = false;
+        switch (wid) {
+        case 0: lo = A, hi = A, existed = true; break;
+        case 1: lo = A, hi = B, existed = true, active = !same; break;
+        case 2: lo = B, hi = B, existed = true, active = !same; break;
+        case 3: lo = A, hi = Nw; break;
+        case 4: lo = B, hi = Nw, active = !same; break;
+        default: lo = Nw, hi = Nw; break;
+        }
+        if (active) {
+            // rows[Nw] was written by thread 0 before the barrier above; make it visible to this wave's loads
+            __threadfence_block();
+            int slot = existed ? table_find(ch, pack_pair(lo, hi), hash_pair(lo, hi)) : -1;
+            if (slot >= 0)
+                table_update(ch, slot, [&](int k, uint32_t) { return cnt[k]; });
+            else if (wave_any_ge2(cnt, ch.K))
+                table_insert(ch, lo, hi, [&](int k) { return cnt[k]; });
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ k_iter_update
+// grid (U, n_chains).  Work unit = UNIT consecutive entries of the row list of one matched column.  Every row
+// found there (other than A, B, new) is claimed once per iteration and handled by ONE wavefront: it subtracts the
+// occurrences lost with A's / B's consumed digits from the blocks (A,r), (B,r) and creates the block (r,new).
+template <class Cell> __global__ void __launch_bounds__(UPD_THREADS) k_iter_update(ChainDev *chains) {
+    ChainDev &ch = chains[blockIdx.y];
+    if (ch.done || ch.n_units == 0) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(smem);  // [UPD_WAVES][3][Kpad]
+    __shared__ uint32_t s_rows[UNIT];
+    __shared__ uint32_t s_n;
+    __shared__ int s_unit;
+    const int tid = threadIdx.x, lane = lane_id(), wid = wave_id();
+    const uint32_t A = ch.A, B = ch.B, Nw = ch.Nw;
+    const bool same = A == B;
+    const int m = ch.m, nb = ch.n_bits, Kpad = ch.Kpad, K = ch.K;
+    const uint32_t tag = (uint32_t)ch.iter;  // >= 1, unique per iteration
+    const Cell *cells = reinterpret_cast<const Cell *>(ch.cells);
+    const Cell *mA = reinterpret_cast<const Cell *>(ch.mA), *mB = reinterpret_cast<const Cell *>(ch.mB);
+    uint32_t *dA = s_cnt + (size_t)wid * 3 * Kpad, *dB = dA + Kpad, *cN = dB + Kpad;
+    unsigned int partners = 0;
+
+    while (true) {
+        if (tid == 0) {
+            s_unit = (int)atomicAdd(&ch.work_ctr, 1u);
+            s_n = 0;
+        }
+        __syncthreads();
+        const int unit = s_unit;
+        if (unit >= ch.n_units) break;
+        // locate the matched column of this unit (unit_off is ascending, m is small)
+        int lo = 0, hi = m;
+        while (hi - lo > 1) {
+            int mid = (lo + hi) >> 1;
+            if (ch.unit_off[mid] <= unit)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        const int col = ch.mcol[lo];
+        const int e = (unit - ch.unit_off[lo]) * UNIT + tid;
+        // entries beyond the pre-append length are the new row itself
+        bool mine = false;
+        uint32_t r = 0;
+        if (e < ch.collen[col]) {
+            r = ch.collist[(size_t)col * ch.lcap + e];
+            if (r != A && r != B && r != Nw) mine = atomicExch(&ch.stamp[r], tag) != tag;
+        }
+        if (mine) s_rows[atomicAdd(&s_n, 1u)] = r;
+        __syncthreads();
+        const uint32_t n = s_n;
+        for (uint32_t q = wid; q < n; q += UPD_WAVES) {
+            const uint32_t pr = s_rows[q];
+            ++partners;
+            for (int k = lane; k < 3 * Kpad; k += WAVE) dA[k] = 0;
+            lds_fence();
+            const Cell *rowR = cells + (size_t)pr * ch.n_out;
+            int touched = 0;
+            for (int j = lane; j < m; j += WAVE) {
+                Cell x = rowR[ch.mcol[j]];
+                if (!x) continue;
+                touched = 1;
+                Cell ma = mA[j], mb = mB[j];
+                for_pairs_part<Cell>(ma, x, A < pr, nb, [&](int k) { atomicAdd(&dA[k], 1u); });
+                if (same)
+                    for_pairs_part<Cell>(mb, x, A < pr, nb, [&](int k) { atomicAdd(&dA[k], 1u); });
+                else
+                    for_pairs_part<Cell>(mb, x, B < pr, nb, [&](int k) { atomicAdd(&dB[k], 1u); });
+                for_pairs_cross<Cell>(x, ma, nb, [&](int k) { atomicAdd(&cN[k], 1u); });
+            }
+            lds_fence();
+            if (!__any(touched)) continue;  // stale list entry: the row lost its digits in every matched column
+            {
+                uint32_t l = min(A, pr), h = max(A, pr);
+                int slot = table_find(ch, pack_pair(l, h), hash_pair(l, h));
+                if (slot >= 0) table_update(ch, slot, [&](int k, uint32_t old) { return old - dA[k]; });
+            }
+            if (!same) {
+                uint32_t l = min(B, pr), h = max(B, pr);
+                int slot = table_find(ch, pack_pair(l, h), hash_pair(l, h));
+                if (slot >= 0) table_update(ch, slot, [&](int k, uint32_t old) { return old - dB[k]; });
+            }
+            if (wave_any_ge2(cN, K)) table_insert(ch, pr, Nw, [&](int k) { return cN[k]; });
+        }
+        __syncthreads();
+    }
+    if (lane == 0 && partners) atomicAdd(&ch.st_partners, (unsigned long long)partners);
+}
+
+// ------------------------------------------------------------------------------------------------ k_extract
+// grid (ceil(n_out / 4), n_chains): one wave per column compacts the surviving (row, cell) entries in row order.
+template <class Cell> __global__ void __launch_bounds__(256) k_extract(ChainDev *chains) {
+    using O = CellOps<Cell>;
+    ChainDev &ch = chains[blockIdx.y];
+    int j = blockIdx.x * (blockDim.x / WAVE) + wave_id();
+    if (j >= ch.n_out) return;
+    const Cell *cells = reinterpret_cast<const Cell *>(ch.cells);
+    int lane = lane_id(), len = ch.collen[j], out = 0;
+    for (int base = 0; base < len; base += WAVE) {
+        int e = base + lane;
+        Cell c = 0;
+        uint32_t r = 0;
+        if (e < len) {
+            r = ch.collist[(size_t)j * ch.lcap + e];
+            c = cells[(size_t)r * ch.n_out + j];
+        }
+        unsigned long long nz = __ballot(c != 0);
+        if (c != 0) {
+            size_t at = (size_t)j * ch.lcap + out + __popcll(nz & ((1ull << lane) - 1));
+            ch.fin_row[at] = r;
+            ch.fin_cell[at] = (unsigned long long)O::plus(c) | ((unsigned long long)O::minus(c) << 32);
+        }
+        out += __popcll(nz);
+    }
+    if (lane == 0) ch.fin_count[j] = (uint32_t)out;
+}
+
+// ------------------------------------------------------------------------------------------------ k_col_dist
+// Stage-1 distance matrix: d0[a][b] = sum_i nnzNAF(M[i,a] - M[i,b]), d1 with '+'.  grid (ceil(W/16), ceil(W/16)),
+// block 16x16: a 16x16 tile of (a,b); the two 16-column strips of M are staged through LDS 64 rows at a time.
+__global__ void __launch_bounds__(256) k_col_dist(const int32_t *aug, int n_in, int W, long long *d0, long long *d1) {
+    __shared__ int32_t sa[64][17], sb[64][17];
+    int ta = threadIdx.y, tb = threadIdx.x;
+    int a = blockIdx.y * 16 + ta, b = blockIdx.x * 16 + tb;
+    int tid = ta * 16 + tb;
+    long long acc0 = 0, acc1 = 0;
+    for (int base = 0; base < n_in; base += 64) {
+        for (int q = tid; q < 64 * 16; q += 256) {
+            int i = base + q / 16, c = q % 16;
+            int ca = blockIdx.y * 16 + c, cb = blockIdx.x * 16 + c;
+            sa[q / 16][c] = (i < n_in && ca < W) ? aug[(size_t)i * W + ca] : 0;
+            sb[q / 16][c] = (i < n_in && cb < W) ? aug[(size_t)i * W + cb] : 0;
+        }
+        __syncthreads();
+        int rows = min(64, n_in - base);
+        for (int i = 0; i < rows; ++i) {
+            int32_t x = sa[i][ta], y = sb[i][tb];
+            acc0 += naf_weight(x - y);
+            acc1 += naf_weight(x + y);
+        }
+        __syncthreads();
+    }
+    if (a < W && b < W) {
+        d0[(size_t)a * W + b] = acc0;
+        d1[(size_t)a * W + b] = acc1;
+    }
+}
+
+// NAF digits of a flat int32 array (int_arr_to_csd, bit_decompose.cc:22-42): out[i][b] in {-1,0,1}
+__global__ void __launch_bounds__(256) k_naf_digits(const int32_t *x, long long n, int N, int8_t *out) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t p, m;
+    naf_masks(x[i], p, m);
+    for (int b = 0; b < N; ++b) out[i * N + b] = (int8_t)(((p >> b) & 1) - ((m >> b) & 1));
+}
+__global__ void __launch_bounds__(256) k_absmax(const int32_t *x, long long n, unsigned int *out) {
+    unsigned int mx = 0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        int32_t v = x[i];
+        mx = max(mx, (unsigned int)(v < 0 ? -v : v));
+    }
+    mx = wave_max_u32(mx);
+    if (lane_id() == 0) atomicMax(out, mx);
+}
+
+// =================================================================================================== host side
+
+namespace {
+
+struct DeviceBuffer {  // grow-only device allocation reused across calls
+    void *ptr = nullptr;
+    size_t cap = 0;
+    void *get(size_t bytes) {
+        if (bytes > cap) {
+            if (ptr) (void)hipFree(ptr);
+            ptr = nullptr;
+            cap = 0;
+            size_t want = bytes + bytes / 8;
+            HIP_CHECK(hipMalloc(&ptr, want));
+            cap = want;
+        }
+        return ptr;
+    }
+    ~DeviceBuffer() {
+        if (ptr) (void)hipFree(ptr);
+    }
+};
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct Carver {  // bump allocator over the arena; first pass sizes, second pass assigns
+    unsigned char *base;
+    size_t off = 0;
+    explicit Carver(unsigned char *b) : base(b) {}
+    template <class T> T *take(size_t count) {
+        off = align_up(off, 256);
+        T *p = base ? reinterpret_cast<T *>(base + off) : nullptr;
+        off += count * sizeof(T);
+        return p;
+    }
+};
+
+uint32_t pow2_ceil(uint64_t v) {
+    uint32_t p = 1;
+    while (p < v && p < (1u << 31)) p <<= 1;
+    return p;
+}
+
+}  // namespace
+
+struct HipBackend::Impl {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    DeviceBuffer arena, desc_buf, io_buf;
+    unsigned int *d_done = nullptr;
+    unsigned int *h_done = nullptr;  // pinned
+    GpuTimings timings;
+    double table_scale = 1.0;  // grows on E_TABLE_CAPACITY retries
+};
+
+HipBackend::HipBackend(int device) : impl_(new Impl) {
+    impl_->device = device;
+    HIP_CHECK(hipSetDevice(device));
+    HIP_CHECK(hipStreamCreateWithFlags(&impl_->stream, hipStreamNonBlocking));
+    HIP_CHECK(hipMalloc(&impl_->d_done, sizeof(unsigned int)));
+    HIP_CHECK(hipHostMalloc(&impl_->h_done, sizeof(unsigned int), hipHostMallocDefault));
+    Log2Table t = measure_log2_table();
+    HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_log2), &t, sizeof t));
+}
+HipBackend::~HipBackend() {
+    (void)hipSetDevice(impl_->device);
+    if (impl_->d_done) (void)hipFree(impl_->d_done);
+    if (impl_->h_done) (void)hipHostFree(impl_->h_done);
+    if (impl_->stream) (void)hipStreamDestroy(impl_->stream);
+}
+const GpuTimings &HipBackend::timings() const { return impl_->timings; }
+void HipBackend::reset_timings() { impl_->timings = GpuTimings{}; }
+void *HipBackend::stream() const { return impl_->stream; }
+
+namespace {
+
+struct Geometry {
+    bool wide;  // 64-bit cells
+    int n_bits, K, Kpad, rcap, lcap, gs_log2, n_groups;
+    uint32_t C;
+};
+
+// carve one chain's arrays; with base == nullptr only the size is computed
+size_t carve_chain(unsigned char *base, const ChainJob &job, const Geometry &g, ChainDev &d) {
+    Carver c(base);
+    size_t cell = g.wide ? 8 : 4;
+    size_t n_in = job.n_in, n_out = job.n_out;
+    d.cells = c.take<unsigned char>((size_t)g.rcap * n_out * cell);
+    d.rows = c.take<RowInfo>(g.rcap);
+    d.stamp = c.take<uint32_t>(g.rcap);
+    d.collist = c.take<uint32_t>(n_out * (size_t)g.lcap);
+    d.collen = c.take<int>(n_out);
+    d.hkey = c.take<unsigned long long>(g.C);
+    d.hrank = c.take<uint32_t>(g.C);
+    d.hidx = c.take<uint8_t>(g.C);
+    d.hstat = c.take<HStat>(g.C);
+    d.hcnt = c.take<uint16_t>((size_t)g.C * g.Kpad);
+    d.ub = c.take<unsigned long long>(g.n_groups);
+    d.mcol = c.take<int>(n_out);
+    d.mA = c.take<unsigned char>(n_out * cell);
+    d.mB = c.take<unsigned char>(n_out * cell);
+    d.unit_off = c.take<int>(n_out + 1);
+    d.picks = c.take<int4>(g.rcap);
+    d.fin_row = c.take<uint32_t>(n_out * (size_t)g.lcap);
+    d.fin_cell = c.take<unsigned long long>(n_out * (size_t)g.lcap);
+    d.fin_count = c.take<uint32_t>(n_out);
+    (void)n_in;
+    return align_up(c.off, 256);
+}
+
+}  // namespace
+
+// Runs chains [all of one cell width] to completion.  `prep` holds the descriptors after k_prepare (inputs resident).
+void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
+    if (n <= 0) return;
+    Impl &im = *impl_;
+    HIP_CHECK(hipSetDevice(im.device));
+    hipStream_t st = im.stream;
+    auto t_begin = std::chrono::steady_clock::now();
+
+    // ---- 1. inputs to the device, k_prepare
+    std::vector<size_t> in_off(n);
+    size_t in_bytes = 0;
+    for (int i = 0; i < n; ++i) {
+        in_off[i] = in_bytes;
+        size_t e = (size_t)jobs[i].n_in * jobs[i].n_out;
+        in_bytes += align_up(e * 4, 256) + align_up((size_t)jobs[i].n_in * 12, 256) + align_up((size_t)jobs[i].n_in * 4, 256) +
+                    align_up(e * 4, 256) + align_up(jobs[i].n_in, 256) + align_up(jobs[i].n_out, 256);
+    }
+    unsigned char *io = static_cast<unsigned char *>(im.io_buf.get(std::max<size_t>(in_bytes, 256)));
+    std::vector<ChainDev> desc(n);
+    std::vector<unsigned char> stage(in_bytes);
+    for (int i = 0; i < n; ++i) {
+        const ChainJob &j = jobs[i];
+        size_t e = (size_t)j.n_in * j.n_out, o = in_off[i];
+        ChainDev &d = desc[i];
+        std::memset(&d, 0, sizeof d);
+        d.n_in = j.n_in;
+        d.n_out = j.n_out;
+        d.method = j.method;
+        d.adder_size = j.adder_size;
+        d.carry_size = j.carry_size;
+        d.kernel = reinterpret_cast<const float *>(io + o);
+        std::memcpy(stage.data() + o, j.kernel, e * 4);
+        o += align_up(e * 4, 256);
+        d.qints = reinterpret_cast<const float *>(io + o);
+        std::memcpy(stage.data() + o, j.qints, (size_t)j.n_in * 12);
+        o += align_up((size_t)j.n_in * 12, 256);
+        d.lats = reinterpret_cast<const float *>(io + o);
+        std::memcpy(stage.data() + o, j.lats, (size_t)j.n_in * 4);
+        o += align_up((size_t)j.n_in * 4, 256);
+        d.xint = reinterpret_cast<int32_t *>(io + o);
+        o += align_up(e * 4, 256);
+        d.shift0 = reinterpret_cast<int8_t *>(io + o);
+        o += align_up(j.n_in, 256);
+        d.shift1 = reinterpret_cast<int8_t *>(io + o);
+    }
+    HIP_CHECK(hipMemcpyAsync(io, stage.data(), in_bytes, hipMemcpyHostToDevice, st));
+    ChainDev *d_desc = static_cast<ChainDev *>(im.desc_buf.get(sizeof(ChainDev) * (size_t)n));
+    HIP_CHECK(hipMemcpyAsync(d_desc, desc.data(), sizeof(ChainDev) * (size_t)n, hipMemcpyHostToDevice, st));
+    int max_n_out = 0, max_n_in = 0;
+    for (int i = 0; i < n; ++i) {
+        max_n_out = std::max(max_n_out, jobs[i].n_out);
+        max_n_in = std::max(max_n_in, jobs[i].n_in);
+    }
+    hipLaunchKernelGGL(k_prepare, dim3(n), dim3(256), (size_t)max_n_out * 4, st, d_desc);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipMemcpyAsync(desc.data(), d_desc, sizeof(ChainDev) * (size_t)n, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+
+    // ---- 2. geometry and arena
+    std::vector<Geometry> geo(n);
+    std::vector<size_t> a_off(n);
+    size_t arena_bytes = 0;
+    for (int i = 0; i < n; ++i) {
+        const ChainDev &d = desc[i];
+        Geometry &g = geo[i];
+        g.n_bits = d.prep_nbits;
+        if (g.n_bits > 32) throw std::runtime_error("kernel needs more than 32 CSD digits per entry; unsupported");
+        g.wide = g.n_bits > 16;
+        g.K = key_count(g.n_bits);
+        g.Kpad = (g.K + 3) & ~3;
+        long long D0 = d.prep_digits;
+        // every greedy step removes at least one digit; typical chains need ~D0/8 steps
+        long long steps = jobs[i].method == M_DUMMY || jobs[i].method < 0 ? 0 : std::max<long long>(16, (long long)(D0 * row_scale_ / 4));
+        if (steps > D0) steps = std::max<long long>(D0, 1);
+        g.rcap = jobs[i].n_in + (int)steps + 1;
+        g.lcap = jobs[i].n_in + d.prep_maxdcol + 1;
+        // table capacity: blocks peak well above the initial pair count when rows are dense
+        long long pairs0 = std::min<long long>((long long)jobs[i].n_in * (jobs[i].n_in + 1) / 2, std::max<long long>(d.prep_pairs, 1));
+        double growth = std::max(4.0, jobs[i].n_in / 5.0);
+        double want = std::max(1024.0, 1.6 * pairs0 * growth * im.table_scale);
+        if (jobs[i].method == M_DUMMY) want = 64;
+        g.C = pow2_ceil((uint64_t)want);
+        g.gs_log2 = 8;
+        while ((g.C >> g.gs_log2) > (uint32_t)MAX_GROUPS) ++g.gs_log2;
+        if (g.C < 256) g.C = 256;
+        g.n_groups = (int)(g.C >> g.gs_log2);
+        ChainDev tmp;
+        a_off[i] = arena_bytes;
+        arena_bytes += carve_chain(nullptr, jobs[i], g, tmp);
+    }
+    unsigned char *arena = static_cast<unsigned char *>(im.arena.get(arena_bytes));
+    for (int i = 0; i < n; ++i) {
+        ChainDev &d = desc[i];
+        const Geometry &g = geo[i];
+        carve_chain(arena + a_off[i], jobs[i], g, d);
+        d.n_bits = g.n_bits;
+        d.K = g.K;
+        d.Kpad = g.Kpad;
+        d.rcap = g.rcap;
+        d.lcap = g.lcap;
+        d.gs_log2 = g.gs_log2;
+        d.n_groups = g.n_groups;
+        d.C = g.C;
+        d.cmask = g.C - 1;
+        d.n_rows = jobs[i].n_in;
+        d.iter = 0;
+        d.done = (jobs[i].method == M_DUMMY || jobs[i].method < 0) ? 1 : 0;
+        // zero-initialised state: stamp, hrank, ub; hkey = EMPTY (all ones)
+        HIP_CHECK(hipMemsetAsync(d.stamp, 0, sizeof(uint32_t) * (size_t)g.rcap, st));
+        HIP_CHECK(hipMemsetAsync(d.hkey, 0xFF, sizeof(unsigned long long) * (size_t)g.C, st));
+        HIP_CHECK(hipMemsetAsync(d.hrank, 0, sizeof(uint32_t) * (size_t)g.C, st));
+        HIP_CHECK(hipMemsetAsync(d.ub, 0, sizeof(unsigned long long) * (size_t)g.n_groups, st));
+        // rows beyond n_in start with empty cells: new rows are fully written by k_iter_select
+    }
+    HIP_CHECK(hipMemcpyAsync(d_desc, desc.data(), sizeof(ChainDev) * (size_t)n, hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipMemsetAsync(im.d_done, 0, sizeof(unsigned int), st));
+
+    // ---- 3. launch per cell width (descriptors are grouped so that one launch covers a contiguous range)
+    std::vector<int> order(n);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return geo[a].wide < geo[b].wide; });
+    bool permuted = false;
+    for (int i = 0; i < n; ++i) permuted |= order[i] != i;
+    if (permuted) {
+        std::vector<ChainDev> sorted(n);
+        for (int i = 0; i < n; ++i) sorted[i] = desc[order[i]];
+        HIP_CHECK(hipMemcpyAsync(d_desc, sorted.data(), sizeof(ChainDev) * (size_t)n, hipMemcpyHostToDevice, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+    }
+    int n_narrow = 0;
+    for (int i = 0; i < n; ++i) n_narrow += !geo[i].wide;
+    struct Range {
+        int first, count;
+        bool wide;
+    } ranges[2] = {{0, n_narrow, false}, {n_narrow, n - n_narrow, true}};
+    int active = 0;
+    for (int i = 0; i < n; ++i) active += desc[i].done ? 0 : 1;
+
+    size_t sel_lds[2] = {0, 0}, upd_lds[2] = {0, 0}, pair_lds[2] = {0, 0};
+    int upd_blocks[2] = {1, 1};
+    long long max_pairs[2] = {0, 0};
+    for (int i = 0; i < n; ++i) {
+        int w = geo[i].wide;
+        size_t s = (size_t)geo[i].n_groups * 8 + (((size_t)geo[i].n_groups + 7) & ~(size_t)7) + 6 * (size_t)geo[i].Kpad * 4 +
+                   ((size_t)jobs[i].n_out + 1) * 4;
+        s = align_up(s, 16);
+        sel_lds[w] = std::max(sel_lds[w], s);
+        upd_lds[w] = std::max(upd_lds[w], (size_t)UPD_WAVES * 3 * geo[i].Kpad * 4);
+        pair_lds[w] = std::max(pair_lds[w], (size_t)4 * geo[i].Kpad * 4);
+        max_pairs[w] = std::max(max_pairs[w], (long long)jobs[i].n_in * (jobs[i].n_in + 1) / 2);
+    }
+    for (int w = 0; w < 2; ++w) {
+        int cnt = ranges[w].count;
+        if (cnt == 0) continue;
+        // keep the whole chip busy: ~4 blocks per CU in total, at least 2 and at most 32 per chain
+        upd_blocks[w] = std::max(2, std::min(32, 1024 / std::max(cnt, 1)));
+    }
+    for (int w = 0; w < 2; ++w) {
+        const Range &r = ranges[w];
+        if (r.count == 0) continue;
+        ChainDev *base = d_desc + r.first;
+        dim3 colgrid((max_n_out + 3) / 4, r.count);
+        dim3 pairgrid((unsigned)((max_pairs[w] + 3) / 4), r.count);
+        if (!r.wide) {
+            hipLaunchKernelGGL(k_init_cells<uint32_t>, colgrid, dim3(256), 0, st, base);
+            hipLaunchKernelGGL(k_init_pairs<uint32_t>, pairgrid, dim3(256), pair_lds[w], st, base);
+        } else {
+            hipLaunchKernelGGL(k_init_cells<uint64_t>, colgrid, dim3(256), 0, st, base);
+            hipLaunchKernelGGL(k_init_pairs<uint64_t>, pairgrid, dim3(256), pair_lds[w], st, base);
+        }
+        HIP_CHECK(hipGetLastError());
+    }
+    if (sel_lds[0] > 150 * 1024 || sel_lds[1] > 150 * 1024) throw std::runtime_error("selection kernel needs more than 150 KiB of LDS (n_out too large)");
+    if (ranges[0].count)
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_iter_select<uint32_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sel_lds[0]));
+    if (ranges[1].count)
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_iter_select<uint64_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sel_lds[1]));
+
+    // ---- 4. greedy loop: all chains advance in lockstep, two kernels per iteration
+    hipEvent_t ev0, ev1;
+    HIP_CHECK(hipEventCreate(&ev0));
+    HIP_CHECK(hipEventCreate(&ev1));
+    HIP_CHECK(hipEventRecord(ev0, st));
+    long long launched_iters = 0, iter_cap = 0;
+    for (int i = 0; i < n; ++i) iter_cap = std::max<long long>(iter_cap, geo[i].rcap - jobs[i].n_in + 2);
+    const int poll_every = 64;
+    while (active > 0) {
+        if (launched_iters > iter_cap + poll_every) throw std::runtime_error("greedy loop did not terminate within its row capacity (internal error)");
+        for (int it = 0; it < poll_every; ++it) {
+            for (int w = 0; w < 2; ++w) {
+                const Range &r = ranges[w];
+                if (r.count == 0) continue;
+                ChainDev *base = d_desc + r.first;
+                if (!r.wide) {
+                    hipLaunchKernelGGL(k_iter_select<uint32_t>, dim3(r.count), dim3(SEL_THREADS), sel_lds[w], st, base, im.d_done);
+                    hipLaunchKernelGGL(k_iter_update<uint32_t>, dim3(upd_blocks[w], r.count), dim3(UPD_THREADS), upd_lds[w], st, base);
+                } else {
+                    hipLaunchKernelGGL(k_iter_select<uint64_t>, dim3(r.count), dim3(SEL_THREADS), sel_lds[w], st, base, im.d_done);
+                    hipLaunchKernelGGL(k_iter_update<uint64_t>, dim3(upd_blocks[w], r.count), dim3(UPD_THREADS), upd_lds[w], st, base);
+                }
+            }
+        }
+        launched_iters += poll_every;
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipMemcpyAsync(im.h_done, im.d_done, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        int pre_done = 0;
+        for (int i = 0; i < n; ++i) pre_done += (jobs[i].method == M_DUMMY || jobs[i].method < 0) ? 1 : 0;
+        active = n - pre_done - (int)*im.h_done;
+    }
+    HIP_CHECK(hipEventRecord(ev1, st));
+
+    // ---- 5. extraction and download
+    for (int w = 0; w < 2; ++w) {
+        const Range &r = ranges[w];
+        if (r.count == 0) continue;
+        dim3 colgrid((max_n_out + 3) / 4, r.count);
+        if (!r.wide)
+            hipLaunchKernelGGL(k_extract<uint32_t>, colgrid, dim3(256), 0, st, d_desc + r.first);
+        else
+            hipLaunchKernelGGL(k_extract<uint64_t>, colgrid, dim3(256), 0, st, d_desc + r.first);
+    }
+    HIP_CHECK(hipGetLastError());
+    std::vector<ChainDev> fin(n);
+    HIP_CHECK(hipMemcpyAsync(fin.data(), d_desc, sizeof(ChainDev) * (size_t)n, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    float loop_ms = 0;
+    HIP_CHECK(hipEventElapsedTime(&loop_ms, ev0, ev1));
+    (void)hipEventDestroy(ev0);
+    (void)hipEventDestroy(ev1);
+
+    bool need_retry = false;
+    for (int s = 0; s < n; ++s) {
+        const ChainDev &d = fin[s];
+        int i = order[s];
+        ChainOut &o = outs[i];
+        o = ChainOut{};
+        o.error = d.error;
+        o.unknown_method_hit = d.unknown_hit != 0;
+        o.n_bits = d.n_bits;
+        if (d.error == E_TABLE_CAPACITY || d.error == E_ROW_CAPACITY) need_retry = true;
+    }
+    if (need_retry && retry_depth_ < 4) {
+        // some chain outgrew its arena: rerun the whole group with larger capacities (rare; sizes are heuristics)
+        ++retry_depth_;
+        double keep_t = im.table_scale, keep_r = row_scale_;
+        im.table_scale *= 4.0;
+        row_scale_ *= 4.0;
+        try {
+            run_chains(jobs, outs, n);
+        } catch (...) {
+            im.table_scale = keep_t;
+            row_scale_ = keep_r;
+            --retry_depth_;
+            throw;
+        }
+        im.table_scale = keep_t;
+        row_scale_ = keep_r;
+        --retry_depth_;
+        return;
+    }
+    size_t down_bytes = 0;
+    for (int s = 0; s < n; ++s) {
+        const ChainDev &d = fin[s];
+        int i = order[s];
+        const ChainJob &j = jobs[i];
+        ChainOut &o = outs[i];
+        size_t iters = (size_t)d.iter;
+        o.shift0.resize(j.n_in);
+        o.shift1.resize(j.n_out);
+        HIP_CHECK(hipMemcpyAsync(o.shift0.data(), d.shift0, j.n_in, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipMemcpyAsync(o.shift1.data(), d.shift1, j.n_out, hipMemcpyDeviceToHost, st));
+        o.picks.resize(iters * 4);
+        if (iters) HIP_CHECK(hipMemcpyAsync(o.picks.data(), d.picks, iters * sizeof(int4), hipMemcpyDeviceToHost, st));
+        down_bytes += iters * 16;
+    }
+    // row latencies and surviving digits need staging (strided on the device)
+    std::vector<std::vector<RowInfo>> rowbuf(n);
+    std::vector<std::vector<uint32_t>> cntbuf(n), frow(n);
+    std::vector<std::vector<unsigned long long>> fcell(n);
+    for (int s = 0; s < n; ++s) {
+        const ChainDev &d = fin[s];
+        int i = order[s];
+        const ChainJob &j = jobs[i];
+        rowbuf[s].resize(d.n_rows);
+        HIP_CHECK(hipMemcpyAsync(rowbuf[s].data(), d.rows, sizeof(RowInfo) * (size_t)d.n_rows, hipMemcpyDeviceToHost, st));
+        cntbuf[s].resize(j.n_out);
+        HIP_CHECK(hipMemcpyAsync(cntbuf[s].data(), d.fin_count, 4 * (size_t)j.n_out, hipMemcpyDeviceToHost, st));
+        frow[s].resize((size_t)j.n_out * d.lcap);
+        fcell[s].resize((size_t)j.n_out * d.lcap);
+        HIP_CHECK(hipMemcpyAsync(frow[s].data(), d.fin_row, 4 * frow[s].size(), hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipMemcpyAsync(fcell[s].data(), d.fin_cell, 8 * fcell[s].size(), hipMemcpyDeviceToHost, st));
+        down_bytes += 12 * frow[s].size();
+        (void)i;
+    }
+    HIP_CHECK(hipStreamSynchronize(st));
+    for (int s = 0; s < n; ++s) {
+        const ChainDev &d = fin[s];
+        int i = order[s];
+        const ChainJob &j = jobs[i];
+        ChainOut &o = outs[i];
+        o.row_lat.resize(d.n_rows);
+        for (int r = 0; r < d.n_rows; ++r) o.row_lat[r] = rowbuf[s][r].lat;
+        o.col_start.assign(j.n_out + 1, 0);
+        for (int c = 0; c < j.n_out; ++c) o.col_start[c + 1] = o.col_start[c] + cntbuf[s][c];
+        o.dig_row.resize(o.col_start[j.n_out]);
+        o.dig_cell.resize(o.col_start[j.n_out]);
+        for (int c = 0; c < j.n_out; ++c) {
+            std::copy_n(&frow[s][(size_t)c * d.lcap], cntbuf[s][c], &o.dig_row[o.col_start[c]]);
+            std::copy_n(&fcell[s][(size_t)c * d.lcap], cntbuf[s][c], &o.dig_cell[o.col_start[c]]);
+        }
+        o.stats.iterations = d.iter;
+        o.stats.digits0 = d.prep_digits;
+        o.stats.table_peak = d.live_peak;
+        o.stats.scan_slots = (long long)d.st_rescans << d.gs_log2;
+        o.stats.partners = (long long)d.st_partners;
+        o.stats.matches = (long long)d.st_matches;
+        o.stats.rebuilds = (long long)d.st_rounds;  // selection rounds (reported through the spare field)
+        im.timings.iterations += d.iter;
+        im.timings.rescans += (long long)d.st_rescans;
+        im.timings.partners += (long long)d.st_partners;
+        im.timings.table_bytes += (double)d.C * (8 + 4 + 1 + 8 + 2.0 * d.Kpad);
+    }
+    im.timings.loop_ms += loop_ms;
+    im.timings.lockstep_iters += launched_iters;
+    im.timings.chains += n;
+    im.timings.arena_bytes = std::max(im.timings.arena_bytes, (double)arena_bytes);
+    im.timings.total_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    (void)down_bytes;
+    (void)max_n_in;
+}
+
+void HipBackend::column_distances(const int32_t *aug, int n_in, int W, int64_t *d0, int64_t *d1) {
+    Impl &im = *impl_;
+    HIP_CHECK(hipSetDevice(im.device));
+    hipStream_t st = im.stream;
+    size_t a_bytes = align_up((size_t)n_in * W * 4, 256), d_bytes = align_up((size_t)W * W * 8, 256);
+    unsigned char *buf = static_cast<unsigned char *>(im.io_buf.get(a_bytes + 2 * d_bytes));
+    HIP_CHECK(hipMemcpyAsync(buf, aug, (size_t)n_in * W * 4, hipMemcpyHostToDevice, st));
+    auto *dd0 = reinterpret_cast<long long *>(buf + a_bytes), *dd1 = reinterpret_cast<long long *>(buf + a_bytes + d_bytes);
+    hipEvent_t e0, e1;
+    HIP_CHECK(hipEventCreate(&e0));
+    HIP_CHECK(hipEventCreate(&e1));
+    HIP_CHECK(hipEventRecord(e0, st));
+    hipLaunchKernelGGL(k_col_dist, dim3((W + 15) / 16, (W + 15) / 16), dim3(16, 16), 0, st, reinterpret_cast<const int32_t *>(buf), n_in, W, dd0, dd1);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipEventRecord(e1, st));
+    HIP_CHECK(hipMemcpyAsync(d0, dd0, (size_t)W * W * 8, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipMemcpyAsync(d1, dd1, (size_t)W * W * 8, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    float ms = 0;
+    HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    im.timings.dist_ms += ms;
+    im.timings.dist_calls += 1;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+}
+
+int HipBackend::int_to_csd(const int32_t *x, int64_t n, std::vector<int8_t> &csd) {
+    Impl &im = *impl_;
+    HIP_CHECK(hipSetDevice(im.device));
+    hipStream_t st = im.stream;
+    size_t xb = align_up(std::max<size_t>((size_t)n * 4, 4), 256);
+    // two-step: global |max| -> N, then the digits
+    unsigned char *buf = static_cast<unsigned char *>(im.io_buf.get(xb + 256 + (size_t)n * 33));
+    auto *dx = reinterpret_cast<int32_t *>(buf);
+    auto *dmax = reinterpret_cast<unsigned int *>(buf + xb);
+    auto *dout = reinterpret_cast<int8_t *>(buf + xb + 256);
+    HIP_CHECK(hipMemcpyAsync(dx, x, (size_t)n * 4, hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipMemsetAsync(dmax, 0, 4, st));
+    unsigned int mx = 0;
+    if (n > 0) {
+        int blocks = (int)std::min<int64_t>(1024, (n + 255) / 256);
+        hipLaunchKernelGGL(k_absmax, dim3(blocks), dim3(256), 0, st, dx, (long long)n, dmax);
+        HIP_CHECK(hipMemcpyAsync(&mx, dmax, 4, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+    }
+    int N = csd_width(mx);
+    csd.assign((size_t)n * N, 0);
+    if (n > 0) {
+        hipLaunchKernelGGL(k_naf_digits, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dx, (long long)n, N, dout);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipMemcpyAsync(csd.data(), dout, (size_t)n * N, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+    }
+    return N;
+}
+
+int HipBackend::csd_decompose(const float *kernel, int n_in, int n_out, bool center, std::vector<int8_t> &csd,
+                              std::vector<int8_t> &s0, std::vector<int8_t> &s1) {
+    // centring on the device through k_prepare of a one-chain batch, then the digit kernel
+    Impl &im = *impl_;
+    HIP_CHECK(hipSetDevice(im.device));
+    hipStream_t st = im.stream;
+    size_t e = (size_t)n_in * n_out;
+    std::vector<int32_t> xi(e);
+    if (center) {
+        size_t kb = align_up(e * 4, 256), qb = align_up((size_t)n_in * 12, 256);
+        unsigned char *buf = static_cast<unsigned char *>(im.io_buf.get(2 * kb + qb + align_up(n_in, 256) + align_up(n_out, 256) + 512));
+        ChainDev d;
+        std::memset(&d, 0, sizeof d);
+        d.n_in = n_in;
+        d.n_out = n_out;
+        d.kernel = reinterpret_cast<const float *>(buf);
+        d.qints = reinterpret_cast<const float *>(buf + kb);
+        d.xint = reinterpret_cast<int32_t *>(buf + kb + qb);
+        d.shift0 = reinterpret_cast<int8_t *>(buf + 2 * kb + qb);
+        d.shift1 = d.shift0 + align_up(n_in, 256);
+        std::vector<float> ones((size_t)n_in * 3, 1.0f);  // no row is treated as dead here
+        HIP_CHECK(hipMemcpyAsync(buf, kernel, e * 4, hipMemcpyHostToDevice, st));
+        HIP_CHECK(hipMemcpyAsync(buf + kb, ones.data(), ones.size() * 4, hipMemcpyHostToDevice, st));
+        ChainDev *dd = static_cast<ChainDev *>(im.desc_buf.get(sizeof(ChainDev)));
+        HIP_CHECK(hipMemcpyAsync(dd, &d, sizeof d, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_prepare, dim3(1), dim3(256), (size_t)n_out * 4, st, dd);
+        HIP_CHECK(hipGetLastError());
+        s0.resize(n_in);
+        s1.resize(n_out);
+        HIP_CHECK(hipMemcpyAsync(xi.data(), d.xint, e * 4, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipMemcpyAsync(s0.data(), d.shift0, n_in, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipMemcpyAsync(s1.data(), d.shift1, n_out, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+    } else {
+        s0.assign(n_in, 0);
+        s1.assign(n_out, 0);
+        for (size_t k = 0; k < e; ++k) xi[k] = (int32_t)kernel[k];
+    }
+    return int_to_csd(xi.data(), (int64_t)e, csd);
+}
+
+int device_count() {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+}  // namespace gpu
+}  // namespace da

@@ -1,0 +1,49 @@
+// cmvm_gpu.h -- the HIP implementation of da::Backend (kernels in cmvm_engine.hip).
+#pragma once
+
+#include <memory>
+
+#include "cmvm_host.h"
+
+namespace da {
+namespace gpu {
+
+struct GpuTimings {  // accumulated since the last reset; read by the benchmark harness
+    double loop_ms = 0;       // HIP-event time of the greedy loops (k_iter_select + k_iter_update launches)
+    double dist_ms = 0;       // HIP-event time of k_col_dist
+    double total_ms = 0;      // wall time inside run_chains (uploads, set-up, loop, downloads)
+    long long lockstep_iters = 0;  // launched (select, update) kernel pairs
+    long long iterations = 0;      // greedy iterations summed over chains
+    long long rescans = 0;         // table groups re-read by the selection
+    long long partners = 0;        // partner rows processed by the update kernel
+    long long chains = 0;
+    long long dist_calls = 0;
+    double table_bytes = 0;   // bytes of pair-table storage summed over chains
+    double arena_bytes = 0;   // largest device arena used
+};
+
+class HipBackend : public Backend {
+  public:
+    explicit HipBackend(int device = 0);
+    ~HipBackend() override;
+    void run_chains(const ChainJob *jobs, ChainOut *outs, int n) override;
+    void column_distances(const int32_t *aug, int n_in, int W, int64_t *d0, int64_t *d1) override;
+    int csd_decompose(const float *kernel, int n_in, int n_out, bool center, std::vector<int8_t> &csd, std::vector<int8_t> &s0,
+                      std::vector<int8_t> &s1) override;
+    int int_to_csd(const int32_t *x, int64_t n, std::vector<int8_t> &csd) override;
+
+    const GpuTimings &timings() const;
+    void reset_timings();
+    void *stream() const;  // hipStream_t the kernels are launched on
+
+  private:
+    struct Impl;
+    std::unique_ptr<Impl> impl_;
+    double row_scale_ = 1.0;
+    int retry_depth_ = 0;
+};
+
+int device_count();
+
+}  // namespace gpu
+}  // namespace da

@@ -1,0 +1,500 @@
+// cmvm_host.cc -- host side of the MI355X CMVM solver (see cmvm_host.h for the device/host split).
+// Reference behaviour restated here: api.cc (option resolution, candidate search), mat_decompose.cc
+// (MST + m0/m1 assembly), cmvm_core.cc:75-225 (adder trees), state_opr.cc:8-67 (interval / cost model).
+
+#include "cmvm_host.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <memory>
+
+namespace da {
+
+int parse_method(const std::string &name) {
+    static const char *names[] = {"mc", "mc-dc", "mc-pdc", "wmc", "wmc-dc", "wmc-pdc", "dummy"};
+    for (int i = 0; i < 7; ++i)
+        if (name == names[i]) return i;
+    return -1;
+}
+
+// ------------------------------------------------------------------------------- scalar helpers
+QInt qint_add(const QInt &a, const QInt &b, int64_t shift, bool neg_a, bool neg_b) {
+    float lo0 = neg_a ? -a.hi : a.lo, hi0 = neg_a ? -a.lo : a.hi;
+    float lo1 = neg_b ? -b.hi : b.lo, hi1 = neg_b ? -b.lo : b.hi;
+    float scale = (float)std::pow(2.0, (double)shift);
+    lo1 *= scale;
+    hi1 *= scale;
+    float st1 = b.step * scale;
+    return QInt{lo0 + lo1, hi0 + hi1, std::min(a.step, st1)};
+}
+
+void cost_add(const QInt &a, const QInt &b, int64_t shift, bool sub, int adder_size, int carry_size, float &dlat,
+              float &cost) {
+    if (adder_size < 0 && carry_size < 0) {
+        dlat = cost = 1.0f;
+        return;
+    }
+    int adder = adder_size < 0 ? 65535 : adder_size, carry = carry_size < 0 ? 65535 : carry_size;
+    float scale = (float)std::pow(2.0, (double)shift);
+    float lo1 = (sub ? b.hi : b.lo) * scale, hi1 = (sub ? b.lo : b.hi) * scale, st1 = b.step * scale;
+    float hi0 = a.hi + a.step;
+    hi1 += st1;
+    float frac_bits = -std::log2(std::max(a.step, st1));
+    float int_bits = std::ceil(std::log2(std::max({std::abs(a.lo), std::abs(lo1), std::abs(hi0), std::abs(hi1)})));
+    int sign_bit = (a.lo < 0 || b.lo < 0) ? 1 : 0;
+    float width = sign_bit + int_bits + frac_bits;
+    dlat = std::ceil(width / carry);
+    cost = std::ceil(width / adder);
+}
+
+Log2Table measure_log2_table() {
+    Log2Table t;
+    std::memset(t.tie, 0, sizeof t.tie);
+    for (int e = -126; e <= 127; ++e) {
+        int run = 0;
+        for (int k = 1; k < 255; ++k) {
+            float x = std::ldexp(1.0f + (float)k * 0x1p-23f, e);
+            if (std::log2(x) == (float)e)
+                run = k;
+            else
+                break;
+        }
+        t.tie[e + 150] = (uint8_t)run;
+    }
+    return t;
+}
+
+void center_matrix(std::vector<float> &a, int n_in, int n_out, std::vector<int8_t> &s0, std::vector<int8_t> &s1) {
+    s0.assign(n_in, 0);
+    s1.assign(n_out, 0);
+    for (int j = 0; j < n_out; ++j) {
+        int low = 127;
+        for (int i = 0; i < n_in; ++i) low = std::min(low, lsb_loc(a[(size_t)i * n_out + j]));
+        s1[j] = (int8_t)low;
+        double scale = std::pow(2.0, -low);
+        for (int i = 0; i < n_in; ++i) a[(size_t)i * n_out + j] = (float)(a[(size_t)i * n_out + j] * scale);
+    }
+    for (int i = 0; i < n_in; ++i) {
+        int low = 127;
+        for (int j = 0; j < n_out; ++j) low = std::min(low, lsb_loc(a[(size_t)i * n_out + j]));
+        s0[i] = (int8_t)low;
+        double scale = std::pow(2.0, -low);
+        for (int j = 0; j < n_out; ++j) a[(size_t)i * n_out + j] = (float)(a[(size_t)i * n_out + j] * scale);
+    }
+}
+
+// ------------------------------------------------------------------------------- stage 1
+namespace {
+
+struct Stage1 {  // everything about a matrix that does not depend on decompose_dc
+    int n_in = 0, n_out = 0, W = 0;
+    std::vector<float> centered, aug;
+    std::vector<int8_t> s0, s1;
+    std::vector<int64_t> dist, sign;
+    bool have_dist = false;
+};
+
+void stage1_prepare(Stage1 &s, const float *kernel, int n_in, int n_out) {
+    s.n_in = n_in;
+    s.n_out = n_out;
+    s.W = n_out + 1;
+    s.centered.assign(kernel, kernel + (size_t)n_in * n_out);
+    center_matrix(s.centered, n_in, n_out, s.s0, s.s1);
+    s.aug.assign((size_t)n_in * s.W, 0.0f);
+    for (int i = 0; i < n_in; ++i)
+        std::copy_n(&s.centered[(size_t)i * n_out], n_out, &s.aug[(size_t)i * s.W + 1]);
+}
+
+void stage1_distances(Backend &be, Stage1 &s) {
+    if (s.have_dist) return;
+    size_t W = (size_t)s.W;
+    std::vector<int32_t> ai(s.aug.size());
+    for (size_t k = 0; k < ai.size(); ++k) ai[k] = (int32_t)s.aug[k];
+    std::vector<int64_t> d0(W * W), d1(W * W);
+    be.column_distances(ai.data(), s.n_in, s.W, d0.data(), d1.data());
+    s.dist.resize(W * W);
+    s.sign.resize(W * W);
+    for (size_t k = 0; k < W * W; ++k) {
+        s.sign[k] = d1[k] - d0[k] < 0 ? -1 : 1;
+        s.dist[k] = std::min(d0[k], d1[k]);
+    }
+    s.have_dist = true;
+}
+
+// Prim's tree from vertex 0 with the reference's scan order and optional depth cap (mat_decompose.cc:6-60)
+std::vector<std::pair<int, int>> spanning_tree(const std::vector<int64_t> &cost, int V, int dc) {
+    auto edge_lat = [&](int i, int j) { return std::ceil(std::log2((float)std::max<int64_t>(cost[(size_t)i * V + j], 1))); };
+    std::vector<char> in_tree(V, 0);
+    std::vector<int32_t> depth(V, 0);
+    in_tree[0] = 1;
+    float cap = -1.0f;
+    if (dc >= 0) {
+        float top = (float)*std::max_element(cost.begin(), cost.begin() + V);
+        cap = (float)((std::pow(2.0, dc) - 1) + std::ceil(std::log2(top + 1e-32)));
+    }
+    const int64_t blocked = std::numeric_limits<int64_t>::max() / 2;
+    std::vector<std::pair<int, int>> edges;
+    edges.reserve(V > 0 ? V - 1 : 0);
+    for (int step = 1; step < V; ++step) {
+        int64_t best = std::numeric_limits<int64_t>::max();
+        int bi = -1, bj = -1;
+        for (int i = 0; i < V; ++i) {
+            if (in_tree[i]) continue;
+            for (int j = 0; j < V; ++j) {
+                if (!in_tree[j]) continue;
+                int64_t c = cost[(size_t)i * V + j];
+                if (dc >= 0 && std::max(edge_lat(i, j), (float)depth[j]) + 1 > cap) c = blocked;
+                if (c < best) {
+                    best = c;
+                    bi = i;
+                    bj = j;
+                }
+            }
+        }
+        in_tree[bi] = 1;
+        depth[bi] = (int32_t)(std::max(edge_lat(bi, bj), (float)depth[bj]) + 1);
+        edges.emplace_back(bj, bi);
+    }
+    return edges;
+}
+
+void stage1_split(Backend &be, Stage1 &s, int dc, std::vector<float> &m0, std::vector<float> &m1) {
+    int n_in = s.n_in, n_out = s.n_out, W = s.W;
+    m0.assign((size_t)n_in * n_out, 0.0f);
+    m1.assign((size_t)n_out * n_out, 0.0f);
+    if (dc == -1) {  // no decomposition: m0 = centred kernel, m1 = identity (mat_decompose.cc:101-107)
+        m0 = s.centered;
+        for (int j = 0; j < n_out; ++j) m1[(size_t)j * n_out + j] = 1.0f;
+    } else {
+        stage1_distances(be, s);
+        auto edges = spanning_tree(s.dist, W, dc);
+        int used = 0;
+        std::vector<float> delta(n_in), combo(n_out);
+        for (auto [from, to] : edges) {
+            float sg = (float)s.sign[(size_t)to * W + from];
+            bool nonzero = false;
+            for (int i = 0; i < n_in; ++i) {
+                delta[i] = s.aug[(size_t)i * W + to] - s.aug[(size_t)i * W + from] * sg;
+                nonzero |= delta[i] != 0.0f;
+            }
+            for (int r = 0; r < n_out; ++r) combo[r] = from != 0 ? m1[(size_t)r * n_out + (from - 1)] * sg : 0.0f;
+            if (nonzero) {
+                combo[used] = 1.0f;
+                for (int i = 0; i < n_in; ++i) m0[(size_t)i * n_out + used] = delta[i];
+                ++used;
+            }
+            for (int r = 0; r < n_out; ++r) m1[(size_t)r * n_out + (to - 1)] = combo[r];
+        }
+    }
+    for (int i = 0; i < n_in; ++i) {
+        float sc = std::pow(2.0f, (float)s.s0[i]);
+        for (int j = 0; j < n_out; ++j) m0[(size_t)i * n_out + j] *= sc;
+    }
+    for (int j = 0; j < n_out; ++j) {
+        float sc = std::pow(2.0f, (float)s.s1[j]);
+        for (int r = 0; r < n_out; ++r) m1[(size_t)r * n_out + j] *= sc;
+    }
+}
+
+}  // namespace
+
+void kernel_decompose(Backend &be, const float *kernel, int n_in, int n_out, int dc, std::vector<float> &m0,
+                      std::vector<float> &m1) {
+    Stage1 s;
+    stage1_prepare(s, kernel, n_in, n_out);
+    stage1_split(be, s, dc, m0, m1);
+}
+
+// ------------------------------------------------------------------------------- adder trees
+namespace {
+
+struct Term {
+    float lat;
+    int64_t neg, align;
+    QInt q;
+    int64_t id, shift;
+};
+inline bool term_after(const Term &x, const Term &y) {  // x > y in (lat, neg, align, q.lo, q.hi, q.step, id, shift)
+    if (x.lat != y.lat) return x.lat > y.lat;
+    if (x.neg != y.neg) return x.neg > y.neg;
+    if (x.align != y.align) return x.align > y.align;
+    if (x.q.lo != y.q.lo) return x.q.lo > y.q.lo;
+    if (x.q.hi != y.q.hi) return x.q.hi > y.q.hi;
+    if (x.q.step != y.q.step) return x.q.step > y.q.step;
+    if (x.id != y.id) return x.id > y.id;
+    return x.shift > y.shift;
+}
+inline int64_t magnitude_bits(const QInt &q) { return (int64_t)std::log2(std::max(std::abs(q.hi + q.step), std::abs(q.lo))); }
+
+}  // namespace
+
+StageResult finalize_chain(const ChainJob &job, const ChainOut &out) {
+    if (out.error != E_OK) throw std::runtime_error("CMVM chain failed on the device (error " + std::to_string(out.error) + ")");
+    StageResult r;
+    r.n_in = job.n_in;
+    r.n_out = job.n_out;
+    r.adder_size = job.adder_size;
+    r.carry_size = job.carry_size;
+    r.inp_shifts.assign(out.shift0.begin(), out.shift0.end());
+    size_t n_iter = out.picks.size() / 4;
+    r.ops.reserve(job.n_in + n_iter * 2);
+    for (int i = 0; i < job.n_in; ++i) r.ops.push_back(OpRec{i, -1, -1, 0, job.qints[i], job.lats[i], 0.0f});
+    // op records of the greedy picks, with the host libm (state_opr.cc:211-225)
+    for (size_t t = 0; t < n_iter; ++t) {
+        int64_t a = out.picks[4 * t], b = out.picks[4 * t + 1];
+        bool sub = out.picks[4 * t + 2] != 0;
+        int64_t shift = out.picks[4 * t + 3];
+        const OpRec &oa = r.ops[a], &ob = r.ops[b];
+        float dlat, cost;
+        cost_add(oa.q, ob.q, shift, sub, job.adder_size, job.carry_size, dlat, cost);
+        float lat = std::max(oa.latency, ob.latency) + dlat;
+        float seen = out.row_lat[job.n_in + t];
+        if (std::memcmp(&lat, &seen, 4) != 0 && !(lat != lat && seen != seen))
+            throw std::runtime_error("device latency model diverged from the host libm at iteration " + std::to_string(t));
+        r.ops.push_back(OpRec{a, b, (int64_t)sub, shift, qint_add(oa.q, ob.q, shift, false, sub), lat, cost});
+    }
+    // one min-heap reduction per output column (cmvm_core.cc:103-210)
+    std::vector<Term> heap;
+    auto cmp = [](const Term &x, const Term &y) { return term_after(x, y); };
+    for (int j = 0; j < job.n_out; ++j) {
+        heap.clear();
+        for (uint32_t k = out.col_start[j]; k < out.col_start[j + 1]; ++k) {
+            uint64_t cell = out.dig_cell[k];
+            uint32_t plus = (uint32_t)cell, minus = (uint32_t)(cell >> 32), any = plus | minus;
+            int64_t row = out.dig_row[k];
+            while (any) {
+                int pos = __builtin_ctz(any);
+                any &= any - 1;
+                const OpRec &o = r.ops[row];
+                heap.push_back(Term{o.latency, (int64_t)((minus >> pos) & 1), magnitude_bits(o.q) + pos, o.q, row, pos});
+            }
+        }
+        if (heap.empty()) {
+            r.out_idxs.push_back(-1);
+            r.out_shifts.push_back(out.shift1[j]);
+            r.out_negs.push_back(0);
+            continue;
+        }
+        if (heap.size() == 1) {
+            r.out_idxs.push_back(heap[0].id);
+            r.out_shifts.push_back((int64_t)out.shift1[j] + heap[0].shift);
+            r.out_negs.push_back(heap[0].neg);
+            continue;
+        }
+        std::make_heap(heap.begin(), heap.end(), cmp);
+        while (heap.size() > 1) {
+            std::pop_heap(heap.begin(), heap.end(), cmp);
+            Term first = heap.back();
+            heap.pop_back();
+            std::pop_heap(heap.begin(), heap.end(), cmp);
+            Term second = heap.back();
+            heap.pop_back();
+            // the result is anchored on the non-negated operand when the first one is negative
+            const Term &base = first.neg ? second : first, &other = first.neg ? first : second;
+            int64_t sh = other.shift - base.shift;
+            bool sub_op = first.neg ? (second.neg == 0) : (second.neg != 0);
+            QInt q = qint_add(base.q, other.q, sh, base.neg != 0, other.neg != 0);
+            float dlat, cost;
+            cost_add(base.q, other.q, sh, sub_op, job.adder_size, job.carry_size, dlat, cost);
+            float lat = std::max(first.lat, second.lat) + dlat;
+            int64_t id = (int64_t)r.ops.size();
+            r.ops.push_back(OpRec{base.id, other.id, (int64_t)sub_op, sh, q, lat, cost});
+            heap.push_back(Term{lat, first.neg & second.neg, magnitude_bits(q) + base.shift, q, id, base.shift});
+            std::push_heap(heap.begin(), heap.end(), cmp);
+        }
+        r.out_idxs.push_back((int64_t)r.ops.size() - 1);
+        r.out_negs.push_back(heap[0].neg);
+        r.out_shifts.push_back((int64_t)out.shift1[j] + heap[0].shift);
+    }
+    return r;
+}
+
+// ------------------------------------------------------------------------------- search orchestration
+namespace {
+
+bool has_dc_suffix(const std::string &m) { return m.size() >= 2 && m.compare(m.size() - 2, 2, "dc") == 0; }
+
+struct Candidate {  // one _solve() of the reference (api.cc:28-145) as a resumable state machine
+    int problem = 0;
+    std::string method0, method1;
+    int hard_dc = -1, decompose_dc = -2;
+    float allowed = std::numeric_limits<float>::infinity();
+    enum Phase { NEED_MINLAT, NEED_STAGE0, NEED_STAGE1, DONE } phase = NEED_STAGE0;
+    std::vector<float> m0, m1;
+    StageResult sol0, sol1;
+    std::vector<QInt> q_mid;
+    std::vector<float> lat_mid;
+};
+
+struct ProblemState {
+    const Problem *p = nullptr;
+    std::vector<QInt> qints;
+    std::vector<float> lats;
+    Stage1 s1;
+    bool minlat_known = false;
+    float minlat = 0.0f;
+    std::vector<int> cand;  // indices into the candidate array
+};
+
+float max_out_latency(const StageResult &s) {
+    float top = 0.0f;
+    for (auto idx : s.out_idxs) top = std::max(top, idx >= 0 ? s.ops[idx].latency : 0.0f);
+    return top;
+}
+
+}  // namespace
+
+std::vector<PipeResult> solve_batch(Backend &be, const std::vector<Problem> &problems, std::vector<ChainStats> *stats) {
+    std::vector<ProblemState> ps(problems.size());
+    std::vector<Candidate> cands;
+    for (size_t i = 0; i < problems.size(); ++i) {
+        const Problem &p = problems[i];
+        ProblemState &s = ps[i];
+        s.p = &p;
+        s.qints = p.opt.qints.empty() ? std::vector<QInt>(p.n_in, QInt{-128.0f, 127.0f, 1.0f}) : p.opt.qints;
+        s.lats = p.opt.lats.empty() ? std::vector<float>(p.n_in, 0.0f) : p.opt.lats;
+        if ((int)s.qints.size() != p.n_in || (int)s.lats.size() != p.n_in)
+            throw std::invalid_argument("qintervals / latencies must have one entry per kernel row");
+        stage1_prepare(s.s1, p.kernel, p.n_in, p.n_out);
+        int log2_n = (int)std::ceil(std::log2((float)p.n_in));
+        std::vector<std::pair<int, int>> tries;  // (hard_dc, decompose_dc)
+        if (!p.opt.search_all)
+            tries.emplace_back(p.opt.hard_dc, p.opt.decompose_dc);
+        else {
+            int hdc = p.opt.hard_dc < 0 ? 1000000000 : p.opt.hard_dc;
+            for (int d = -1; d <= std::min(hdc, log2_n); ++d) tries.emplace_back(hdc, d);
+        }
+        for (auto [hdc, ddc] : tries) {
+            Candidate c;
+            c.problem = (int)i;
+            c.method0 = p.opt.method0;
+            c.method1 = p.opt.method1;
+            c.hard_dc = hdc;
+            if (c.method1 == "auto") c.method1 = (hdc >= 6 || has_dc_suffix(c.method0)) ? c.method0 : c.method0 + "-dc";
+            if (hdc == 0 && !has_dc_suffix(c.method0)) c.method0 += "-dc";
+            c.decompose_dc = ddc == -2 ? std::min(hdc, log2_n) : std::min({hdc, ddc, log2_n});
+            c.phase = hdc >= 0 ? Candidate::NEED_MINLAT : Candidate::NEED_STAGE0;
+            s.cand.push_back((int)cands.size());
+            cands.push_back(std::move(c));
+        }
+    }
+
+    auto prepare_stage0 = [&](Candidate &c) {
+        ProblemState &s = ps[c.problem];
+        if (c.decompose_dc < 0 && c.hard_dc >= 0) c.method0 = c.method1 = (c.method0 != "dummy") ? "wmc-dc" : "dummy";
+        stage1_split(be, s.s1, c.decompose_dc, c.m0, c.m1);
+    };
+
+    struct Pending {
+        int cand;
+        int what;  // 0 = minimal latency probe, 1 = stage 0, 2 = stage 1
+        int problem;
+    };
+    while (true) {
+        std::vector<ChainJob> jobs;
+        std::vector<Pending> owners;
+        std::vector<char> minlat_queued(ps.size(), 0);
+        for (size_t ci = 0; ci < cands.size(); ++ci) {
+            Candidate &c = cands[ci];
+            ProblemState &s = ps[c.problem];
+            const Problem &p = *s.p;
+            if (c.phase == Candidate::NEED_MINLAT) {
+                if (s.minlat_known) {
+                    c.allowed = c.hard_dc + s.minlat;
+                    c.phase = Candidate::NEED_STAGE0;
+                } else if (!minlat_queued[c.problem]) {
+                    // minimal_latency(): adder trees straight from the CSD digits (api.cc:11-26)
+                    jobs.push_back(ChainJob{p.kernel, p.n_in, p.n_out, M_DUMMY, s.qints.data(), s.lats.data(), p.opt.adder_size, p.opt.carry_size});
+                    owners.push_back(Pending{(int)ci, 0, c.problem});
+                    minlat_queued[c.problem] = 1;
+                    continue;
+                } else
+                    continue;
+            }
+            if (c.phase == Candidate::NEED_STAGE0) {
+                prepare_stage0(c);
+                jobs.push_back(ChainJob{c.m0.data(), p.n_in, p.n_out, parse_method(c.method0), s.qints.data(), s.lats.data(), p.opt.adder_size, p.opt.carry_size});
+                owners.push_back(Pending{(int)ci, 1, c.problem});
+            } else if (c.phase == Candidate::NEED_STAGE1) {
+                jobs.push_back(ChainJob{c.m1.data(), p.n_out, p.n_out, parse_method(c.method1), c.q_mid.data(), c.lat_mid.data(), p.opt.adder_size, p.opt.carry_size});
+                owners.push_back(Pending{(int)ci, 2, c.problem});
+            }
+        }
+        if (jobs.empty()) break;
+        std::vector<ChainOut> outs(jobs.size());
+        be.run_chains(jobs.data(), outs.data(), (int)jobs.size());
+        for (size_t k = 0; k < jobs.size(); ++k) {
+            Candidate &c = cands[owners[k].cand];
+            ProblemState &s = ps[c.problem];
+            if (stats) {
+                if (stats->size() < problems.size()) stats->resize(problems.size());
+                ChainStats &a = (*stats)[c.problem];
+                const ChainStats &b = outs[k].stats;
+                a.iterations += b.iterations;
+                a.digits0 += b.digits0;
+                a.blocks0 += b.blocks0;
+                a.rebuilds += b.rebuilds;
+                a.table_peak = std::max(a.table_peak, b.table_peak);
+                a.scan_slots += b.scan_slots;
+                a.partners += b.partners;
+                a.matches += b.matches;
+            }
+            if (outs[k].unknown_method_hit)
+                throw std::runtime_error("Unknown method: " + (owners[k].what == 2 ? c.method1 : c.method0));
+            StageResult sol = finalize_chain(jobs[k], outs[k]);
+            bool both_wmc_dc = c.method0 == "wmc-dc" && c.method1 == "wmc-dc";
+            if (owners[k].what == 0) {
+                s.minlat = max_out_latency(sol);
+                s.minlat_known = true;
+                continue;  // candidates pick the value up at the top of the next round
+            }
+            if (owners[k].what == 1) {
+                c.sol0 = std::move(sol);
+                c.q_mid.clear();
+                c.lat_mid.clear();
+                for (auto idx : c.sol0.out_idxs) {
+                    c.lat_mid.push_back(idx >= 0 ? c.sol0.ops[idx].latency : 0.0f);
+                    c.q_mid.push_back(idx >= 0 ? c.sol0.ops[idx].q : QInt{0.0f, 0.0f, std::numeric_limits<float>::infinity()});
+                }
+                if (max_out_latency(c.sol0) > c.allowed && (!both_wmc_dc || c.decompose_dc >= 0)) {
+                    c.decompose_dc--;
+                    c.phase = Candidate::NEED_STAGE0;
+                } else
+                    c.phase = Candidate::NEED_STAGE1;
+            } else {
+                c.sol1 = std::move(sol);
+                if (max_out_latency(c.sol1) > c.allowed && (!both_wmc_dc || c.decompose_dc >= 0)) {
+                    c.decompose_dc--;
+                    c.phase = Candidate::NEED_STAGE0;
+                } else
+                    c.phase = Candidate::DONE;
+            }
+        }
+    }
+
+    std::vector<PipeResult> results(problems.size());
+    for (size_t i = 0; i < problems.size(); ++i) {
+        ProblemState &s = ps[i];
+        int best = 0;
+        if (s.p->opt.search_all) {
+            std::vector<float> costs;
+            for (int ci : s.cand) {
+                float total = 0.0f;
+                for (const StageResult *st : {&cands[ci].sol0, &cands[ci].sol1})
+                    for (const OpRec &op : st->ops) total += op.cost;
+                costs.push_back(total);
+            }
+            for (size_t k = 1; k < costs.size(); ++k)
+                if (costs[k] < costs[best]) best = (int)k;
+            results[i].picked = best;
+        }
+        Candidate &w = cands[s.cand[best]];
+        results[i].stages.push_back(std::move(w.sol0));
+        results[i].stages.push_back(std::move(w.sol1));
+    }
+    return results;
+}
+
+}  // namespace da

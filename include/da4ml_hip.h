@@ -1,0 +1,95 @@
+/* da4ml_hip.h -- C ABI of libda4ml_hip.so, the MI355X-native drop-in for da4ml's native CMVM module.
+ *
+ * Every entry point replaces one binding of the reference's nanobind module `cmvm_bin`
+ * (reference src/da4ml/_binary/cmvm/bindings.cc:227-264, re-exported by src/da4ml/_binary/__init__.py:4 and
+ * src/da4ml/cmvm/__init__.py:7).  Plain pointers and sizes only; no Python, torch or HIP types cross this
+ * boundary.  All matrices are dense row-major; `kernel` is float32 [n_in, n_out] holding dyadic rationals
+ * exactly (the reference's own contract, trace/fixed_variable_array.py:76).
+ *
+ * Error handling: functions returning int give 0 on success and a negative DA_ERR_* otherwise; functions returning
+ * a handle give NULL on error.  da_last_error() returns the message of the calling thread's last failure
+ * (the reference raises C++ exceptions that nanobind maps to Python exceptions, bindings.cc / api.cc:207-240).
+ * The library never keeps pointers to caller memory after a call returns.
+ *
+ * Threading: calls are serialised per device by an internal mutex; solves of a batch run concurrently on the GPU.
+ */
+#ifndef DA4ML_HIP_H
+#define DA4ML_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DA_OK 0
+#define DA_ERR_RUNTIME (-1)  /* maps to Python RuntimeError (std::runtime_error in the reference) */
+#define DA_ERR_VALUE (-2)    /* maps to Python ValueError   (std::invalid_argument in the reference) */
+#define DA_ERR_NO_DEVICE (-3)
+
+typedef struct da_result da_result; /* one solved Pipeline (two CombLogic stages) */
+
+/* ---- library / device ------------------------------------------------------------------------------------ */
+const char *da_last_error(void);
+const char *da_version(void);
+int da_device_count(void);     /* number of visible HIP devices (0 if none) */
+int da_set_device(int device); /* device used by subsequent calls of this process (default 0) */
+
+/* ---- scalar helpers -------------------------------------------------------------------------------------- */
+/* cmvm_bin.get_lsb_loc (bindings.cc:229 -> bit_decompose.cc:10-20) */
+int da_get_lsb_loc(float x);
+/* cmvm_bin.iceil_log2 (bindings.cc:230 -> indexers.hh:12-18) */
+int da_iceil_log2(float x);
+/* cmvm_bin.cost_add (bindings.cc:25-41,249-263 -> state_opr.cc:31-67); q0,q1 = {min,max,step}; out2 = {latency,cost} */
+int da_cost_add(const float *q0, const float *q1, int64_t shift, int sub, int adder_size, int carry_size, float *out2);
+
+/* ---- decompositions (run on the GPU) --------------------------------------------------------------------- */
+/* cmvm_bin.int_arr_to_csd (bindings.cc:43-61,228 -> bit_decompose.cc:22-42).  Returns the digit count N (>= 1) or a
+ * negative error; `out` may be NULL to query N, otherwise int8 [n, N]. */
+int da_int_arr_to_csd(const int32_t *x, int64_t n, int8_t *out);
+/* cmvm_bin.csd_decompose (bindings.cc:63-103,231 -> bit_decompose.cc:45-62).  Returns N or a negative error; `csd`
+ * (int8 [n_in, n_out, N]), `shift0` (int8 [n_in]), `shift1` (int8 [n_out]) may be NULL to query N. */
+int da_csd_decompose(const float *kernel, int64_t n_in, int64_t n_out, int center, int8_t *csd, int8_t *shift0, int8_t *shift1);
+/* cmvm_bin.kernel_decompose (bindings.cc:232-234 -> mat_decompose.cc:63-169): m0 float32 [n_in,n_out], m1 [n_out,n_out] */
+int da_kernel_decompose(const float *kernel, int64_t n_in, int64_t n_out, int dc, float *m0, float *m1);
+
+/* ---- solve ------------------------------------------------------------------------------------------------ */
+/* cmvm_bin.solve (bindings.cc:184-225,235-248 -> api.cc:147-250).  `qintervals` is float32 [n_in,3] or NULL
+ * (default (-128,127,1)), `latencies` float32 [n_in] or NULL (default 0).  Steps must be powers of two. */
+da_result *da_solve(const float *kernel, int64_t n_in, int64_t n_out, const char *method0, const char *method1, int hard_dc,
+                    int decompose_dc, const float *qintervals, const float *latencies, int adder_size, int carry_size,
+                    int search_all_decompose_dc);
+
+/* Batched form of da_solve (addition): `count` independent problems sharing the option
+ * set are solved concurrently on the device.  kernels[i] is [n_in[i], n_out[i]]; qintervals / latencies may be NULL
+ * or hold per-problem pointers (each possibly NULL).  results[i] receives a handle (to be freed with da_free).
+ * Returns DA_OK, or an error in which case no handle is returned. */
+int da_solve_batch(int count, const float *const *kernels, const int64_t *n_in, const int64_t *n_out, const char *method0,
+                   const char *method1, int hard_dc, int decompose_dc, const float *const *qintervals,
+                   const float *const *latencies, int adder_size, int carry_size, int search_all_decompose_dc,
+                   da_result **results);
+
+/* ---- result access (da4ml.types.Pipeline / CombLogic / Op, bindings.cc:106-151) ---------------------------- */
+int da_n_stages(const da_result *r);
+/* index of the winning decompose_dc candidate when search_all_decompose_dc was set, else -1 */
+int da_picked(const da_result *r);
+/* info[0..4] = n_in, n_out, n_ops, carry_size, adder_size */
+int da_stage_info(const da_result *r, int stage, int64_t *info);
+/* inp_shifts[n_in], out_idxs[n_out], out_shifts[n_out], out_negs[n_out] (0/1), ops_i[n_ops,4] = id0,id1,opcode,data,
+ * ops_f[n_ops,5] = qint.min,qint.max,qint.step,latency,cost */
+int da_stage_copy(const da_result *r, int stage, int64_t *inp_shifts, int64_t *out_idxs, int64_t *out_shifts, int64_t *out_negs,
+                  int64_t *ops_i, float *ops_f);
+/* stats[0..7] = greedy iterations, initial digits, -, selection rounds, peak pair blocks, re-read table slots,
+ * partner rows updated, substituted digits -- summed over the chains run for this problem */
+int da_result_stats(const da_result *r, int64_t *stats);
+void da_free(da_result *r);
+
+/* ---- instrumentation for the benchmark harness ------------------------------------------------------------- */
+/* t[0..9] = loop_ms (HIP events around the greedy-loop launches), dist_ms, total_ms, lockstep iterations,
+ * greedy iterations, table groups re-read, partner rows, chains, table bytes, arena bytes -- accumulated since reset */
+int da_timings(double *t, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DA4ML_HIP_H */

@@ -35,8 +35,14 @@ def build(targets=('liboracle.so', 'ref')):
 class Oracle:
     def __init__(self, kind: str = 'port'):
         self.kind = kind
-        path, self.p = {'port': (HERE / 'liboracle.so', 'orc_'), 'ref': (HERE / '_ref' / 'libref.so', 'ref_')}[kind]
-        if not path.exists():
+        path, self.p = {
+            'port': (HERE / 'liboracle.so', 'orc_'),
+            'ref': (HERE / '_ref' / 'libref.so', 'ref_'),
+            'model': (HERE.parent / 'tests' / 'model' / 'libmodel.so', 'mdl_'),  # sequential model of the GPU engine
+        }[kind]
+        if kind == 'model':
+            subprocess.run(['make', '-C', str(path.parent), 'libmodel.so'], check=True, stdout=subprocess.DEVNULL)
+        elif not path.exists():
             build(('liboracle.so',) if kind == 'port' else ('ref',))
         if not path.exists():
             raise FileNotFoundError(f'{path} is not built (kind={kind})')

@@ -1,0 +1,58 @@
+"""Seeded inputs shared by the CPU and GPU parity tests (no unseeded randomness, unlike the reference's tests)."""
+
+import numpy as np
+
+
+def int_matrix(seed, n_in, n_out, lo, hi):
+    return np.random.default_rng(seed).integers(lo, hi, (n_in, n_out)).astype(np.float32)
+
+
+def reference_style_kernel(seed, n, bits):
+    """The generator of the reference's tests/test_cmvm.py:17-20, seeded."""
+    r = np.random.default_rng(seed)
+    return np.round((r.random((n, n)) - 0.5) * 2 ** (bits + 1)).astype(np.float32)
+
+
+def random_case(seed):
+    """A random small matrix with a random option set, covering every method / cost-model / search combination."""
+    rng = np.random.default_rng(seed)
+    n_in, n_out = (int(v) for v in rng.integers(1, 13, 2))
+    b = int(rng.integers(1, 10))
+    k = (rng.random((n_in, n_out)).astype(np.float32) * 2**b - 2 ** (b - 1)).round()
+    if seed % 5 == 0:
+        k *= 2.0 ** int(rng.integers(-3, 3))
+    if seed % 7 == 0:
+        k[rng.integers(0, n_in)] = 0
+    if seed % 11 == 0:
+        k[:, rng.integers(0, n_out)] = 0
+    k = np.ascontiguousarray(k, dtype=np.float32)
+    opts = dict(
+        method0=str(rng.choice(['mc', 'wmc', 'mc-dc', 'wmc-dc', 'mc-pdc', 'wmc-pdc'])),
+        method1=str(rng.choice(['auto', 'mc', 'wmc', 'wmc-dc', 'mc-pdc'])),
+        hard_dc=int(rng.choice([-1, 0, 1, 2, 3])),
+        decompose_dc=int(rng.choice([-2, -1, 0, 1, 2])),
+        adder_size=int(rng.choice([-1, 1, 4])),
+        carry_size=int(rng.choice([-1, 2, 8])),
+        search_all_decompose_dc=bool(rng.integers(0, 2)),
+    )
+    zero_input = False
+    if seed % 3 == 0:
+        lo = rng.integers(-64, 1, n_in)
+        hi = lo + rng.integers(0, 200, n_in)
+        st = 2.0 ** rng.integers(-3, 2, n_in)
+        opts['qintervals'] = [(float(a * s), float(c * s), float(s)) for a, c, s in zip(lo, hi, st)]
+        opts['latencies'] = [float(v) for v in rng.integers(0, 4, n_in)]
+        if seed % 6 == 0:
+            opts['qintervals'][0] = (0.0, 0.0, 1.0)
+            zero_input = True
+    return k, opts, zero_input
+
+
+TEST_CMVM_GRID = [
+    dict(hard_dc=h, method0=m0, method1=m1, decompose_dc=d, search_all_decompose_dc=s, adder_size=1, carry_size=-1)
+    for h in (0, 2, -1)
+    for m0 in ('mc', 'wmc')
+    for m1 in ('mc', 'wmc')
+    for d in (0, -1, -2)
+    for s in (False, True)
+]

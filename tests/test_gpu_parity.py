@@ -1,0 +1,92 @@
+"""GPU parity: the HIP path (through the C ABI) must reproduce the oracle's op lists bit for bit."""
+
+import numpy as np
+import pytest
+
+from cases import TEST_CMVM_GRID, int_matrix, random_case, reference_style_kernel
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def hip():
+    from da4ml_amd import _binary
+
+    assert _binary.device_count() >= 1, 'no HIP device visible: the GPU tests must run on the MI355X box'
+    return _binary
+
+
+def test_scalar_and_decompositions(hip, oracle):
+    rng = np.random.default_rng(7)
+    for x in list(rng.standard_normal(64).astype(np.float32)) + [0.0, 1.0, 0.375, 65536.0]:
+        assert hip.get_lsb_loc(float(x)) == oracle.get_lsb_loc(float(x))
+    for n, bits in [(2, 2), (4, 4), (8, 8), (13, 6)]:
+        k = reference_style_kernel(n * 100 + bits, n, bits)
+        a, b = hip.csd_decompose(k), oracle.csd_decompose(k)
+        assert all(np.array_equal(x, y) for x, y in zip(a, b))
+        csd, s0, s1 = a
+        rec = (csd * 2.0 ** s0[:, None, None] * 2.0 ** s1[None, :, None] * 2.0 ** np.arange(csd.shape[-1])[None, None, :]).sum(-1)
+        assert np.all(rec == k)  # reference tests/test_cmvm.py:23-28
+        for dc in (-2, -1, 0, 1, 2):
+            m = hip.kernel_decompose(k, dc)
+            assert all(np.array_equal(x, y) for x, y in zip(m, oracle.kernel_decompose(k, dc)))
+            assert np.all(m[0] @ m[1] == k)  # reference tests/test_cmvm.py:31-35
+    x = rng.integers(-70000, 70000, (5, 7)).astype(np.int32)
+    assert np.array_equal(hip.int_arr_to_csd(x), oracle.int_arr_to_csd(x))
+
+
+@pytest.mark.parametrize('seed', range(120))
+def test_random_small(hip, oracle, seed):
+    k, opts, zero_input = random_case(seed)
+    got, want = hip.solve(k, **opts), oracle.solve(k, **opts)
+    assert got == want
+    if not zero_input:
+        assert np.all(got.kernel == k)
+
+
+@pytest.mark.parametrize('n,bits', [(2, 2), (4, 4), (8, 8), (8, 2)])
+def test_reference_grid(hip, oracle, n, bits):
+    """The 72-combination grid of the reference's tests/test_cmvm.py:38-55, with op-list equality on top."""
+    k = reference_style_kernel(n * 10 + bits, n, bits)
+    for opts in TEST_CMVM_GRID:
+        got = hip.solve(k, **opts)
+        assert got == oracle.solve(k, **opts), opts
+        assert np.all(got.kernel == k)
+
+
+@pytest.mark.parametrize('seed', range(8))
+def test_c1_16x16_int4(hip, oracle, seed):
+    k = int_matrix(seed, 16, 16, -8, 8)
+    for opts in (dict(), dict(adder_size=1, carry_size=-1)):
+        assert hip.solve(k, **opts) == oracle.solve(k, **opts)
+
+
+@pytest.mark.parametrize('seed', range(2))
+def test_c2_64x64_int8_single_chain(hip, oracle, seed):
+    k = int_matrix(seed, 64, 64, -128, 128)
+    opts = dict(method0='wmc', method1='wmc', decompose_dc=-1, search_all_decompose_dc=False)
+    got = hip.solve(k, **opts)
+    assert got == oracle.solve(k, **opts)
+    assert np.all(got.kernel == k)
+
+
+def test_batch_equals_single(hip, oracle):
+    ks = [int_matrix(s, 12 + s, 9 + s, -32, 32) for s in range(6)]
+    got = hip.solve_many(ks, adder_size=1, carry_size=-1)
+    for k, g in zip(ks, got):
+        assert g == oracle.solve(k, adder_size=1, carry_size=-1)
+
+
+def test_wide_digits(hip, oracle):
+    """more than 16 CSD digits per entry -> 64-bit cells"""
+    k = (int_matrix(3, 6, 5, -(2**19), 2**19)).astype(np.float32)
+    assert hip.solve(k) == oracle.solve(k)
+
+
+def test_errors(hip):
+    with pytest.raises(TypeError):
+        hip.solve(np.eye(3))
+    with pytest.raises(RuntimeError, match='Unknown method'):
+        hip.solve(int_matrix(0, 8, 8, -8, 8), method0='nope', search_all_decompose_dc=False)
+    with pytest.raises(ValueError):
+        hip.solve(np.eye(3, dtype=np.float32), qintervals=[(-1.0, 1.0, 0.3)] * 3)
