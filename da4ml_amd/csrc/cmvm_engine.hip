@@ -61,7 +61,6 @@ constexpr int SEL_THREADS = 1024;  // k_iter_select block (16 waves)
 constexpr int UPD_THREADS = 256;   // k_iter_update block
 constexpr int UPD_WAVES = UPD_THREADS / WAVE;
 constexpr int MAX_GROUPS = 8192;   // ub[] copy held in LDS by k_iter_select (64 KiB of u64)
-constexpr int UNIT = 256;          // list entries per update work unit
 
 struct HStat {
     int ov;
@@ -95,8 +94,8 @@ struct ChainDev {
     // per-iteration hand-off select -> update
     int *mcol;
     void *mA, *mB;
-    int *unit_off;
-    int m, n_units;
+    uint32_t *plist;
+    int m, n_partners;
     unsigned int work_ctr;
     uint32_t A, B, Nw;
     // progress
@@ -160,99 +159,153 @@ __device__ __forceinline__ unsigned long long bound_word(uint32_t rank, unsigned
 }
 
 // ------------------------------------------------------------------------------------------------ table ops
+// Register-resident copy of the constant part of a chain descriptor (wave-uniform, lives in SGPRs); `g` is used
+// for the few mutable counters only.
+struct Ctx {
+    int n_out, n_bits, K, Kpad, method, gs_log2;
+    uint32_t cmask, windows;
+    unsigned long long *hkey;
+    uint32_t *hrank;
+    uint8_t *hidx;
+    HStat *hstat;
+    uint16_t *hcnt;
+    unsigned long long *ub;
+    const RowInfo *rows;
+    ChainDev *g;
+};
+__device__ __forceinline__ Ctx make_ctx(ChainDev *g) {
+    Ctx c;
+    c.n_out = g->n_out;
+    c.n_bits = g->n_bits;
+    c.K = g->K;
+    c.Kpad = g->Kpad;
+    c.method = g->method;
+    c.gs_log2 = g->gs_log2;
+    c.cmask = g->cmask;
+    c.windows = g->C / WAVE ? g->C / WAVE : 1;
+    c.hkey = g->hkey;
+    c.hrank = g->hrank;
+    c.hidx = g->hidx;
+    c.hstat = g->hstat;
+    c.hcnt = g->hcnt;
+    c.ub = g->ub;
+    c.rows = g->rows;
+    c.g = g;
+    return c;
+}
+
 // All table operations are executed by one full wavefront; lane order == probe order inside a 64-slot window.
 
+// resolve one probe window: 1 = found (slot set), 0 = absent, -1 = undecided (continue with the next window)
+__device__ __forceinline__ int probe_window(unsigned long long kk, unsigned long long key, uint32_t start, uint32_t cmask, int &slot) {
+    unsigned long long hit = __ballot(kk == key);
+    unsigned long long emp = __ballot(kk == KEY_EMPTY);
+    if (hit) {
+        int l = __ffsll((long long)hit) - 1;
+        if (emp && (__ffsll((long long)emp) - 1) < l) return 0;
+        slot = (int)((start + l) & cmask);
+        return 1;
+    }
+    return emp ? 0 : -1;
+}
 // returns slot or -1
-__device__ int table_find(const ChainDev &ch, unsigned long long key, uint32_t h) {
+__device__ int table_find_from(const Ctx &c, unsigned long long key, uint32_t h, uint32_t first_window) {
     int lane = lane_id();
-    uint32_t windows = ch.C / WAVE ? ch.C / WAVE : 1;
-    for (uint32_t w = 0; w < windows; ++w) {
-        uint32_t s = (h + w * WAVE + lane) & ch.cmask;
-        unsigned long long kk = ch.hkey[s];
-        unsigned long long hit = __ballot(kk == key);
-        unsigned long long emp = __ballot(kk == KEY_EMPTY);
-        if (hit) {
-            int l = __ffsll((long long)hit) - 1;
-            if (emp && (__ffsll((long long)emp) - 1) < l) return -1;
-            return (int)((h + w * WAVE + l) & ch.cmask);
-        }
-        if (emp) return -1;
+    for (uint32_t w = first_window; w < c.windows; ++w) {
+        unsigned long long kk = c.hkey[(h + w * WAVE + lane) & c.cmask];
+        int slot = -1;
+        int r = probe_window(kk, key, h + w * WAVE, c.cmask, slot);
+        if (r >= 0) return r ? slot : -1;
     }
     return -1;
 }
+__device__ __forceinline__ int table_find(const Ctx &c, unsigned long long key, uint32_t h) { return table_find_from(c, key, h, 0); }
+// two independent look-ups with their first probe windows in flight together
+__device__ __forceinline__ void table_find2(const Ctx &c, unsigned long long key0, uint32_t h0, unsigned long long key1, uint32_t h1,
+                                            bool want1, int &slot0, int &slot1) {
+    int lane = lane_id();
+    unsigned long long k0 = c.hkey[(h0 + lane) & c.cmask];
+    unsigned long long k1 = want1 ? c.hkey[(h1 + lane) & c.cmask] : KEY_EMPTY;
+    slot0 = slot1 = -1;
+    int r0 = probe_window(k0, key0, h0, c.cmask, slot0);
+    if (r0 < 0) slot0 = table_find_from(c, key0, h0, 1);
+    if (want1) {
+        int r1 = probe_window(k1, key1, h1, c.cmask, slot1);
+        if (r1 < 0) slot1 = table_find_from(c, key1, h1, 1);
+    }
+}
 
 // claim a slot for a key that is known to be absent; returns slot or -1 (table full)
-__device__ int table_claim(ChainDev &ch, unsigned long long key, uint32_t h) {
+__device__ int table_claim(const Ctx &c, unsigned long long key, uint32_t h) {
     int lane = lane_id();
-    uint32_t windows = ch.C / WAVE ? ch.C / WAVE : 1;
-    for (uint32_t w = 0; w < windows; ++w) {
-        uint32_t s = (h + w * WAVE + lane) & ch.cmask;
-        unsigned long long kk = ch.hkey[s];
+    for (uint32_t w = 0; w < c.windows; ++w) {
+        uint32_t s = (h + w * WAVE + lane) & c.cmask;
+        unsigned long long kk = c.hkey[s];
         unsigned long long avail = __ballot(kk == KEY_EMPTY || kk == KEY_TOMB);
         while (avail) {
             int l = __ffsll((long long)avail) - 1;
             avail &= avail - 1;
             int ok = 0;
             if (lane == l) {
-                ok = atomicCAS(&ch.hkey[s], kk, key) == kk;
-                if (ok && kk == KEY_EMPTY) atomicAdd(&ch.n_used, 1u);
+                ok = atomicCAS(&c.hkey[s], kk, key) == kk;
+                if (ok && kk == KEY_EMPTY) atomicAdd(&c.g->n_used, 1u);
             }
             ok = __shfl(ok, l);
-            if (ok) return (int)((h + w * WAVE + l) & ch.cmask);
+            if (ok) return (int)((h + w * WAVE + l) & c.cmask);
         }
     }
     return -1;
 }
 
 // Store a complete block.  cnt_of(k) gives the count of key k; returns false when the table is full.
-// Precondition: at least one count >= 2 (checked by the caller), key absent.
+// Precondition: at least one count >= 2 (checked by the caller), key absent.  ra / rb: intervals of rows lo / hi.
 template <class CntFn>
-__device__ bool table_insert(ChainDev &ch, uint32_t lo, uint32_t hi, CntFn cnt_of) {
+__device__ bool table_insert(const Ctx &c, uint32_t lo, uint32_t hi, const RowInfo &ra, const RowInfo &rb, CntFn cnt_of) {
     int lane = lane_id();
     unsigned long long key = pack_pair(lo, hi);
-    int slot = table_claim(ch, key, hash_pair(lo, hi));
+    int slot = table_claim(c, key, hash_pair(lo, hi));
     if (slot < 0) {
-        if (lane == 0) ch.error = E_TABLE_CAPACITY;
+        if (lane == 0) c.g->error = E_TABLE_CAPACITY;
         return false;
     }
-    RowInfo ra = ch.rows[lo], rb = ch.rows[hi];
     int ov = n_overlap(ra, rb);
     float dl = fabsf(ra.lat - rb.lat);
     unsigned long long best = 0;
-    for (int k = lane; k < ch.Kpad; k += WAVE) {
-        uint32_t c = k < ch.K ? cnt_of(k) : 0u;
-        if (c > 65535u) ch.error = E_COUNT_OVERFLOW;
-        ch.hcnt[(size_t)slot * ch.Kpad + k] = (uint16_t)c;
-        uint32_t r = entry_rank(c, ov, dl, ch.method);
+    for (int k = lane; k < c.Kpad; k += WAVE) {
+        uint32_t n = k < c.K ? cnt_of(k) : 0u;
+        if (n > 65535u) c.g->error = E_COUNT_OVERFLOW;
+        c.hcnt[(size_t)slot * c.Kpad + k] = (uint16_t)n;
+        uint32_t r = entry_rank(n, ov, dl, c.method);
         unsigned long long cand = r ? (((unsigned long long)r << 8) | (unsigned)k) : 0ull;
         best = cand > best ? cand : best;
     }
     best = wave_max_u64(best);
     if (lane == 0) {
         uint32_t rank = (uint32_t)(best >> 8);
-        ch.hstat[slot] = HStat{ov, dl};
-        ch.hrank[slot] = rank;
-        ch.hidx[slot] = (uint8_t)(best & 0xFF);
-        if (rank) atomicMax(&ch.ub[slot >> ch.gs_log2], bound_word(rank, tie_word(lo, hi, (int)(best & 0xFF))));
-        unsigned int live = atomicAdd(&ch.n_live, 1u) + 1;
-        atomicMax(&ch.live_peak, live);
+        c.hstat[slot] = HStat{ov, dl};
+        c.hrank[slot] = rank;
+        c.hidx[slot] = (uint8_t)(best & 0xFF);
+        if (rank) atomicMax(&c.ub[slot >> c.gs_log2], bound_word(rank, tie_word(lo, hi, (int)(best & 0xFF))));
+        unsigned int live = atomicAdd(&c.g->n_live, 1u) + 1;
+        atomicMax(&c.g->live_peak, live);
     }
     return true;
 }
 
 // Re-evaluate a block after its counts changed (new_cnt(k, old) -> new count); deletes it when no count >= 2.
 template <class CntFn>
-__device__ void table_update(ChainDev &ch, int slot, CntFn new_cnt) {
+__device__ void table_update(const Ctx &c, int slot, unsigned long long key, CntFn new_cnt) {
     int lane = lane_id();
-    HStat st = ch.hstat[slot];
+    HStat st = c.hstat[slot];
+    uint32_t prev = c.hrank[slot];
     unsigned long long best = 0;
     int alive = 0;
-    for (int k = lane; k < ch.K; k += WAVE) {
-        uint32_t old = ch.hcnt[(size_t)slot * ch.Kpad + k];
-        uint32_t c = new_cnt(k, old);
-        if (c != old) ch.hcnt[(size_t)slot * ch.Kpad + k] = (uint16_t)c;
-        alive |= c >= 2;
-        uint32_t r = entry_rank(c, st.ov, st.dl, ch.method);
+    for (int k = lane; k < c.K; k += WAVE) {
+        uint32_t old = c.hcnt[(size_t)slot * c.Kpad + k];
+        uint32_t n = new_cnt(k, old);
+        if (n != old) c.hcnt[(size_t)slot * c.Kpad + k] = (uint16_t)n;
+        alive |= n >= 2;
+        uint32_t r = entry_rank(n, st.ov, st.dl, c.method);
         unsigned long long cand = r ? (((unsigned long long)r << 8) | (unsigned)k) : 0ull;
         best = cand > best ? cand : best;
     }
@@ -260,18 +313,15 @@ __device__ void table_update(ChainDev &ch, int slot, CntFn new_cnt) {
     alive = __any(alive);
     if (lane == 0) {
         if (!alive) {
-            ch.hrank[slot] = 0;
-            ch.hkey[slot] = KEY_TOMB;
-            atomicSub(&ch.n_live, 1u);
+            c.hrank[slot] = 0;
+            c.hkey[slot] = KEY_TOMB;
+            atomicSub(&c.g->n_live, 1u);
         } else {
             uint32_t rank = (uint32_t)(best >> 8);
-            uint32_t prev = ch.hrank[slot];
-            ch.hrank[slot] = rank;
-            ch.hidx[slot] = (uint8_t)(best & 0xFF);
-            if (rank > prev) {
-                unsigned long long kk = ch.hkey[slot];
-                atomicMax(&ch.ub[slot >> ch.gs_log2], bound_word(rank, tie_word((uint32_t)kk, (uint32_t)(kk >> 32), (int)(best & 0xFF))));
-            }
+            if (rank != prev) c.hrank[slot] = rank;
+            c.hidx[slot] = (uint8_t)(best & 0xFF);
+            if (rank > prev)
+                atomicMax(&c.ub[slot >> c.gs_log2], bound_word(rank, tie_word((uint32_t)key, (uint32_t)(key >> 32), (int)(best & 0xFF))));
         }
     }
 }
@@ -370,19 +420,19 @@ template <class Cell> __global__ void __launch_bounds__(256) k_init_cells(ChainD
 
 // exact pair counts of one row pair over all columns into LDS counters (one wave)
 template <class Cell>
-__device__ __forceinline__ void count_row_pair(const ChainDev &ch, const Cell *cells, uint32_t lo, uint32_t hi, uint32_t *cnt) {
+__device__ __forceinline__ void count_row_pair(const Ctx &c, const Cell *cells, uint32_t lo, uint32_t hi, uint32_t *cnt) {
     int lane = lane_id();
-    for (int k = lane; k < ch.Kpad; k += WAVE) cnt[k] = 0;
+    for (int k = lane; k < c.Kpad; k += WAVE) cnt[k] = 0;
     lds_fence();
-    const Cell *rl = cells + (size_t)lo * ch.n_out, *rh = cells + (size_t)hi * ch.n_out;
-    for (int j = lane; j < ch.n_out; j += WAVE) {
+    const Cell *rl = cells + (size_t)lo * c.n_out, *rh = cells + (size_t)hi * c.n_out;
+    for (int j = lane; j < c.n_out; j += WAVE) {
         Cell a = rl[j];
         if (!a) continue;
         if (lo == hi)
-            for_pairs_self<Cell>(a, ch.n_bits, [&](int k) { atomicAdd(&cnt[k], 1u); });
+            for_pairs_self<Cell>(a, c.n_bits, [&](int k) { atomicAdd(&cnt[k], 1u); });
         else {
             Cell b = rh[j];
-            if (b) for_pairs_cross<Cell>(a, b, ch.n_bits, [&](int k) { atomicAdd(&cnt[k], 1u); });
+            if (b) for_pairs_cross<Cell>(a, b, c.n_bits, [&](int k) { atomicAdd(&cnt[k], 1u); });
         }
     }
     lds_fence();
@@ -396,11 +446,13 @@ __device__ __forceinline__ bool wave_any_ge2(const uint32_t *cnt, int K) {
 // ------------------------------------------------------------------------------------------------ k_init_pairs
 // grid (ceil(n_pairs / 4), n_chains): one wave per initial row pair (i0 <= i1).
 template <class Cell> __global__ void __launch_bounds__(256) k_init_pairs(ChainDev *chains) {
-    ChainDev &ch = chains[blockIdx.y];
-    if (ch.method == M_DUMMY) return;
+    ChainDev *g = &chains[blockIdx.y];
+    if (g->method == M_DUMMY) return;
+    const Ctx c = make_ctx(g);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint32_t *cnt = reinterpret_cast<uint32_t *>(smem) + (size_t)wave_id() * ch.Kpad;
-    long long n_pairs = (long long)ch.n_in * (ch.n_in + 1) / 2;
+    uint32_t *cnt = reinterpret_cast<uint32_t *>(smem) + (size_t)wave_id() * c.Kpad;
+    long long n_in = g->n_in;
+    long long n_pairs = n_in * (n_in + 1) / 2;
     long long p = (long long)blockIdx.x * (blockDim.x / WAVE) + wave_id();
     if (p >= n_pairs) return;
     // p = i1 (i1 + 1) / 2 + i0
@@ -408,47 +460,49 @@ template <class Cell> __global__ void __launch_bounds__(256) k_init_pairs(ChainD
     while (i1 * (i1 + 1) / 2 > p) --i1;
     while ((i1 + 1) * (i1 + 2) / 2 <= p) ++i1;
     uint32_t hi = (uint32_t)i1, lo = (uint32_t)(p - i1 * (i1 + 1) / 2);
-    const auto *cells = reinterpret_cast<const Cell *>(ch.cells);
-    count_row_pair<Cell>(ch, cells, lo, hi, cnt);
-    if (!wave_any_ge2(cnt, ch.K)) return;
-    if (ch.method < 0) {  // unknown method string with a non-empty table: the reference throws here
-        if (lane_id() == 0) ch.unknown_hit = 1;
+    const auto *cells = reinterpret_cast<const Cell *>(g->cells);
+    count_row_pair<Cell>(c, cells, lo, hi, cnt);
+    if (!wave_any_ge2(cnt, c.K)) return;
+    if (c.method < 0) {  // unknown method string with a non-empty table: the reference throws here
+        if (lane_id() == 0) g->unknown_hit = 1;
         return;
     }
-    table_insert(ch, lo, hi, [&](int k) { return cnt[k]; });
+    table_insert(c, lo, hi, c.rows[lo], c.rows[hi], [&](int k) { return cnt[k]; });
 }
 
 // ------------------------------------------------------------------------------------------------ k_iter_select
 // One block per chain: (1) arg-max of the pair table via lazily tightened group upper bounds, (2) substitution
 // of the chosen pair in every column, (3) exact recount of the pairs among the modified rows {A, B, new},
-// (4) publication of the matched-column list for k_iter_update.
+// (4) the de-duplicated list of partner rows (rows sharing a substituted column) for k_iter_update.
 template <class Cell> __global__ void __launch_bounds__(SEL_THREADS) k_iter_select(ChainDev *chains, unsigned int *n_done) {
     using O = CellOps<Cell>;
-    ChainDev &ch = chains[blockIdx.x];
-    if (ch.done) return;
+    ChainDev *g = &chains[blockIdx.x];
+    if (g->done) return;
+    const Ctx c = make_ctx(g);
+    const int n_groups = g->n_groups, n_out = c.n_out, Kpad = c.Kpad, nb = c.n_bits, lcap = g->lcap;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // dynamic LDS carve: bound copy | verified flags | special-pair counters | unit scratch
-    unsigned long long *s_ub = reinterpret_cast<unsigned long long *>(smem);   // [n_groups]
-    uint8_t *s_seen = reinterpret_cast<uint8_t *>(s_ub + ch.n_groups);         // [n_groups] (padded to 8)
-    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_seen + ((ch.n_groups + 7) & ~7));  // [6][Kpad]
-    int *s_scan = reinterpret_cast<int *>(s_cnt + 6 * ch.Kpad);                // [n_out + 1]
+    // dynamic LDS carve: bound copy | verified flags | special-pair counters | per-matched-column scratch
+    unsigned long long *s_ub = reinterpret_cast<unsigned long long *>(smem);          // [n_groups]
+    uint8_t *s_seen = reinterpret_cast<uint8_t *>(s_ub + n_groups);                   // [n_groups] (padded to 8)
+    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_seen + ((n_groups + 7) & ~7));   // [6][Kpad]
+    int *s_len = reinterpret_cast<int *>(s_cnt + 6 * Kpad);                           // [n_out + 1] list lengths -> offsets
+    int *s_col = s_len + n_out + 1;                                                   // [n_out] matched columns
     constexpr int NW = SEL_THREADS / WAVE;
     __shared__ uint32_t s_red_rank[NW];
     __shared__ unsigned long long s_red_tie[NW];
     __shared__ unsigned long long s_floor;  // lower bound (bound-word form) of the best verified entry
     __shared__ uint32_t s_best_rank;
     __shared__ unsigned long long s_best_tie;
-    __shared__ int s_m;
+    __shared__ int s_m, s_np, s_part[NW];
     __shared__ RowInfo s_new;
 
     const int tid = threadIdx.x, lane = lane_id(), wid = wave_id();
-    const int n_groups = ch.n_groups, gs = 1 << ch.gs_log2;
+    const int gs = 1 << c.gs_log2;
 
-    if (ch.error != E_OK) {  // a capacity error poisons the chain: stop it (the host retries with a larger arena)
+    if (g->error != E_OK) {  // a capacity error poisons the chain: stop it (the host retries with a larger arena)
         if (tid == 0) {
-            ch.done = 1;
-            ch.m = 0;
-            ch.n_units = 0;
+            g->done = 1;
+            g->n_partners = 0;
             atomicAdd(n_done, 1u);
         }
         return;
@@ -456,9 +510,9 @@ template <class Cell> __global__ void __launch_bounds__(SEL_THREADS) k_iter_sele
 
     // ---------------- (1) selection: every wave owns the groups g == wid (mod NW) and repeatedly verifies its
     // highest unverified bound until that bound falls below the best verified entry of the whole block.
-    for (int g = tid; g < n_groups; g += SEL_THREADS) {
-        s_ub[g] = ch.ub[g];
-        s_seen[g] = 0;
+    for (int q = tid; q < n_groups; q += SEL_THREADS) {
+        s_ub[q] = c.ub[q];
+        s_seen[q] = 0;
     }
     if (tid == 0) s_floor = 0;
     __syncthreads();
@@ -469,11 +523,11 @@ template <class Cell> __global__ void __launch_bounds__(SEL_THREADS) k_iter_sele
         while (true) {
             unsigned long long top = 0;
             int top_g = -1;
-            for (int g = wid + lane * NW; g < n_groups; g += NW * WAVE) {
-                unsigned long long v = s_seen[g] ? 0ull : s_ub[g];
+            for (int q = wid + lane * NW; q < n_groups; q += NW * WAVE) {
+                unsigned long long v = s_seen[q] ? 0ull : s_ub[q];
                 if (v > top) {
                     top = v;
-                    top_g = g;
+                    top_g = q;
                 }
             }
             unsigned long long wtop = wave_max_u64(top);
@@ -481,18 +535,18 @@ template <class Cell> __global__ void __launch_bounds__(SEL_THREADS) k_iter_sele
             unsigned long long floor_now = *(volatile unsigned long long *)&s_floor;
             if (wtop < floor_now) break;  // nothing left in this partition can beat or tie the best verified entry
             unsigned long long who = __ballot(top == wtop && top_g >= 0);
-            int g = __shfl(top_g, __ffsll((long long)who) - 1);
-            uint32_t base = (uint32_t)g * gs;
+            int grp = __shfl(top_g, __ffsll((long long)who) - 1);
+            uint32_t base = (uint32_t)grp * gs;
             uint32_t grank = 0;
-            for (int o = lane; o < gs; o += WAVE) grank = max(grank, ch.hrank[base + o]);
+            for (int o = lane; o < gs; o += WAVE) grank = max(grank, c.hrank[base + o]);
             grank = wave_max_u32(grank);
             unsigned long long gtie = 0;
             if (grank) {
                 for (int o = lane; o < gs; o += WAVE) {
                     uint32_t sl = base + o;
-                    if (ch.hrank[sl] == grank) {
-                        unsigned long long kk = ch.hkey[sl];
-                        unsigned long long tw = tie_word((uint32_t)kk, (uint32_t)(kk >> 32), ch.hidx[sl]);
+                    if (c.hrank[sl] == grank) {
+                        unsigned long long kk = c.hkey[sl];
+                        unsigned long long tw = tie_word((uint32_t)kk, (uint32_t)(kk >> 32), c.hidx[sl]);
                         gtie = tw > gtie ? tw : gtie;
                     }
                 }
@@ -500,9 +554,9 @@ template <class Cell> __global__ void __launch_bounds__(SEL_THREADS) k_iter_sele
             }
             unsigned long long exact = grank ? bound_word(grank, gtie) : 0ull;
             if (lane == 0) {
-                s_ub[g] = exact;
-                s_seen[g] = 1;
-                ch.ub[g] = exact;  // no writer races with this kernel: the bound is now tight
+                s_ub[grp] = exact;
+                s_seen[grp] = 1;
+                c.ub[grp] = exact;  // no writer races with this kernel: the bound is now tight
                 if (exact) atomicMax(&s_floor, exact);
             }
             lds_fence();
@@ -515,7 +569,7 @@ template <class Cell> __global__ void __launch_bounds__(SEL_THREADS) k_iter_sele
         if (lane == 0) {
             s_red_rank[wid] = wrank;
             s_red_tie[wid] = wtie;
-            if (rescans) atomicAdd(&ch.st_rescans, (unsigned long long)rescans);
+            if (rescans) atomicAdd(&g->st_rescans, (unsigned long long)rescans);
         }
     }
     __syncthreads();
@@ -529,16 +583,18 @@ template <class Cell> __global__ void __launch_bounds__(SEL_THREADS) k_iter_sele
             }
         s_best_rank = br;
         s_best_tie = bt;
+        s_m = 0;
+        s_np = 0;
     }
     __syncthreads();
     const uint32_t best_rank = s_best_rank;
     const unsigned long long best_tie = s_best_tie;
-    if (best_rank == 0 || ch.n_rows >= ch.rcap) {
+    const uint32_t Nw = (uint32_t)g->n_rows;
+    if (best_rank == 0 || (int)Nw >= g->rcap) {
         if (tid == 0) {
-            if (best_rank != 0) ch.error = E_ROW_CAPACITY;
-            ch.done = 1;
-            ch.m = 0;
-            ch.n_units = 0;
+            if (best_rank != 0) g->error = E_ROW_CAPACITY;
+            g->done = 1;
+            g->n_partners = 0;
             atomicAdd(n_done, 1u);
         }
         return;
@@ -546,51 +602,51 @@ template <class Cell> __global__ void __launch_bounds__(SEL_THREADS) k_iter_sele
     const uint32_t A = (uint32_t)((best_tie >> 7) & 0xFFFFFFu), B = (uint32_t)(best_tie >> 31);
     const int idx = (int)(best_tie & 0x7F);
     int shift, sub;
-    key_decode(idx, ch.n_bits, shift, sub);
-    const uint32_t Nw = (uint32_t)ch.n_rows;
+    key_decode(idx, nb, shift, sub);
     const bool same = A == B;
+    const int iter = g->iter;
 
     // ---------------- (2) new row record + substitution
     if (tid == 0) {
-        RowInfo ra = ch.rows[A], rb = ch.rows[B], rn;
+        RowInfo ra = c.rows[A], rb = c.rows[B], rn;
         int derr = 0;
         qint_add_pair(ra, rb, shift, sub, rn.lo, rn.hi, rn.step);
-        float dlat = adder_dlat(ra, rb, shift, sub, ch.adder_size, ch.carry_size, c_log2, derr);
+        float dlat = adder_dlat(ra, rb, shift, sub, g->adder_size, g->carry_size, c_log2, derr);
         rn.lat = (ra.lat < rb.lat ? rb.lat : ra.lat) + dlat;
-        if (derr) ch.error = E_FLOAT_DOMAIN;
-        ch.rows[Nw] = rn;
+        if (derr) g->error = E_FLOAT_DOMAIN;
+        g->rows[Nw] = rn;
         s_new = rn;
-        ch.picks[ch.iter] = make_int4((int)A, (int)B, sub, shift);
-        s_m = 0;
+        g->picks[iter] = make_int4((int)A, (int)B, sub, shift);
     }
-    for (int k = tid; k < 6 * ch.Kpad; k += SEL_THREADS) s_cnt[k] = 0;
+    for (int k = tid; k < 6 * Kpad; k += SEL_THREADS) s_cnt[k] = 0;
     __syncthreads();
-    Cell *cells = reinterpret_cast<Cell *>(ch.cells);
-    Cell *rowA = cells + (size_t)A * ch.n_out, *rowB = cells + (size_t)B * ch.n_out, *rowN = cells + (size_t)Nw * ch.n_out;
-    Cell *mA = reinterpret_cast<Cell *>(ch.mA), *mB = reinterpret_cast<Cell *>(ch.mB);
-    uint32_t *cAA = s_cnt, *cAB = s_cnt + ch.Kpad, *cBB = s_cnt + 2 * ch.Kpad, *cAN = s_cnt + 3 * ch.Kpad,
-             *cBN = s_cnt + 4 * ch.Kpad, *cNN = s_cnt + 5 * ch.Kpad;
-    const int nb = ch.n_bits;
+    Cell *cells = reinterpret_cast<Cell *>(g->cells);
+    Cell *rowA = cells + (size_t)A * n_out, *rowB = cells + (size_t)B * n_out, *rowN = cells + (size_t)Nw * n_out;
+    Cell *mA = reinterpret_cast<Cell *>(g->mA), *mB = reinterpret_cast<Cell *>(g->mB);
+    int *mcol = g->mcol, *collen = g->collen;
+    uint32_t *collist = g->collist;
+    uint32_t *cAA = s_cnt, *cAB = s_cnt + Kpad, *cBB = s_cnt + 2 * Kpad, *cAN = s_cnt + 3 * Kpad, *cBN = s_cnt + 4 * Kpad,
+             *cNN = s_cnt + 5 * Kpad;
     unsigned int my_matches = 0;
-    for (int j = tid; j < ch.n_out; j += SEL_THREADS) {
+    for (int j = tid; j < n_out; j += SEL_THREADS) {
         Cell a = rowA[j], b = same ? a : rowB[j], ma = 0, mb = 0;
         if (a && b) substitute_column<Cell>(a, b, same, shift, sub, ma, mb);
-        Cell na = a & ~ma, nbv = b & ~mb;
-        if (same) na = a & ~ma & ~mb;
+        Cell na = same ? (Cell)(a & ~ma & ~mb) : (Cell)(a & ~ma), nbv = b & ~mb;
         if (ma) {
             rowA[j] = na;
             if (!same) rowB[j] = nbv;
             int at = atomicAdd(&s_m, 1);
-            ch.mcol[at] = j;
+            mcol[at] = j;
             mA[at] = ma;
             mB[at] = mb;
-            int len = ch.collen[j];
-            s_scan[at] = (len + UNIT - 1) / UNIT;  // update work units of this column (the new row is not a partner)
-            if (len < ch.lcap) {
-                ch.collist[(size_t)j * ch.lcap + len] = Nw;
-                ch.collen[j] = len + 1;
+            int len = collen[j];
+            s_len[at] = len;  // the pre-append length: the new row itself is not a partner
+            s_col[at] = j;
+            if (len < lcap) {
+                collist[(size_t)j * lcap + len] = Nw;
+                collen[j] = len + 1;
             } else
-                ch.error = E_LIST_CAPACITY;
+                g->error = E_LIST_CAPACITY;
             my_matches += popc32(O::plus(ma) | O::minus(ma));
         }
         rowN[j] = ma;
@@ -604,31 +660,55 @@ template <class Cell> __global__ void __launch_bounds__(SEL_THREADS) k_iter_sele
         if (na && ma) for_pairs_cross<Cell>(na, ma, nb, [&](int k) { atomicAdd(&cAN[k], 1u); });
         if (ma) for_pairs_self<Cell>(ma, nb, [&](int k) { atomicAdd(&cNN[k], 1u); });
     }
-    if (my_matches) atomicAdd(&ch.st_matches, (unsigned long long)my_matches);
+    if (my_matches) atomicAdd(&g->st_matches, (unsigned long long)my_matches);
     __syncthreads();
     const int m = s_m;
-    // prefix sum of the per-column unit counts (m <= n_out; serial for short lists, they are short)
-    if (tid == 0) {
-        int acc = 0;
-        for (int q = 0; q < m; ++q) {
-            ch.unit_off[q] = acc;
-            acc += s_scan[q];
+    // exclusive prefix sum of the list lengths of the matched columns (m <= n_out): chunked block scan
+    {
+        int per = (m + SEL_THREADS - 1) / SEL_THREADS;
+        int lo = min(tid * per, m), hi = min(lo + per, m), sum = 0;
+        for (int q = lo; q < hi; ++q) sum += s_len[q];
+        int inc = sum;
+        for (int o = 1; o < WAVE; o <<= 1) {
+            int t = __shfl_up(inc, o);
+            if (lane >= o) inc += t;
         }
-        ch.unit_off[m] = acc;
-        ch.m = m;
-        ch.n_units = acc;
-        ch.work_ctr = 0;
-        ch.A = A;
-        ch.B = B;
-        ch.Nw = Nw;
-        ch.n_rows = (int)Nw + 1;
-        ch.iter = ch.iter + 1;
-        ch.stamp[A] = ch.stamp[B] = ch.stamp[Nw] = 0;
+        if (lane == WAVE - 1) s_part[wid] = inc;
+        __syncthreads();
+        int wbase = 0;
+        for (int w = 0; w < wid; ++w) wbase += s_part[w];
+        int run = wbase + inc - sum;
+        __syncthreads();
+        for (int q = lo; q < hi; ++q) {
+            int l = s_len[q];
+            s_len[q] = run;
+            run += l;
+        }
+        if (tid == SEL_THREADS - 1) s_len[m] = wbase + inc;
+        __syncthreads();
     }
-    // six special pairs, one wave each
+    const int total = s_len[m];
+    // ---------------- (4) partner rows: every row listed in a matched column, claimed once (stamp) and appended
+    {
+        uint32_t *stamp = g->stamp, *plist = g->plist;
+        const uint32_t tag = (uint32_t)iter + 1u;
+        for (int f = tid; f < total; f += SEL_THREADS) {
+            int lo = 0, hi = m;
+            while (hi - lo > 1) {
+                int mid = (lo + hi) >> 1;
+                if (s_len[mid] <= f)
+                    lo = mid;
+                else
+                    hi = mid;
+            }
+            uint32_t r = collist[(size_t)s_col[lo] * lcap + (f - s_len[lo])];
+            if (r != A && r != B && atomicExch(&stamp[r], tag) != tag) plist[atomicAdd(&s_np, 1)] = r;
+        }
+    }
+    // six special pairs, one wave each (runs concurrently with the claims above on the other waves)
     if (wid < 6) {
-        uint32_t lo, hi;
-        const uint32_t *cnt = s_cnt + wid * ch.Kpad;
+        uint32_t lo = A, hi = A;
+        const uint32_t *cnt = s_cnt + wid * Kpad;
         bool active = true, existed = false;
         switch (wid) {
         case 0: lo = A, hi = A, existed = true; break;
@@ -639,104 +719,98 @@ template <class Cell> __global__ void __launch_bounds__(SEL_THREADS) k_iter_sele
         default: lo = Nw, hi = Nw; break;
         }
         if (active) {
-            // rows[Nw] was written by thread 0 before the barrier above; make it visible to this wave's loads
-            __threadfence_block();
-            int slot = existed ? table_find(ch, pack_pair(lo, hi), hash_pair(lo, hi)) : -1;
+            unsigned long long key = pack_pair(lo, hi);
+            int slot = existed ? table_find(c, key, hash_pair(lo, hi)) : -1;
             if (slot >= 0)
-                table_update(ch, slot, [&](int k, uint32_t) { return cnt[k]; });
-            else if (wave_any_ge2(cnt, ch.K))
-                table_insert(ch, lo, hi, [&](int k) { return cnt[k]; });
+                table_update(c, slot, key, [&](int k, uint32_t) { return cnt[k]; });
+            else if (wave_any_ge2(cnt, c.K)) {
+                RowInfo ra = c.rows[lo], rb = hi == Nw ? s_new : c.rows[hi];
+                if (lo == Nw) ra = s_new;
+                table_insert(c, lo, hi, ra, rb, [&](int k) { return cnt[k]; });
+            }
         }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        g->m = m;
+        g->n_partners = s_np;
+        g->work_ctr = 0;
+        g->A = A;
+        g->B = B;
+        g->Nw = Nw;
+        g->n_rows = (int)Nw + 1;
+        g->iter = iter + 1;
     }
 }
 
 // ------------------------------------------------------------------------------------------------ k_iter_update
-// grid (U, n_chains).  Work unit = UNIT consecutive entries of the row list of one matched column.  Every row
-// found there (other than A, B, new) is claimed once per iteration and handled by ONE wavefront: it subtracts the
-// occurrences lost with A's / B's consumed digits from the blocks (A,r), (B,r) and creates the block (r,new).
+// grid (U, n_chains).  Every partner row (a row other than A, B, new that shares a substituted column) is handled
+// by ONE wavefront, fetched from the chain's work list with an atomic counter: it subtracts the pair occurrences
+// lost with A's / B's consumed digits from the blocks (A,r), (B,r) and creates the block (r,new).
 template <class Cell> __global__ void __launch_bounds__(UPD_THREADS) k_iter_update(ChainDev *chains) {
-    ChainDev &ch = chains[blockIdx.y];
-    if (ch.done || ch.n_units == 0) return;
+    ChainDev *g = &chains[blockIdx.y];
+    if (g->done) return;
+    const int n_partners = g->n_partners;
+    if (n_partners == 0) return;
+    const Ctx c = make_ctx(g);
+    const int m = g->m, nb = c.n_bits, Kpad = c.Kpad, K = c.K, n_out = c.n_out;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(smem);  // [UPD_WAVES][3][Kpad]
-    __shared__ uint32_t s_rows[UNIT];
-    __shared__ uint32_t s_n;
-    __shared__ int s_unit;
+    // LDS: per-wave counters [UPD_WAVES][3][Kpad] | matched columns [m] | consumed digits of A [m] and B [m]
+    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(smem);
+    int *s_col = reinterpret_cast<int *>(s_cnt + UPD_WAVES * 3 * Kpad);
+    Cell *s_mA = reinterpret_cast<Cell *>(s_col + ((n_out + 1) & ~1));
+    Cell *s_mB = s_mA + n_out;
     const int tid = threadIdx.x, lane = lane_id(), wid = wave_id();
-    const uint32_t A = ch.A, B = ch.B, Nw = ch.Nw;
+    {
+        const int *mcol = g->mcol;
+        const Cell *mA = reinterpret_cast<const Cell *>(g->mA), *mB = reinterpret_cast<const Cell *>(g->mB);
+        for (int j = tid; j < m; j += UPD_THREADS) {
+            s_col[j] = mcol[j];
+            s_mA[j] = mA[j];
+            s_mB[j] = mB[j];
+        }
+    }
+    __syncthreads();
+    const uint32_t A = g->A, B = g->B, Nw = g->Nw;
     const bool same = A == B;
-    const int m = ch.m, nb = ch.n_bits, Kpad = ch.Kpad, K = ch.K;
-    const uint32_t tag = (uint32_t)ch.iter;  // >= 1, unique per iteration
-    const Cell *cells = reinterpret_cast<const Cell *>(ch.cells);
-    const Cell *mA = reinterpret_cast<const Cell *>(ch.mA), *mB = reinterpret_cast<const Cell *>(ch.mB);
+    const Cell *cells = reinterpret_cast<const Cell *>(g->cells);
+    const uint32_t *plist = g->plist;
+    const RowInfo rnew = c.rows[Nw];
     uint32_t *dA = s_cnt + (size_t)wid * 3 * Kpad, *dB = dA + Kpad, *cN = dB + Kpad;
     unsigned int partners = 0;
-
     while (true) {
-        if (tid == 0) {
-            s_unit = (int)atomicAdd(&ch.work_ctr, 1u);
-            s_n = 0;
-        }
-        __syncthreads();
-        const int unit = s_unit;
-        if (unit >= ch.n_units) break;
-        // locate the matched column of this unit (unit_off is ascending, m is small)
-        int lo = 0, hi = m;
-        while (hi - lo > 1) {
-            int mid = (lo + hi) >> 1;
-            if (ch.unit_off[mid] <= unit)
-                lo = mid;
-            else
-                hi = mid;
-        }
-        const int col = ch.mcol[lo];
-        const int e = (unit - ch.unit_off[lo]) * UNIT + tid;
-        // entries beyond the pre-append length are the new row itself
-        bool mine = false;
-        uint32_t r = 0;
-        if (e < ch.collen[col]) {
-            r = ch.collist[(size_t)col * ch.lcap + e];
-            if (r != A && r != B && r != Nw) mine = atomicExch(&ch.stamp[r], tag) != tag;
-        }
-        if (mine) s_rows[atomicAdd(&s_n, 1u)] = r;
-        __syncthreads();
-        const uint32_t n = s_n;
-        for (uint32_t q = wid; q < n; q += UPD_WAVES) {
-            const uint32_t pr = s_rows[q];
-            ++partners;
-            for (int k = lane; k < 3 * Kpad; k += WAVE) dA[k] = 0;
-            lds_fence();
-            const Cell *rowR = cells + (size_t)pr * ch.n_out;
-            int touched = 0;
-            for (int j = lane; j < m; j += WAVE) {
-                Cell x = rowR[ch.mcol[j]];
-                if (!x) continue;
-                touched = 1;
-                Cell ma = mA[j], mb = mB[j];
+        int q = 0;
+        if (lane == 0) q = (int)atomicAdd(&g->work_ctr, 1u);
+        q = __shfl(q, 0);
+        if (q >= n_partners) break;
+        const uint32_t pr = plist[q];
+        ++partners;
+        // both table probes and the partner's interval are independent of the digit loop: issue them first
+        const uint32_t lA = min(A, pr), hA = max(A, pr), lB = min(B, pr), hB = max(B, pr);
+        const unsigned long long keyA = pack_pair(lA, hA), keyB = pack_pair(lB, hB);
+        int slotA, slotB;
+        table_find2(c, keyA, hash_pair(lA, hA), keyB, hash_pair(lB, hB), !same, slotA, slotB);
+        for (int k = lane; k < 3 * Kpad; k += WAVE) dA[k] = 0;
+        lds_fence();
+        const Cell *rowR = cells + (size_t)pr * n_out;
+        int got_new = 0;
+        for (int j = lane; j < m; j += WAVE) {
+            Cell x = rowR[s_col[j]];
+            if (!x) continue;
+            Cell ma = s_mA[j], mb = s_mB[j];
+            if (slotA >= 0) {
                 for_pairs_part<Cell>(ma, x, A < pr, nb, [&](int k) { atomicAdd(&dA[k], 1u); });
-                if (same)
-                    for_pairs_part<Cell>(mb, x, A < pr, nb, [&](int k) { atomicAdd(&dA[k], 1u); });
-                else
-                    for_pairs_part<Cell>(mb, x, B < pr, nb, [&](int k) { atomicAdd(&dB[k], 1u); });
-                for_pairs_cross<Cell>(x, ma, nb, [&](int k) { atomicAdd(&cN[k], 1u); });
+                if (same) for_pairs_part<Cell>(mb, x, A < pr, nb, [&](int k) { atomicAdd(&dA[k], 1u); });
             }
-            lds_fence();
-            if (!__any(touched)) continue;  // stale list entry: the row lost its digits in every matched column
-            {
-                uint32_t l = min(A, pr), h = max(A, pr);
-                int slot = table_find(ch, pack_pair(l, h), hash_pair(l, h));
-                if (slot >= 0) table_update(ch, slot, [&](int k, uint32_t old) { return old - dA[k]; });
-            }
-            if (!same) {
-                uint32_t l = min(B, pr), h = max(B, pr);
-                int slot = table_find(ch, pack_pair(l, h), hash_pair(l, h));
-                if (slot >= 0) table_update(ch, slot, [&](int k, uint32_t old) { return old - dB[k]; });
-            }
-            if (wave_any_ge2(cN, K)) table_insert(ch, pr, Nw, [&](int k) { return cN[k]; });
+            if (!same && slotB >= 0) for_pairs_part<Cell>(mb, x, B < pr, nb, [&](int k) { atomicAdd(&dB[k], 1u); });
+            for_pairs_cross<Cell>(x, ma, nb, [&](int k) { got_new |= atomicAdd(&cN[k], 1u) >= 1u; });
         }
-        __syncthreads();
+        lds_fence();
+        if (slotA >= 0) table_update(c, slotA, keyA, [&](int k, uint32_t old) { return old - dA[k]; });
+        if (slotB >= 0) table_update(c, slotB, keyB, [&](int k, uint32_t old) { return old - dB[k]; });
+        if (__any(got_new)) table_insert(c, pr, Nw, c.rows[pr], rnew, [&](int k) { return cN[k]; });
     }
-    if (lane == 0 && partners) atomicAdd(&ch.st_partners, (unsigned long long)partners);
+    if (lane == 0 && partners) atomicAdd(&g->st_partners, (unsigned long long)partners);
 }
 
 // ------------------------------------------------------------------------------------------------ k_extract
@@ -917,7 +991,7 @@ size_t carve_chain(unsigned char *base, const ChainJob &job, const Geometry &g, 
     d.mcol = c.take<int>(n_out);
     d.mA = c.take<unsigned char>(n_out * cell);
     d.mB = c.take<unsigned char>(n_out * cell);
-    d.unit_off = c.take<int>(n_out + 1);
+    d.plist = c.take<uint32_t>(g.rcap);
     d.picks = c.take<int4>(g.rcap);
     d.fin_row = c.take<uint32_t>(n_out * (size_t)g.lcap);
     d.fin_cell = c.take<unsigned long long>(n_out * (size_t)g.lcap);
@@ -1072,10 +1146,10 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
     for (int i = 0; i < n; ++i) {
         int w = geo[i].wide;
         size_t s = (size_t)geo[i].n_groups * 8 + (((size_t)geo[i].n_groups + 7) & ~(size_t)7) + 6 * (size_t)geo[i].Kpad * 4 +
-                   ((size_t)jobs[i].n_out + 1) * 4;
+                   (2 * (size_t)jobs[i].n_out + 1) * 4;
         s = align_up(s, 16);
         sel_lds[w] = std::max(sel_lds[w], s);
-        upd_lds[w] = std::max(upd_lds[w], (size_t)UPD_WAVES * 3 * geo[i].Kpad * 4);
+        upd_lds[w] = std::max(upd_lds[w], align_up((size_t)UPD_WAVES * 3 * geo[i].Kpad * 4 + (((size_t)jobs[i].n_out + 1) & ~(size_t)1) * 4 + 2 * (size_t)jobs[i].n_out * (geo[i].wide ? 8 : 4), 16));
         pair_lds[w] = std::max(pair_lds[w], (size_t)4 * geo[i].Kpad * 4);
         max_pairs[w] = std::max(max_pairs[w], (long long)jobs[i].n_in * (jobs[i].n_in + 1) / 2);
     }

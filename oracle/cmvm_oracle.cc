@@ -21,6 +21,7 @@
 // /root/reference/src/da4ml/_binary/cmvm/).
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -442,6 +443,7 @@ static void refresh_table(State &s, const PairKey &p) {
 
 // optional per-iteration trace (instrumentation only; enabled by env ORC_TRACE=<file>)
 static FILE *trace_fp = nullptr;
+static std::chrono::steady_clock::time_point trace_t0;
 static void trace_iteration(const State &s, const PairKey &p, int64_t matches) {
     int64_t it = s.st.iterations;
     int64_t live = -1, digits = -1;
@@ -454,8 +456,9 @@ static void trace_iteration(const State &s, const PairKey &p, int64_t matches) {
             digits += d;
         }
     }
-    std::fprintf(trace_fp, "%lld %zu %lld %lld %lld %lld %lld %d %d\n", (long long)it, s.table.size(), (long long)matches,
-                 (long long)live, (long long)digits, (long long)p.id0, (long long)p.id1, (int)p.shift, (int)p.sub);
+    double now = std::chrono::duration<double>(std::chrono::steady_clock::now() - trace_t0).count();
+    std::fprintf(trace_fp, "%lld %zu %lld %lld %lld %lld %lld %d %d %.3f\n", (long long)it, s.table.size(), (long long)matches,
+                 (long long)live, (long long)digits, (long long)p.id0, (long long)p.id1, (int)p.shift, (int)p.sub, now);
 }
 
 // ---------------------------------------------------------------- cmvm_core.cc:10-72
@@ -466,6 +469,7 @@ static State greedy(const float *kernel, int64_t n_in, int64_t n_out, const std:
     if (qints.empty()) qints.assign(n_in, QInt{-128.0f, 127.0f, 1.0f});
     std::vector<float> lats = lats_in;
     if (lats.empty()) lats.assign(n_in, 0.0f);
+    trace_t0 = std::chrono::steady_clock::now();
     State s = create_state(kernel, n_in, n_out, qints, lats, false);
     if (const char *tp = std::getenv("ORC_TRACE")) {
         if (trace_fp) std::fclose(trace_fp);
