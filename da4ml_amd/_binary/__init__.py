@@ -240,13 +240,72 @@ def solve_many(
     return [_collect(res[i], _stats) for i in range(n)]
 
 
+class RawBatch:
+    """Handles of a solved batch kept on the C side (no Python objects built): the benchmark times the C-ABI call
+    itself and converts / inspects results outside the timed region."""
+
+    def __init__(self, handles):
+        self.handles = list(handles)
+
+    def __len__(self):
+        return len(self.handles)
+
+    def summary(self, i: int) -> dict:
+        """(cost, adders, ops per stage) of result ``i`` straight from the C arrays"""
+        L, h = lib(), self.handles[i]
+        cost, adders, n_ops = 0.0, 0, []
+        for s in range(L.da_n_stages(h)):
+            info = np.zeros(5, np.int64)
+            L.da_stage_info(h, s, info)
+            n_in, n_out, n = int(info[0]), int(info[1]), int(info[2])
+            arr = [np.zeros(k, np.int64) for k in (n_in, n_out, n_out, n_out)]
+            oi, of = np.zeros((n, 4), np.int64), np.zeros((n, 5), np.float32)
+            L.da_stage_copy(h, s, *arr, oi, of)
+            c = np.float32(0)
+            for v in of[:, 4]:  # float32 accumulation in op order, like the reference's candidate cost (api.cc:222-229)
+                c = np.float32(c + v)
+            cost += float(of[:, 4].astype(np.float64).sum())
+            adders += int(np.isin(oi[:, 2], (0, 1)).sum())
+            n_ops.append(n)
+        st = np.zeros(8, np.int64)
+        L.da_result_stats(h, st)
+        return dict(cost=cost, adders=adders, n_ops=n_ops, iterations=int(st[0]))
+
+    def pipeline(self, i: int):
+        h, self.handles[i] = self.handles[i], None
+        return _collect(h)
+
+    def free(self):
+        for h in self.handles:
+            if h:
+                lib().da_free(h)
+        self.handles = []
+
+
+def solve_many_raw(kernels, method0='wmc', method1='auto', hard_dc=-1, decompose_dc=-2, adder_size=-1, carry_size=-1,
+                   search_all_decompose_dc=True) -> RawBatch:  # fmt: skip
+    """``solve_many`` without result marshalling (benchmark use)."""
+    ks = [_kernel(k) for k in kernels]
+    n = len(ks)
+    n_in = np.array([k.shape[0] for k in ks], np.int64)
+    n_out = np.array([k.shape[1] for k in ks], np.int64)
+    kptr = (C.c_void_p * n)(*[k.ctypes.data for k in ks])
+    res = (C.c_void_p * n)()
+    rc = lib().da_solve_batch(n, kptr, n_in, n_out, method0.encode(), method1.encode(), int(hard_dc), int(decompose_dc), None, None,
+                              int(adder_size), int(carry_size), int(bool(search_all_decompose_dc)), res)  # fmt: skip
+    if rc != 0:
+        _raise(rc)
+    return RawBatch([res[i] for i in range(n)])
+
+
 def timings(reset: bool = False) -> dict:
     """Accumulated device-side timings / counters of the greedy loops (benchmark instrumentation)."""
-    t = np.zeros(10, np.float64)
+    t = np.zeros(18, np.float64)
     rc = lib().da_timings(t, int(reset))
     if rc != 0:
         _raise(rc)
-    names = ('loop_ms', 'dist_ms', 'total_ms', 'lockstep_iters', 'iterations', 'rescans', 'partners', 'chains', 'table_bytes', 'arena_bytes')
+    names = ('loop_ms', 'dist_ms', 'total_ms', 'lockstep_iters', 'iterations', 'rescans', 'partners', 'chains', 'table_bytes', 'arena_bytes',
+             'select_ms_sampled', 'update_ms_sampled', 'samples', 'found', 'inserts', 'cell_reads', 'block_bytes', 'cell_bytes')
     return dict(zip(names, t.tolist()))
 
 

@@ -110,7 +110,7 @@ struct ChainDev {
     unsigned long long *fin_cell;
     uint32_t *fin_count;
     // statistics
-    unsigned long long st_rescans, st_partners, st_matches, st_rounds;
+    unsigned long long st_rescans, st_partners, st_matches, st_found, st_inserts, st_cells;
 };
 
 __constant__ Log2Table c_log2;
@@ -753,7 +753,7 @@ template <class Cell> __global__ void __launch_bounds__(UPD_THREADS) k_iter_upda
     const int n_partners = g->n_partners;
     if (n_partners == 0) return;
     const Ctx c = make_ctx(g);
-    const int m = g->m, nb = c.n_bits, Kpad = c.Kpad, K = c.K, n_out = c.n_out;
+    const int m = g->m, nb = c.n_bits, Kpad = c.Kpad, n_out = c.n_out;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // LDS: per-wave counters [UPD_WAVES][3][Kpad] | matched columns [m] | consumed digits of A [m] and B [m]
     uint32_t *s_cnt = reinterpret_cast<uint32_t *>(smem);
@@ -777,7 +777,7 @@ template <class Cell> __global__ void __launch_bounds__(UPD_THREADS) k_iter_upda
     const uint32_t *plist = g->plist;
     const RowInfo rnew = c.rows[Nw];
     uint32_t *dA = s_cnt + (size_t)wid * 3 * Kpad, *dB = dA + Kpad, *cN = dB + Kpad;
-    unsigned int partners = 0;
+    unsigned int partners = 0, found = 0, inserts = 0;
     while (true) {
         int q = 0;
         if (lane == 0) q = (int)atomicAdd(&g->work_ctr, 1u);
@@ -808,9 +808,18 @@ template <class Cell> __global__ void __launch_bounds__(UPD_THREADS) k_iter_upda
         lds_fence();
         if (slotA >= 0) table_update(c, slotA, keyA, [&](int k, uint32_t old) { return old - dA[k]; });
         if (slotB >= 0) table_update(c, slotB, keyB, [&](int k, uint32_t old) { return old - dB[k]; });
-        if (__any(got_new)) table_insert(c, pr, Nw, c.rows[pr], rnew, [&](int k) { return cN[k]; });
+        found += (slotA >= 0) + (slotB >= 0);
+        if (__any(got_new)) {
+            table_insert(c, pr, Nw, c.rows[pr], rnew, [&](int k) { return cN[k]; });
+            ++inserts;
+        }
     }
-    if (lane == 0 && partners) atomicAdd(&g->st_partners, (unsigned long long)partners);
+    if (lane == 0 && partners) {
+        atomicAdd(&g->st_partners, (unsigned long long)partners);
+        atomicAdd(&g->st_cells, (unsigned long long)partners * (unsigned)m);
+        if (found) atomicAdd(&g->st_found, (unsigned long long)found);
+        if (inserts) atomicAdd(&g->st_inserts, (unsigned long long)inserts);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ k_extract
@@ -1068,7 +1077,7 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
         const ChainDev &d = desc[i];
         Geometry &g = geo[i];
         g.n_bits = d.prep_nbits;
-        if (g.n_bits > 32) throw std::runtime_error("kernel needs more than 32 CSD digits per entry; unsupported");
+        if (g.n_bits > 30) throw std::runtime_error("kernel needs more than 30 CSD digits per entry (the reference overflows int32 there); unsupported");
         g.wide = g.n_bits > 16;
         g.K = key_count(g.n_bits);
         g.Kpad = (g.K + 3) & ~3;
@@ -1185,24 +1194,42 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
     HIP_CHECK(hipEventCreate(&ev0));
     HIP_CHECK(hipEventCreate(&ev1));
     HIP_CHECK(hipEventRecord(ev0, st));
+    // per-kernel durations: every SAMPLE_EVERY-th lockstep iteration is bracketed by HIP events on the launch stream
+    constexpr int SAMPLE_EVERY = 16, MAX_SAMPLES = 2048;
+    const bool can_sample = (ranges[0].count == 0) != (ranges[1].count == 0);
+    std::vector<hipEvent_t> sample_ev;
+    int n_samples = 0;
     long long launched_iters = 0, iter_cap = 0;
     for (int i = 0; i < n; ++i) iter_cap = std::max<long long>(iter_cap, geo[i].rcap - jobs[i].n_in + 2);
     const int poll_every = 64;
     while (active > 0) {
         if (launched_iters > iter_cap + poll_every) throw std::runtime_error("greedy loop did not terminate within its row capacity (internal error)");
         for (int it = 0; it < poll_every; ++it) {
+            const bool sample = can_sample && n_samples < MAX_SAMPLES && (launched_iters + it) % SAMPLE_EVERY == 0;
+            hipEvent_t se[3] = {nullptr, nullptr, nullptr};
+            if (sample) {
+                for (auto &e : se) {
+                    HIP_CHECK(hipEventCreate(&e));
+                    sample_ev.push_back(e);
+                }
+                ++n_samples;
+                HIP_CHECK(hipEventRecord(se[0], st));
+            }
             for (int w = 0; w < 2; ++w) {
                 const Range &r = ranges[w];
                 if (r.count == 0) continue;
                 ChainDev *base = d_desc + r.first;
-                if (!r.wide) {
+                if (!r.wide)
                     hipLaunchKernelGGL(k_iter_select<uint32_t>, dim3(r.count), dim3(SEL_THREADS), sel_lds[w], st, base, im.d_done);
-                    hipLaunchKernelGGL(k_iter_update<uint32_t>, dim3(upd_blocks[w], r.count), dim3(UPD_THREADS), upd_lds[w], st, base);
-                } else {
+                else
                     hipLaunchKernelGGL(k_iter_select<uint64_t>, dim3(r.count), dim3(SEL_THREADS), sel_lds[w], st, base, im.d_done);
+                if (sample) HIP_CHECK(hipEventRecord(se[1], st));
+                if (!r.wide)
+                    hipLaunchKernelGGL(k_iter_update<uint32_t>, dim3(upd_blocks[w], r.count), dim3(UPD_THREADS), upd_lds[w], st, base);
+                else
                     hipLaunchKernelGGL(k_iter_update<uint64_t>, dim3(upd_blocks[w], r.count), dim3(UPD_THREADS), upd_lds[w], st, base);
-                }
             }
+            if (sample) HIP_CHECK(hipEventRecord(se[2], st));
         }
         launched_iters += poll_every;
         HIP_CHECK(hipGetLastError());
@@ -1230,6 +1257,15 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
     HIP_CHECK(hipStreamSynchronize(st));
     float loop_ms = 0;
     HIP_CHECK(hipEventElapsedTime(&loop_ms, ev0, ev1));
+    for (int k = 0; k < n_samples; ++k) {
+        float a = 0, b = 0;
+        HIP_CHECK(hipEventElapsedTime(&a, sample_ev[3 * k], sample_ev[3 * k + 1]));
+        HIP_CHECK(hipEventElapsedTime(&b, sample_ev[3 * k + 1], sample_ev[3 * k + 2]));
+        im.timings.select_ms_sampled += a;
+        im.timings.update_ms_sampled += b;
+    }
+    im.timings.samples += n_samples;
+    for (hipEvent_t e : sample_ev) (void)hipEventDestroy(e);
     (void)hipEventDestroy(ev0);
     (void)hipEventDestroy(ev1);
 
@@ -1319,7 +1355,11 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
         o.stats.scan_slots = (long long)d.st_rescans << d.gs_log2;
         o.stats.partners = (long long)d.st_partners;
         o.stats.matches = (long long)d.st_matches;
-        o.stats.rebuilds = (long long)d.st_rounds;  // selection rounds (reported through the spare field)
+        im.timings.found += (long long)d.st_found;
+        im.timings.inserts += (long long)d.st_inserts;
+        im.timings.cell_reads += (long long)d.st_cells;
+        im.timings.key_bytes += 2.0 * d.K * (double)(d.st_found + d.st_inserts);
+        im.timings.cell_bytes += (geo[i].wide ? 8.0 : 4.0) * (double)d.st_cells;
         im.timings.iterations += d.iter;
         im.timings.rescans += (long long)d.st_rescans;
         im.timings.partners += (long long)d.st_partners;

@@ -18,6 +18,13 @@ struct GpuTimings {  // accumulated since the last reset; read by the benchmark 
     long long partners = 0;        // partner rows processed by the update kernel
     long long chains = 0;
     long long dist_calls = 0;
+    // sampled per-kernel durations (HIP events around every 16th lockstep iteration)
+    double select_ms_sampled = 0, update_ms_sampled = 0;
+    long long samples = 0;
+    // algorithmic-traffic counters of k_iter_update, summed over chains
+    long long found = 0, inserts = 0, cell_reads = 0;
+    double key_bytes = 0;     // 2 * K bytes per touched count block (u16 counts)
+    double cell_bytes = 0;    // bytes of partner cells read
     double table_bytes = 0;   // bytes of pair-table storage summed over chains
     double arena_bytes = 0;   // largest device arena used
 };

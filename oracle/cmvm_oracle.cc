@@ -935,6 +935,42 @@ void *orc_solve_single(const float *kernel, int64_t n_in, int64_t n_out, const c
     }
 }
 
+// Bounded CPU timing sample for bench.py: build the state of one greedy chain, then run greedy iterations until
+// `budget_s` seconds are spent.  out[0] = seconds for state + table creation, out[1] = iterations completed,
+// out[2] = seconds spent in those iterations, out[3] = 1 if the chain finished within the budget.
+int orc_sample_chain(const float *kernel, int64_t n_in, int64_t n_out, const char *method, double budget_s, double *out) {
+    try {
+        std::vector<QInt> q(n_in, QInt{-128.0f, 127.0f, 1.0f});
+        std::vector<float> l(n_in, 0.0f);
+        std::string m(method);
+        auto t0 = std::chrono::steady_clock::now();
+        State s = create_state(kernel, n_in, n_out, q, l, false);
+        auto t1 = std::chrono::steady_clock::now();
+        out[0] = std::chrono::duration<double>(t1 - t0).count();
+        out[1] = out[2] = out[3] = 0;
+        while (true) {
+            if (s.table.empty()) {
+                out[3] = 1;
+                break;
+            }
+            PairKey pick = m == "mc" ? pick_mc(s) : m == "wmc" ? pick_wmc(s) : m == "wmc-dc" ? pick_wmc_dc(s, true) : pick_mc_dc(s, true);
+            if (pick.id0 == -1 || pick.id1 == -1) {
+                out[3] = 1;
+                break;
+            }
+            substitute(s, pick, -1, -1);
+            refresh_table(s, pick);
+            out[1] += 1;
+            out[2] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
+            if (out[2] >= budget_s) break;
+        }
+        return 0;
+    } catch (const std::exception &e) {
+        g_err = e.what();
+        return -1;
+    }
+}
+
 int orc_n_stages(void *h) { return (int)((OrcResult *)h)->pipe.stages.size(); }
 int orc_picked(void *h) { return ((OrcResult *)h)->picked; }
 

@@ -66,6 +66,7 @@ class Oracle:
             g('solve_single').restype = C.c_void_p
             g('solve_single').argtypes = [_f32p, C.c_int64, C.c_int64, C.c_char_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
             g('stage_stats').argtypes = [C.c_void_p, C.c_int, _i64p]
+            g('sample_chain').argtypes = [_f32p, C.c_int64, C.c_int64, C.c_char_p, C.c_double, np.ctypeslib.ndpointer(np.float64)]
         self.g = g
 
     # ---- scalar helpers -------------------------------------------------
@@ -153,6 +154,15 @@ class Oracle:
                                    None if l is None else l.ctypes.data, adder_size, carry_size)  # fmt: skip
         r = self._collect(h, stats)
         return (r[0].solutions[0], r[1][0]) if stats else r.solutions[0]
+
+
+def sample_chain(oracle: Oracle, kernel, method: str, budget_s: float) -> dict:
+    """time-bounded CPU sample of one greedy chain (state creation + as many iterations as fit in ``budget_s``)"""
+    k = np.ascontiguousarray(kernel, dtype=np.float32)
+    out = np.zeros(4, np.float64)
+    if oracle.g('sample_chain')(k, k.shape[0], k.shape[1], method.encode(), float(budget_s), out) != 0:
+        raise RuntimeError(oracle.g('last_error')().decode())
+    return dict(create_s=float(out[0]), iterations=int(out[1]), iter_s=float(out[2]), finished=bool(out[3]))
 
 
 def set_threads(n: int):

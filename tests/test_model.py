@@ -1,0 +1,80 @@
+"""CPU proof that (1) the reformulated incremental algorithm of the GPU engine (tests/model/engine_model.cc, built from
+the same cmvm_core.h inline functions as the kernels) picks exactly the reference's pairs and (2) the product's host
+logic (da4ml_amd/csrc/cmvm_host.cc: option resolution, stage-1 MST, adder trees, candidate search) reproduces the
+oracle's op lists.  No GPU involved; the GPU tests repeat the same comparisons through the HIP backend."""
+
+import numpy as np
+import pytest
+
+from cases import TEST_CMVM_GRID, int_matrix, random_case, reference_style_kernel
+
+
+@pytest.mark.parametrize('block', range(8))
+def test_random_cases(model, oracle, block):
+    for seed in range(block * 40, block * 40 + 40):
+        k, opts, zero_input = random_case(seed)
+        got = model.solve(k, **opts)
+        assert got == oracle.solve(k, **opts), (seed, opts)
+        if not zero_input:
+            assert np.all(got.kernel == k)
+
+
+@pytest.mark.parametrize('n,bits', [(2, 2), (4, 4), (8, 8), (8, 4)])
+def test_reference_grid(model, oracle, n, bits):
+    k = reference_style_kernel(n * 10 + bits, n, bits)
+    for opts in TEST_CMVM_GRID:
+        assert model.solve(k, **opts) == oracle.solve(k, **opts), opts
+
+
+def test_decompositions(model, oracle):
+    for seed in range(30):
+        k, _, _ = random_case(seed)
+        assert all(np.array_equal(a, b) for a, b in zip(model.csd_decompose(k), oracle.csd_decompose(k)))
+        assert all(np.array_equal(a, b) for a, b in zip(model.csd_decompose(k, center=False), oracle.csd_decompose(k, center=False)))
+        for dc in (-2, -1, 0, 1, 2, 3):
+            assert all(np.array_equal(a, b) for a, b in zip(model.kernel_decompose(k, dc), oracle.kernel_decompose(k, dc)))
+
+
+def test_naf_equals_threshold_recoding(model, oracle):
+    """the bit-trick NAF of cmvm_core.h against the reference's threshold recoding: every |x| < 2^13 and sampled large values"""
+    x = np.arange(-(2**13), 2**13 + 1, dtype=np.int32)
+    assert np.array_equal(model.int_arr_to_csd(x), oracle.int_arr_to_csd(x))
+    rng = np.random.default_rng(5)
+    for hi in (2**17, 2**24, 2**28):  # beyond 30 digits the reference overflows int32 (bit_decompose.cc:34-35)
+        x = np.concatenate([rng.integers(-hi, hi, 4000), [hi - 1, -(hi - 1), hi // 3, hi // 3 + 1, 2 * hi // 3, 2 * hi // 3 + 1]]).astype(np.int32)
+        assert np.array_equal(model.int_arr_to_csd(x), oracle.int_arr_to_csd(x))
+
+
+@pytest.mark.parametrize('seed', range(4))
+def test_c1_16x16_int4(model, oracle, seed):
+    k = int_matrix(seed, 16, 16, -8, 8)
+    for opts in (dict(), dict(adder_size=1, carry_size=-1)):
+        assert model.solve(k, **opts) == oracle.solve(k, **opts)
+
+
+def test_int8_32(model, oracle):
+    k = int_matrix(0, 32, 32, -128, 128)
+    for opts in (dict(), dict(method0='mc', method1='wmc', hard_dc=2, adder_size=1, carry_size=-1)):
+        assert model.solve(k, **opts) == oracle.solve(k, **opts)
+
+
+def test_wide_and_ragged(model, oracle):
+    """> 16 CSD digits (64-bit cells), single row / column, all-zero rows and columns, fractional (shifted) entries"""
+    ks = [
+        int_matrix(3, 6, 5, -(2**19), 2**19),
+        int_matrix(4, 1, 9, -64, 64),
+        int_matrix(5, 9, 1, -64, 64),
+        np.zeros((3, 4), np.float32),
+        (int_matrix(6, 5, 5, -32, 32) * 2.0**-7).astype(np.float32),
+    ]
+    ks[1][0, 2] = 0
+    for k in ks:
+        for opts in (dict(), dict(search_all_decompose_dc=False, method0='mc-pdc', adder_size=2, carry_size=4)):
+            assert model.solve(k, **opts) == oracle.solve(k, **opts)
+
+
+def test_unknown_method(model):
+    with pytest.raises(RuntimeError, match='Unknown method: nope'):
+        model.solve(int_matrix(0, 8, 8, -8, 8), method0='nope', search_all_decompose_dc=False)
+    # the reference only throws once the table is non-empty (cmvm_core.cc:36-64): a trivial matrix passes
+    model.solve(np.eye(2, dtype=np.float32), method0='nope', method1='nope', search_all_decompose_dc=False)
