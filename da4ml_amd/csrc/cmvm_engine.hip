@@ -1166,7 +1166,7 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
         int cnt = ranges[w].count;
         if (cnt == 0) continue;
         // keep the whole chip busy: ~4 blocks per CU in total, at least 2 and at most 32 per chain
-        upd_blocks[w] = std::max(2, std::min(32, 1024 / std::max(cnt, 1)));
+        upd_blocks[w] = std::max(2, std::min(64, (2048 + cnt - 1) / std::max(cnt, 1)));
     }
     for (int w = 0; w < 2; ++w) {
         const Range &r = ranges[w];

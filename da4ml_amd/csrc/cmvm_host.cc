@@ -7,8 +7,12 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <atomic>
+#include <exception>
 #include <limits>
 #include <memory>
+#include <mutex>
+#include <thread>
 
 namespace da {
 
@@ -314,6 +318,33 @@ StageResult finalize_chain(const ChainJob &job, const ChainOut &out) {
 // ------------------------------------------------------------------------------- search orchestration
 namespace {
 
+// run fn(i) for i in [0, n) on a few host threads (the per-chain host work -- MST, adder trees -- is independent)
+template <class Fn> void parallel_for(size_t n, Fn &&fn) {
+    unsigned hw = std::thread::hardware_concurrency();
+    size_t workers = std::min<size_t>(n, std::max(1u, std::min(hw ? hw : 1u, 32u)));
+    if (workers <= 1) {
+        for (size_t i = 0; i < n; ++i) fn(i);
+        return;
+    }
+    std::atomic<size_t> next{0};
+    std::exception_ptr err;
+    std::mutex err_mu;
+    std::vector<std::thread> pool;
+    for (size_t w = 0; w < workers; ++w)
+        pool.emplace_back([&] {
+            for (size_t i = next++; i < n; i = next++) {
+                try {
+                    fn(i);
+                } catch (...) {
+                    std::lock_guard<std::mutex> lk(err_mu);
+                    if (!err) err = std::current_exception();
+                }
+            }
+        });
+    for (auto &t : pool) t.join();
+    if (err) std::rethrow_exception(err);
+}
+
 bool has_dc_suffix(const std::string &m) { return m.size() >= 2 && m.compare(m.size() - 2, 2, "dc") == 0; }
 
 struct Candidate {  // one _solve() of the reference (api.cc:28-145) as a resumable state machine
@@ -396,6 +427,29 @@ std::vector<PipeResult> solve_batch(Backend &be, const std::vector<Problem> &pro
         std::vector<ChainJob> jobs;
         std::vector<Pending> owners;
         std::vector<char> minlat_queued(ps.size(), 0);
+        // stage-1 work of this round (distance matrix once per problem on the device, MST + m0/m1 per candidate on
+        // host threads)
+        {
+            std::vector<size_t> todo;
+            for (size_t ci = 0; ci < cands.size(); ++ci) {
+                Candidate &c = cands[ci];
+                ProblemState &s = ps[c.problem];
+                bool ready = c.phase == Candidate::NEED_STAGE0 || (c.phase == Candidate::NEED_MINLAT && s.minlat_known);
+                if (!ready) continue;
+                todo.push_back(ci);
+                int ddc = c.decompose_dc;
+                if (ddc != -1) stage1_distances(be, s.s1);
+            }
+            parallel_for(todo.size(), [&](size_t k) {
+                Candidate &c = cands[todo[k]];
+                ProblemState &s = ps[c.problem];
+                if (c.phase == Candidate::NEED_MINLAT) {
+                    c.allowed = c.hard_dc + s.minlat;
+                    c.phase = Candidate::NEED_STAGE0;
+                }
+                prepare_stage0(c);
+            });
+        }
         for (size_t ci = 0; ci < cands.size(); ++ci) {
             Candidate &c = cands[ci];
             ProblemState &s = ps[c.problem];
@@ -414,7 +468,6 @@ std::vector<PipeResult> solve_batch(Backend &be, const std::vector<Problem> &pro
                     continue;
             }
             if (c.phase == Candidate::NEED_STAGE0) {
-                prepare_stage0(c);
                 jobs.push_back(ChainJob{c.m0.data(), p.n_in, p.n_out, parse_method(c.method0), s.qints.data(), s.lats.data(), p.opt.adder_size, p.opt.carry_size});
                 owners.push_back(Pending{(int)ci, 1, c.problem});
             } else if (c.phase == Candidate::NEED_STAGE1) {
@@ -425,6 +478,13 @@ std::vector<PipeResult> solve_batch(Backend &be, const std::vector<Problem> &pro
         if (jobs.empty()) break;
         std::vector<ChainOut> outs(jobs.size());
         be.run_chains(jobs.data(), outs.data(), (int)jobs.size());
+        for (size_t k = 0; k < jobs.size(); ++k)
+            if (outs[k].unknown_method_hit) {
+                Candidate &c = cands[owners[k].cand];
+                throw std::runtime_error("Unknown method: " + (owners[k].what == 2 ? c.method1 : c.method0));
+            }
+        std::vector<StageResult> sols(jobs.size());
+        parallel_for(jobs.size(), [&](size_t k) { sols[k] = finalize_chain(jobs[k], outs[k]); });
         for (size_t k = 0; k < jobs.size(); ++k) {
             Candidate &c = cands[owners[k].cand];
             ProblemState &s = ps[c.problem];
@@ -441,9 +501,7 @@ std::vector<PipeResult> solve_batch(Backend &be, const std::vector<Problem> &pro
                 a.partners += b.partners;
                 a.matches += b.matches;
             }
-            if (outs[k].unknown_method_hit)
-                throw std::runtime_error("Unknown method: " + (owners[k].what == 2 ? c.method1 : c.method0));
-            StageResult sol = finalize_chain(jobs[k], outs[k]);
+            StageResult sol = std::move(sols[k]);
             bool both_wmc_dc = c.method0 == "wmc-dc" && c.method1 == "wmc-dc";
             if (owners[k].what == 0) {
                 s.minlat = max_out_latency(sol);
