@@ -33,11 +33,14 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <numeric>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "cmvm_core.h"
@@ -60,7 +63,7 @@ constexpr int WAVE = 64;
 constexpr int SEL_THREADS = 1024;  // k_iter_select block (16 waves)
 constexpr int UPD_THREADS = 256;   // k_iter_update block
 constexpr int UPD_WAVES = UPD_THREADS / WAVE;
-constexpr int MAX_GROUPS = 8192;   // ub[] copy held in LDS by k_iter_select (64 KiB of u64)
+constexpr int MAX_GROUPS = 4096;   // ub[] copy held in LDS by k_iter_select (32 KiB of u64)
 
 struct HStat {
     int ov;
@@ -111,6 +114,7 @@ struct ChainDev {
     uint32_t *fin_count;
     // statistics
     unsigned long long st_rescans, st_partners, st_matches, st_found, st_inserts, st_cells;
+    unsigned long long st_phase[12];  // shader-clock cycles per kernel phase (select: 0-6, update: 7-11)
 };
 
 __constant__ Log2Table c_log2;
@@ -326,6 +330,81 @@ __device__ void table_update(const Ctx &c, int slot, unsigned long long key, Cnt
     }
 }
 
+// Two block updates with all their loads in flight together (a partner row touches its blocks with A and with B).
+// slot < 0 means "no such block".  delta arrays live in LDS.
+__device__ __forceinline__ void table_update_pair(const Ctx &c, int slot0, unsigned long long key0, const uint32_t *d0, int slot1,
+                                                  unsigned long long key1, const uint32_t *d1) {
+    const int lane = lane_id();
+    const bool h0 = slot0 >= 0, h1 = slot1 >= 0;
+    HStat st0 = h0 ? c.hstat[slot0] : HStat{0, 0.0f}, st1 = h1 ? c.hstat[slot1] : HStat{0, 0.0f};
+    uint32_t prev0 = h0 ? c.hrank[slot0] : 0u, prev1 = h1 ? c.hrank[slot1] : 0u;
+    uint32_t o0[2] = {0, 0}, o1[2] = {0, 0};
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        int k = lane + u * WAVE;
+        if (k < c.K) {
+            if (h0) o0[u] = c.hcnt[(size_t)slot0 * c.Kpad + k];
+            if (h1) o1[u] = c.hcnt[(size_t)slot1 * c.Kpad + k];
+        }
+    }
+    unsigned long long best0 = 0, best1 = 0;
+    int alive0 = 0, alive1 = 0;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        int k = lane + u * WAVE;
+        if (k < c.K) {
+            if (h0) {
+                uint32_t n = o0[u] - d0[k];
+                if (n != o0[u]) c.hcnt[(size_t)slot0 * c.Kpad + k] = (uint16_t)n;
+                alive0 |= n >= 2;
+                uint32_t r = entry_rank(n, st0.ov, st0.dl, c.method);
+                unsigned long long cand = r ? (((unsigned long long)r << 8) | (unsigned)k) : 0ull;
+                best0 = cand > best0 ? cand : best0;
+            }
+            if (h1) {
+                uint32_t n = o1[u] - d1[k];
+                if (n != o1[u]) c.hcnt[(size_t)slot1 * c.Kpad + k] = (uint16_t)n;
+                alive1 |= n >= 2;
+                uint32_t r = entry_rank(n, st1.ov, st1.dl, c.method);
+                unsigned long long cand = r ? (((unsigned long long)r << 8) | (unsigned)k) : 0ull;
+                best1 = cand > best1 ? cand : best1;
+            }
+        }
+    }
+    best0 = wave_max_u64(best0);
+    best1 = wave_max_u64(best1);
+    alive0 = __any(alive0);
+    alive1 = __any(alive1);
+    if (lane == 0) {
+        if (h0) {
+            if (!alive0) {
+                c.hrank[slot0] = 0;
+                c.hkey[slot0] = KEY_TOMB;
+                atomicSub(&c.g->n_live, 1u);
+            } else {
+                uint32_t rank = (uint32_t)(best0 >> 8);
+                if (rank != prev0) c.hrank[slot0] = rank;
+                c.hidx[slot0] = (uint8_t)(best0 & 0xFF);
+                if (rank > prev0)
+                    atomicMax(&c.ub[slot0 >> c.gs_log2], bound_word(rank, tie_word((uint32_t)key0, (uint32_t)(key0 >> 32), (int)(best0 & 0xFF))));
+            }
+        }
+        if (h1) {
+            if (!alive1) {
+                c.hrank[slot1] = 0;
+                c.hkey[slot1] = KEY_TOMB;
+                atomicSub(&c.g->n_live, 1u);
+            } else {
+                uint32_t rank = (uint32_t)(best1 >> 8);
+                if (rank != prev1) c.hrank[slot1] = rank;
+                c.hidx[slot1] = (uint8_t)(best1 & 0xFF);
+                if (rank > prev1)
+                    atomicMax(&c.ub[slot1 >> c.gs_log2], bound_word(rank, tie_word((uint32_t)key1, (uint32_t)(key1 >> 32), (int)(best1 & 0xFF))));
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ k_prepare
 // One block per chain: centring shifts, centred integer matrix, digit width, digit statistics.
 __global__ void __launch_bounds__(256) k_prepare(ChainDev *chains) {
@@ -488,9 +567,9 @@ template <class Cell> __global__ void __launch_bounds__(SEL_THREADS) k_iter_sele
     int *s_len = reinterpret_cast<int *>(s_cnt + 6 * Kpad);                           // [n_out + 1] list lengths -> offsets
     int *s_col = s_len + n_out + 1;                                                   // [n_out] matched columns
     constexpr int NW = SEL_THREADS / WAVE;
-    __shared__ uint32_t s_red_rank[NW];
-    __shared__ unsigned long long s_red_tie[NW];
-    __shared__ unsigned long long s_floor;  // lower bound (bound-word form) of the best verified entry
+    __shared__ unsigned long long s_prop_b[NW], s_q_tie[NW];
+    __shared__ int s_prop_g[NW];
+    __shared__ uint32_t s_q_rank[NW];
     __shared__ uint32_t s_best_rank;
     __shared__ unsigned long long s_best_tie;
     __shared__ int s_m, s_np, s_part[NW];
@@ -499,6 +578,8 @@ template <class Cell> __global__ void __launch_bounds__(SEL_THREADS) k_iter_sele
     const int tid = threadIdx.x, lane = lane_id(), wid = wave_id();
     const int gs = 1 << c.gs_log2;
 
+    long long tp[8];
+    tp[0] = clock64();
     if (g->error != E_OK) {  // a capacity error poisons the chain: stop it (the host retries with a larger arena)
         if (tid == 0) {
             g->done = 1;
@@ -508,21 +589,28 @@ template <class Cell> __global__ void __launch_bounds__(SEL_THREADS) k_iter_sele
         return;
     }
 
-    // ---------------- (1) selection: every wave owns the groups g == wid (mod NW) and repeatedly verifies its
-    // highest unverified bound until that bound falls below the best verified entry of the whole block.
+    // ---------------- (1) selection.  Bounds are cached in LDS.  Per round every wave proposes its highest unverified
+    // bound (groups g == wid mod NW), the four highest proposals are verified -- each by a quarter of the block, all
+    // four in flight together -- and the loop ends when no unverified bound can beat or tie the best verified entry.
     for (int q = tid; q < n_groups; q += SEL_THREADS) {
         s_ub[q] = c.ub[q];
         s_seen[q] = 0;
     }
-    if (tid == 0) s_floor = 0;
+    if (tid == 0) {
+        s_best_rank = 0;
+        s_best_tie = 0;
+        s_m = 0;
+        s_np = 0;
+    }
     __syncthreads();
+    tp[1] = clock64();
     {
-        uint32_t wrank = 0;
-        unsigned long long wtie = 0;
+        constexpr int QT = SEL_THREADS / 4, QW = QT / WAVE;  // threads / waves per quarter
+        const int quarter = tid / QT, qtid = tid % QT, qwid = wid % QW;
         unsigned int rescans = 0;
         while (true) {
             unsigned long long top = 0;
-            int top_g = -1;
+            int top_g = 0;
             for (int q = wid + lane * NW; q < n_groups; q += NW * WAVE) {
                 unsigned long long v = s_seen[q] ? 0ull : s_ub[q];
                 if (v > top) {
@@ -531,62 +619,95 @@ template <class Cell> __global__ void __launch_bounds__(SEL_THREADS) k_iter_sele
                 }
             }
             unsigned long long wtop = wave_max_u64(top);
-            if (wtop == 0) break;
-            unsigned long long floor_now = *(volatile unsigned long long *)&s_floor;
-            if (wtop < floor_now) break;  // nothing left in this partition can beat or tie the best verified entry
-            unsigned long long who = __ballot(top == wtop && top_g >= 0);
-            int grp = __shfl(top_g, __ffsll((long long)who) - 1);
-            uint32_t base = (uint32_t)grp * gs;
+            unsigned long long who = __ballot(top == wtop);
+            int wg = __shfl(top_g, __ffsll((long long)who) - 1);
+            if (lane == 0) {
+                s_prop_b[wid] = wtop;
+                s_prop_g[wid] = wg;
+            }
+            __syncthreads();
+            // every thread ranks the NW proposals identically and keeps the four highest
+            unsigned long long cb[4] = {0, 0, 0, 0};
+            int cg[4] = {-1, -1, -1, -1};
+            for (int w = 0; w < NW; ++w) {
+                unsigned long long v = s_prop_b[w];
+                int gg = s_prop_g[w];
+                for (int t = 0; t < 4; ++t)
+                    if (v > cb[t]) {
+                        unsigned long long tv = cb[t];
+                        int tg = cg[t];
+                        cb[t] = v;
+                        cg[t] = gg;
+                        v = tv;
+                        gg = tg;
+                    }
+            }
+            const unsigned long long floor_now = s_best_rank ? bound_word(s_best_rank, s_best_tie) : 0ull;
+            if (cb[0] == 0 || cb[0] < floor_now) break;  // uniform: all threads see the same proposals
+            // verify candidate `quarter` with this quarter of the block
+            const unsigned long long my_b = cb[quarter];
+            const int my_g = cg[quarter];
+            const bool work = my_b != 0 && my_b >= floor_now;
+            uint32_t rk[8];
             uint32_t grank = 0;
-            for (int o = lane; o < gs; o += WAVE) grank = max(grank, c.hrank[base + o]);
+            const uint32_t base = work ? (uint32_t)my_g * gs : 0u;
+            if (work) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    int o = qtid + u * QT;
+                    rk[u] = o < gs ? c.hrank[base + o] : 0u;
+                    grank = max(grank, rk[u]);
+                }
+            }
             grank = wave_max_u32(grank);
+            if (lane == 0) s_q_rank[quarter * QW + qwid] = grank;
+            __syncthreads();
+            grank = 0;
+            for (int w = 0; w < QW; ++w) grank = max(grank, s_q_rank[quarter * QW + w]);
             unsigned long long gtie = 0;
-            if (grank) {
-                for (int o = lane; o < gs; o += WAVE) {
-                    uint32_t sl = base + o;
-                    if (c.hrank[sl] == grank) {
-                        unsigned long long kk = c.hkey[sl];
-                        unsigned long long tw = tie_word((uint32_t)kk, (uint32_t)(kk >> 32), c.hidx[sl]);
+            if (work && grank) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    int o = qtid + u * QT;
+                    if (o < gs && rk[u] == grank) {
+                        unsigned long long kk = c.hkey[base + o];
+                        unsigned long long tw = tie_word((uint32_t)kk, (uint32_t)(kk >> 32), c.hidx[base + o]);
                         gtie = tw > gtie ? tw : gtie;
                     }
                 }
-                gtie = wave_max_u64(gtie);
             }
-            unsigned long long exact = grank ? bound_word(grank, gtie) : 0ull;
-            if (lane == 0) {
-                s_ub[grp] = exact;
-                s_seen[grp] = 1;
-                c.ub[grp] = exact;  // no writer races with this kernel: the bound is now tight
-                if (exact) atomicMax(&s_floor, exact);
+            gtie = wave_max_u64(gtie);
+            if (lane == 0) s_q_tie[quarter * QW + qwid] = gtie;
+            __syncthreads();
+            if (tid == 0) {
+                uint32_t br = s_best_rank;
+                unsigned long long bt = s_best_tie;
+                for (int t = 0; t < 4; ++t) {
+                    if (cb[t] == 0 || cb[t] < floor_now) continue;
+                    uint32_t r = 0;
+                    unsigned long long tw = 0;
+                    for (int w = 0; w < QW; ++w) {
+                        r = max(r, s_q_rank[t * QW + w]);
+                        tw = s_q_tie[t * QW + w] > tw ? s_q_tie[t * QW + w] : tw;
+                    }
+                    unsigned long long exact = r ? bound_word(r, tw) : 0ull;
+                    s_ub[cg[t]] = exact;
+                    s_seen[cg[t]] = 1;
+                    c.ub[cg[t]] = exact;  // no writer races with this kernel: the bound is now tight
+                    if (r > br || (r == br && tw > bt)) {
+                        br = r;
+                        bt = tw;
+                    }
+                    ++rescans;
+                }
+                s_best_rank = br;
+                s_best_tie = bt;
             }
-            lds_fence();
-            if (grank > wrank || (grank == wrank && gtie > wtie)) {
-                wrank = grank;
-                wtie = gtie;
-            }
-            ++rescans;
+            __syncthreads();
         }
-        if (lane == 0) {
-            s_red_rank[wid] = wrank;
-            s_red_tie[wid] = wtie;
-            if (rescans) atomicAdd(&g->st_rescans, (unsigned long long)rescans);
-        }
+        if (tid == 0 && rescans) g->st_rescans += rescans;
     }
-    __syncthreads();
-    if (tid == 0) {
-        uint32_t br = 0;
-        unsigned long long bt = 0;
-        for (int w = 0; w < NW; ++w)
-            if (s_red_rank[w] > br || (s_red_rank[w] == br && s_red_tie[w] > bt)) {
-                br = s_red_rank[w];
-                bt = s_red_tie[w];
-            }
-        s_best_rank = br;
-        s_best_tie = bt;
-        s_m = 0;
-        s_np = 0;
-    }
-    __syncthreads();
+    tp[2] = clock64();
     const uint32_t best_rank = s_best_rank;
     const unsigned long long best_tie = s_best_tie;
     const uint32_t Nw = (uint32_t)g->n_rows;
@@ -620,6 +741,7 @@ template <class Cell> __global__ void __launch_bounds__(SEL_THREADS) k_iter_sele
     }
     for (int k = tid; k < 6 * Kpad; k += SEL_THREADS) s_cnt[k] = 0;
     __syncthreads();
+    tp[3] = clock64();
     Cell *cells = reinterpret_cast<Cell *>(g->cells);
     Cell *rowA = cells + (size_t)A * n_out, *rowB = cells + (size_t)B * n_out, *rowN = cells + (size_t)Nw * n_out;
     Cell *mA = reinterpret_cast<Cell *>(g->mA), *mB = reinterpret_cast<Cell *>(g->mB);
@@ -662,6 +784,7 @@ template <class Cell> __global__ void __launch_bounds__(SEL_THREADS) k_iter_sele
     }
     if (my_matches) atomicAdd(&g->st_matches, (unsigned long long)my_matches);
     __syncthreads();
+    tp[4] = clock64();
     const int m = s_m;
     // exclusive prefix sum of the list lengths of the matched columns (m <= n_out): chunked block scan
     {
@@ -688,6 +811,7 @@ template <class Cell> __global__ void __launch_bounds__(SEL_THREADS) k_iter_sele
         __syncthreads();
     }
     const int total = s_len[m];
+    tp[5] = clock64();
     // ---------------- (4) partner rows: every row listed in a matched column, claimed once (stamp) and appended
     {
         uint32_t *stamp = g->stamp, *plist = g->plist;
@@ -705,6 +829,7 @@ template <class Cell> __global__ void __launch_bounds__(SEL_THREADS) k_iter_sele
             if (r != A && r != B && atomicExch(&stamp[r], tag) != tag) plist[atomicAdd(&s_np, 1)] = r;
         }
     }
+    tp[6] = clock64();
     // six special pairs, one wave each (runs concurrently with the claims above on the other waves)
     if (wid < 6) {
         uint32_t lo = A, hi = A;
@@ -731,7 +856,9 @@ template <class Cell> __global__ void __launch_bounds__(SEL_THREADS) k_iter_sele
         }
     }
     __syncthreads();
+    tp[7] = clock64();
     if (tid == 0) {
+        for (int q = 0; q < 7; ++q) g->st_phase[q] += (unsigned long long)(tp[q + 1] - tp[q]);
         g->m = m;
         g->n_partners = s_np;
         g->work_ctr = 0;
@@ -778,24 +905,30 @@ template <class Cell> __global__ void __launch_bounds__(UPD_THREADS) k_iter_upda
     const RowInfo rnew = c.rows[Nw];
     uint32_t *dA = s_cnt + (size_t)wid * 3 * Kpad, *dB = dA + Kpad, *cN = dB + Kpad;
     unsigned int partners = 0, found = 0, inserts = 0;
-    while (true) {
-        int q = 0;
-        if (lane == 0) q = (int)atomicAdd(&g->work_ctr, 1u);
-        q = __shfl(q, 0);
-        if (q >= n_partners) break;
-        const uint32_t pr = plist[q];
+    long long up[5] = {0, 0, 0, 0, 0}, u0 = clock64(), u1;
+    // static striding over the partner list (no work counter: partners cost about the same), next entry prefetched
+    const int total_waves = (int)gridDim.x * UPD_WAVES;
+    const int first = (int)blockIdx.x * UPD_WAVES + wid;
+    uint32_t pr_next = first < n_partners ? plist[first] : 0u;
+    for (int q = first; q < n_partners; q += total_waves) {
+        const uint32_t pr = pr_next;
+        if (q + total_waves < n_partners) pr_next = plist[q + total_waves];
         ++partners;
-        // both table probes and the partner's interval are independent of the digit loop: issue them first
+        // independent loads first: the partner's cells in the first 64 substituted columns and both table probes
+        const Cell *rowR = cells + (size_t)pr * n_out;
+        const Cell x0 = lane < m ? rowR[s_col[lane]] : (Cell)0;
         const uint32_t lA = min(A, pr), hA = max(A, pr), lB = min(B, pr), hB = max(B, pr);
         const unsigned long long keyA = pack_pair(lA, hA), keyB = pack_pair(lB, hB);
         int slotA, slotB;
         table_find2(c, keyA, hash_pair(lA, hA), keyB, hash_pair(lB, hB), !same, slotA, slotB);
+        u1 = clock64();
+        up[1] += u1 - u0;  // list entry + two table probes
+        u0 = u1;
         for (int k = lane; k < 3 * Kpad; k += WAVE) dA[k] = 0;
         lds_fence();
-        const Cell *rowR = cells + (size_t)pr * n_out;
         int got_new = 0;
         for (int j = lane; j < m; j += WAVE) {
-            Cell x = rowR[s_col[j]];
+            Cell x = j == lane ? x0 : rowR[s_col[j]];
             if (!x) continue;
             Cell ma = s_mA[j], mb = s_mB[j];
             if (slotA >= 0) {
@@ -806,14 +939,24 @@ template <class Cell> __global__ void __launch_bounds__(UPD_THREADS) k_iter_upda
             for_pairs_cross<Cell>(x, ma, nb, [&](int k) { got_new |= atomicAdd(&cN[k], 1u) >= 1u; });
         }
         lds_fence();
-        if (slotA >= 0) table_update(c, slotA, keyA, [&](int k, uint32_t old) { return old - dA[k]; });
-        if (slotB >= 0) table_update(c, slotB, keyB, [&](int k, uint32_t old) { return old - dB[k]; });
+        u1 = clock64();
+        up[2] += u1 - u0;  // cells + pair enumeration
+        u0 = u1;
+        if (slotA >= 0 || slotB >= 0) table_update_pair(c, slotA, keyA, dA, slotB, keyB, dB);
         found += (slotA >= 0) + (slotB >= 0);
+        u1 = clock64();
+        up[3] += u1 - u0;  // block updates
+        u0 = u1;
         if (__any(got_new)) {
             table_insert(c, pr, Nw, c.rows[pr], rnew, [&](int k) { return cN[k]; });
             ++inserts;
         }
+        u1 = clock64();
+        up[4] += u1 - u0;  // block creation
+        u0 = u1;
     }
+    if (lane == 0)
+        for (int q = 0; q < 5; ++q) atomicAdd(&g->st_phase[7 + q], (unsigned long long)up[q]);
     if (lane == 0 && partners) {
         atomicAdd(&g->st_partners, (unsigned long long)partners);
         atomicAdd(&g->st_cells, (unsigned long long)partners * (unsigned)m);
@@ -947,6 +1090,11 @@ uint32_t pow2_ceil(uint64_t v) {
 struct HipBackend::Impl {
     int device = 0;
     hipStream_t stream = nullptr;
+    static constexpr int MAX_LANES = 4;
+    hipStream_t lanes[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};  // greedy-loop streams of the chain groups
+    int n_lanes = 2;
+    bool use_graph = false;
+    bool mt_launch = false;
     DeviceBuffer arena, desc_buf, io_buf;
     unsigned int *d_done = nullptr;
     unsigned int *h_done = nullptr;  // pinned
@@ -958,6 +1106,10 @@ HipBackend::HipBackend(int device) : impl_(new Impl) {
     impl_->device = device;
     HIP_CHECK(hipSetDevice(device));
     HIP_CHECK(hipStreamCreateWithFlags(&impl_->stream, hipStreamNonBlocking));
+    for (auto &l : impl_->lanes) HIP_CHECK(hipStreamCreateWithFlags(&l, hipStreamNonBlocking));
+    if (const char *e = std::getenv("DA4ML_HIP_MT")) impl_->mt_launch = std::atoi(e) != 0;
+    if (const char *e = std::getenv("DA4ML_HIP_GRAPH")) impl_->use_graph = std::atoi(e) != 0;
+    if (const char *e = std::getenv("DA4ML_HIP_LANES")) impl_->n_lanes = std::max(1, std::min((int)Impl::MAX_LANES, std::atoi(e)));
     HIP_CHECK(hipMalloc(&impl_->d_done, sizeof(unsigned int)));
     HIP_CHECK(hipHostMalloc(&impl_->h_done, sizeof(unsigned int), hipHostMallocDefault));
     Log2Table t = measure_log2_table();
@@ -968,6 +1120,8 @@ HipBackend::~HipBackend() {
     if (impl_->d_done) (void)hipFree(impl_->d_done);
     if (impl_->h_done) (void)hipHostFree(impl_->h_done);
     if (impl_->stream) (void)hipStreamDestroy(impl_->stream);
+    for (auto &l : impl_->lanes)
+        if (l) (void)hipStreamDestroy(l);
 }
 const GpuTimings &HipBackend::timings() const { return impl_->timings; }
 void HipBackend::reset_timings() { impl_->timings = GpuTimings{}; }
@@ -1090,11 +1244,12 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
         // table capacity: blocks peak well above the initial pair count when rows are dense
         long long pairs0 = std::min<long long>((long long)jobs[i].n_in * (jobs[i].n_in + 1) / 2, std::max<long long>(d.prep_pairs, 1));
         double growth = std::max(4.0, jobs[i].n_in / 5.0);
-        double want = std::max(1024.0, 1.6 * pairs0 * growth * im.table_scale);
+        double want = std::max(1024.0, 0.8 * pairs0 * growth * im.table_scale);
         if (jobs[i].method == M_DUMMY) want = 64;
         g.C = pow2_ceil((uint64_t)want);
         g.gs_log2 = 8;
         while ((g.C >> g.gs_log2) > (uint32_t)MAX_GROUPS) ++g.gs_log2;
+        if (g.gs_log2 > 11) throw std::runtime_error("pair table larger than 8M slots is not supported yet");
         if (g.C < 256) g.C = 256;
         g.n_groups = (int)(g.C >> g.gs_log2);
         ChainDev tmp;
@@ -1189,56 +1344,137 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
     if (ranges[1].count)
         HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_iter_select<uint64_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sel_lds[1]));
 
-    // ---- 4. greedy loop: all chains advance in lockstep, two kernels per iteration
+    // ---- 4. greedy loop: two kernels per iteration.  The chains are split into up to four groups, each advancing
+    // in lockstep on its own stream, so that the one-block-per-chain select kernel of one group overlaps the update
+    // kernel of the others.
     hipEvent_t ev0, ev1;
     HIP_CHECK(hipEventCreate(&ev0));
     HIP_CHECK(hipEventCreate(&ev1));
     HIP_CHECK(hipEventRecord(ev0, st));
-    // per-kernel durations: every SAMPLE_EVERY-th lockstep iteration is bracketed by HIP events on the launch stream
-    constexpr int SAMPLE_EVERY = 16, MAX_SAMPLES = 2048;
-    const bool can_sample = (ranges[0].count == 0) != (ranges[1].count == 0);
+    HIP_CHECK(hipStreamSynchronize(st));  // set-up done before the group streams start
+    struct Group {
+        int first, count, w;  // descriptor range, cell width index
+        hipStream_t stream;
+    };
+    std::vector<Group> groups;
+    for (int w = 0; w < 2; ++w) {
+        const Range &r = ranges[w];
+        if (r.count == 0) continue;
+        int parts = std::max(1, std::min(im.n_lanes, r.count / 8));
+        if (ranges[0].count && ranges[1].count) parts = std::max(1, parts / 2);
+        for (int p = 0; p < parts; ++p) {
+            int lo = r.first + (int)((long long)r.count * p / parts), hi = r.first + (int)((long long)r.count * (p + 1) / parts);
+            groups.push_back(Group{lo, hi - lo, w, im.lanes[groups.size() % Impl::MAX_LANES]});
+        }
+    }
+    // One greedy iteration of one group = (select, update) on the group's stream.
+    auto launch_pair = [&](const Group &gr, hipEvent_t *se) {
+        ChainDev *base = d_desc + gr.first;
+        if (se) HIP_CHECK(hipEventRecord(se[0], gr.stream));
+        if (gr.w == 0)
+            hipLaunchKernelGGL(k_iter_select<uint32_t>, dim3(gr.count), dim3(SEL_THREADS), sel_lds[0], gr.stream, base, im.d_done);
+        else
+            hipLaunchKernelGGL(k_iter_select<uint64_t>, dim3(gr.count), dim3(SEL_THREADS), sel_lds[1], gr.stream, base, im.d_done);
+        if (se) HIP_CHECK(hipEventRecord(se[1], gr.stream));
+        if (gr.w == 0)
+            hipLaunchKernelGGL(k_iter_update<uint32_t>, dim3(upd_blocks[0], gr.count), dim3(UPD_THREADS), upd_lds[0], gr.stream, base);
+        else
+            hipLaunchKernelGGL(k_iter_update<uint64_t>, dim3(upd_blocks[1], gr.count), dim3(UPD_THREADS), upd_lds[1], gr.stream, base);
+        if (se) HIP_CHECK(hipEventRecord(se[2], gr.stream));
+    };
+    // The launch-bound window of GRAPH_ITERS iterations x all groups is captured once into a hipGraph (fork/join over
+    // the group streams) and replayed; one eager, event-bracketed iteration per window samples the kernel durations.
+    constexpr int GRAPH_ITERS = 63, MAX_SAMPLES = 4096;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+    if (im.use_graph) {
+        hipEvent_t fork_ev;
+        std::vector<hipEvent_t> join_ev(groups.size());
+        bool ok = hipEventCreateWithFlags(&fork_ev, hipEventDisableTiming) == hipSuccess;
+        for (auto &e : join_ev) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess;
+        if (ok) {
+            bool cap = hipEventRecord(fork_ev, st) == hipSuccess;
+            for (const Group &gr : groups) cap = cap && hipStreamWaitEvent(gr.stream, fork_ev, 0) == hipSuccess;
+            if (cap) {
+                try {
+                    for (int it = 0; it < GRAPH_ITERS; ++it)
+                        for (const Group &gr : groups) launch_pair(gr, nullptr);
+                } catch (...) {
+                    cap = false;
+                }
+            }
+            for (size_t gi = 0; gi < groups.size(); ++gi) {
+                cap = cap && hipEventRecord(join_ev[gi], groups[gi].stream) == hipSuccess;
+                cap = cap && hipStreamWaitEvent(st, join_ev[gi], 0) == hipSuccess;
+            }
+            hipError_t e = hipStreamEndCapture(st, &graph);
+            if (!cap || e != hipSuccess || graph == nullptr || hipGraphInstantiate(&graph_exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+                if (graph) (void)hipGraphDestroy(graph);
+                graph = nullptr;
+                graph_exec = nullptr;
+                (void)hipGetLastError();
+            }
+        }
+        (void)hipEventDestroy(fork_ev);
+        for (auto &e : join_ev) (void)hipEventDestroy(e);
+    }
     std::vector<hipEvent_t> sample_ev;
     int n_samples = 0;
     long long launched_iters = 0, iter_cap = 0;
     for (int i = 0; i < n; ++i) iter_cap = std::max<long long>(iter_cap, geo[i].rcap - jobs[i].n_in + 2);
-    const int poll_every = 64;
+    const int poll_every = GRAPH_ITERS + 1;
     while (active > 0) {
         if (launched_iters > iter_cap + poll_every) throw std::runtime_error("greedy loop did not terminate within its row capacity (internal error)");
-        for (int it = 0; it < poll_every; ++it) {
-            const bool sample = can_sample && n_samples < MAX_SAMPLES && (launched_iters + it) % SAMPLE_EVERY == 0;
-            hipEvent_t se[3] = {nullptr, nullptr, nullptr};
+        // sampled eager iteration (all groups; the first group's kernels are bracketed by events on its stream)
+        for (size_t gi = 0; gi < groups.size(); ++gi) {
+            hipEvent_t se[3];
+            const bool sample = gi == 0 && n_samples < MAX_SAMPLES;
             if (sample) {
                 for (auto &e : se) {
                     HIP_CHECK(hipEventCreate(&e));
                     sample_ev.push_back(e);
                 }
                 ++n_samples;
-                HIP_CHECK(hipEventRecord(se[0], st));
             }
-            for (int w = 0; w < 2; ++w) {
-                const Range &r = ranges[w];
-                if (r.count == 0) continue;
-                ChainDev *base = d_desc + r.first;
-                if (!r.wide)
-                    hipLaunchKernelGGL(k_iter_select<uint32_t>, dim3(r.count), dim3(SEL_THREADS), sel_lds[w], st, base, im.d_done);
-                else
-                    hipLaunchKernelGGL(k_iter_select<uint64_t>, dim3(r.count), dim3(SEL_THREADS), sel_lds[w], st, base, im.d_done);
-                if (sample) HIP_CHECK(hipEventRecord(se[1], st));
-                if (!r.wide)
-                    hipLaunchKernelGGL(k_iter_update<uint32_t>, dim3(upd_blocks[w], r.count), dim3(UPD_THREADS), upd_lds[w], st, base);
-                else
-                    hipLaunchKernelGGL(k_iter_update<uint64_t>, dim3(upd_blocks[w], r.count), dim3(UPD_THREADS), upd_lds[w], st, base);
-            }
-            if (sample) HIP_CHECK(hipEventRecord(se[2], st));
+            launch_pair(groups[gi], sample ? se : nullptr);
+        }
+        if (graph_exec) {
+            for (const Group &gr : groups) HIP_CHECK(hipStreamSynchronize(gr.stream));
+            HIP_CHECK(hipGraphLaunch(graph_exec, st));
+        } else if (im.mt_launch && groups.size() > 1) {
+            // one host thread per group: the launch rate of a single thread limits 4 streams x 2 kernels per iteration
+            std::vector<std::thread> th;
+            std::exception_ptr err;
+            std::mutex mu;
+            for (const Group &gr : groups)
+                th.emplace_back([&, gr] {
+                    try {
+                        HIP_CHECK(hipSetDevice(im.device));
+                        for (int it = 0; it < GRAPH_ITERS; ++it) launch_pair(gr, nullptr);
+                    } catch (...) {
+                        std::lock_guard<std::mutex> lk(mu);
+                        if (!err) err = std::current_exception();
+                    }
+                });
+            for (auto &t : th) t.join();
+            if (err) std::rethrow_exception(err);
+        } else {
+            for (int it = 0; it < GRAPH_ITERS; ++it)
+                for (const Group &gr : groups) launch_pair(gr, nullptr);
         }
         launched_iters += poll_every;
         HIP_CHECK(hipGetLastError());
+        for (const Group &gr : groups) HIP_CHECK(hipStreamSynchronize(gr.stream));
         HIP_CHECK(hipMemcpyAsync(im.h_done, im.d_done, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipStreamSynchronize(st));
         int pre_done = 0;
         for (int i = 0; i < n; ++i) pre_done += (jobs[i].method == M_DUMMY || jobs[i].method < 0) ? 1 : 0;
         active = n - pre_done - (int)*im.h_done;
     }
+    if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
+    if (graph) (void)hipGraphDestroy(graph);
+    im.timings.graph_used += graph_exec ? 1 : 0;
     HIP_CHECK(hipEventRecord(ev1, st));
 
     // ---- 5. extraction and download
@@ -1355,6 +1591,7 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
         o.stats.scan_slots = (long long)d.st_rescans << d.gs_log2;
         o.stats.partners = (long long)d.st_partners;
         o.stats.matches = (long long)d.st_matches;
+        for (int q = 0; q < 12; ++q) im.timings.phase_cycles[q] += (double)d.st_phase[q];
         im.timings.found += (long long)d.st_found;
         im.timings.inserts += (long long)d.st_inserts;
         im.timings.cell_reads += (long long)d.st_cells;

@@ -17,6 +17,7 @@ struct GpuTimings {  // accumulated since the last reset; read by the benchmark 
     long long rescans = 0;         // table groups re-read by the selection
     long long partners = 0;        // partner rows processed by the update kernel
     long long chains = 0;
+    long long graph_used = 0;      // run_chains calls whose loop ran from a captured hipGraph
     long long dist_calls = 0;
     // sampled per-kernel durations (HIP events around every 16th lockstep iteration)
     double select_ms_sampled = 0, update_ms_sampled = 0;
@@ -25,6 +26,7 @@ struct GpuTimings {  // accumulated since the last reset; read by the benchmark 
     long long found = 0, inserts = 0, cell_reads = 0;
     double key_bytes = 0;     // 2 * K bytes per touched count block (u16 counts)
     double cell_bytes = 0;    // bytes of partner cells read
+    double phase_cycles[12] = {0};  // shader-clock cycles: k_iter_select phases 0-6, k_iter_update per-wave phases 7-11
     double table_bytes = 0;   // bytes of pair-table storage summed over chains
     double arena_bytes = 0;   // largest device arena used
 };

@@ -9,7 +9,11 @@ ks = [int_matrix(s, n, n, -128, 128) for s in range(B)]
 opts = dict(method0='wmc', method1='wmc', decompose_dc=-1, search_all_decompose_dc=False)
 hip.solve(ks[0][:8, :8].copy(), **opts)
 hip.timings(reset=True)
-t = time.time(); res = hip.solve_many(ks, _stats=True, **opts); dt = time.time() - t
+t = time.time(); raw = hip.solve_many_raw(ks, **opts); dt = time.time() - t; res = [(None, raw.summary(0))]; raw.free()
 tm = hip.timings(reset=True)
 print(f'{n}x{n} batch {B}: {dt:.3f}s  -> {B/dt:.2f} solves/s; loop {tm["loop_ms"]:.1f} ms, lockstep iters {tm["lockstep_iters"]:.0f}, us/iter {1e3*tm["loop_ms"]/max(tm["lockstep_iters"],1):.1f}')
-print(res[0][1], 'cost', res[0][0].cost, tm)
+print(res[0][1])
+ph = {k: v for k, v in tm.items() if k.startswith('sel_') or k.startswith('upd_')}
+its = max(tm['iterations'], 1); pa = max(tm['partners'], 1)
+print('select cycles/iteration:', {k: round(v / its) for k, v in ph.items() if k.startswith('sel_')})
+print('update cycles/partner  :', {k: round(v / pa) for k, v in ph.items() if k.startswith('upd_')}, 'partners/iter', round(pa / its), 'found/partner %.2f' % (tm['found'] / pa), 'inserts/partner %.3f' % (tm['inserts'] / pa))
