@@ -94,6 +94,8 @@ struct ChainDev {
     HStat *hstat;
     uint16_t *hcnt;
     unsigned long long *ub;
+    unsigned long long *gtie;  // [n_groups] full tie word of the group's best entry (valid while the group is clean)
+    uint8_t *gdirty;           // [n_groups] a block's best (rank, key) changed since the group was last verified
     // per-iteration hand-off select -> update
     int *mcol;
     void *mA, *mB;
@@ -174,6 +176,7 @@ struct Ctx {
     HStat *hstat;
     uint16_t *hcnt;
     unsigned long long *ub;
+    uint8_t *gdirty;
     const RowInfo *rows;
     ChainDev *g;
 };
@@ -193,57 +196,62 @@ __device__ __forceinline__ Ctx make_ctx(ChainDev *g) {
     c.hstat = g->hstat;
     c.hcnt = g->hcnt;
     c.ub = g->ub;
+    c.gdirty = g->gdirty;
     c.rows = g->rows;
     c.g = g;
     return c;
 }
 
-// All table operations are executed by one full wavefront; lane order == probe order inside a 64-slot window.
+// All table operations are executed by one full wavefront.  The table is probed in BUCKETS of 16 slots (one 128-byte
+// line of keys), starting at the bucket the hash points into and continuing with the following buckets.  A key is
+// always stored in the first bucket of its sequence that had a free slot, and slots never return to EMPTY, so a
+// look-up stops at the first bucket that contains the key or an EMPTY slot.
+constexpr uint32_t BUCKET = 16;
 
-// resolve one probe window: 1 = found (slot set), 0 = absent, -1 = undecided (continue with the next window)
-__device__ __forceinline__ int probe_window(unsigned long long kk, unsigned long long key, uint32_t start, uint32_t cmask, int &slot) {
-    unsigned long long hit = __ballot(kk == key);
-    unsigned long long emp = __ballot(kk == KEY_EMPTY);
-    if (hit) {
-        int l = __ffsll((long long)hit) - 1;
-        if (emp && (__ffsll((long long)emp) - 1) < l) return 0;
-        slot = (int)((start + l) & cmask);
-        return 1;
-    }
-    return emp ? 0 : -1;
-}
-// returns slot or -1
-__device__ int table_find_from(const Ctx &c, unsigned long long key, uint32_t h, uint32_t first_window) {
-    int lane = lane_id();
-    for (uint32_t w = first_window; w < c.windows; ++w) {
-        unsigned long long kk = c.hkey[(h + w * WAVE + lane) & c.cmask];
-        int slot = -1;
-        int r = probe_window(kk, key, h + w * WAVE, c.cmask, slot);
-        if (r >= 0) return r ? slot : -1;
+// look-up continuing at bucket number `first_bucket` of the sequence, 4 buckets (64 lanes) per step; slot or -1
+__device__ int table_find_from(const Ctx &c, unsigned long long key, uint32_t h, uint32_t first_bucket) {
+    const int lane = lane_id();
+    const uint32_t b0 = (h & ~(BUCKET - 1)) + first_bucket * BUCKET;
+    for (uint32_t w = 0; w < c.windows + 1; ++w) {
+        uint32_t s = (b0 + w * WAVE + lane) & c.cmask;
+        unsigned long long kk = c.hkey[s];
+        unsigned long long hit = __ballot(kk == key);
+        if (hit) return (int)((b0 + w * WAVE + (__ffsll((long long)hit) - 1)) & c.cmask);
+        if (__ballot(kk == KEY_EMPTY)) return -1;
     }
     return -1;
 }
 __device__ __forceinline__ int table_find(const Ctx &c, unsigned long long key, uint32_t h) { return table_find_from(c, key, h, 0); }
-// two independent look-ups with their first probe windows in flight together
+// two independent look-ups: lanes 0-15 read the first bucket of key0, lanes 16-31 that of key1 (one line each)
 __device__ __forceinline__ void table_find2(const Ctx &c, unsigned long long key0, uint32_t h0, unsigned long long key1, uint32_t h1,
                                             bool want1, int &slot0, int &slot1) {
-    int lane = lane_id();
-    unsigned long long k0 = c.hkey[(h0 + lane) & c.cmask];
-    unsigned long long k1 = want1 ? c.hkey[(h1 + lane) & c.cmask] : KEY_EMPTY;
+    const int lane = lane_id();
+    const bool second = lane >= (int)BUCKET;
+    const bool active = lane < (int)BUCKET || (want1 && lane < 2 * (int)BUCKET);
+    const uint32_t base = ((second ? h1 : h0) & ~(BUCKET - 1)) & c.cmask;
+    const unsigned long long want = second ? key1 : key0;
+    unsigned long long kk = active ? c.hkey[base + (lane & (BUCKET - 1))] : KEY_TOMB;
+    const unsigned long long hit = __ballot(active && kk == want), emp = __ballot(active && kk == KEY_EMPTY);
+    const unsigned long long m0 = 0xFFFFull, m1 = 0xFFFF0000ull;
     slot0 = slot1 = -1;
-    int r0 = probe_window(k0, key0, h0, c.cmask, slot0);
-    if (r0 < 0) slot0 = table_find_from(c, key0, h0, 1);
+    if (hit & m0)
+        slot0 = (int)(((h0 & ~(BUCKET - 1)) & c.cmask) + (__ffsll((long long)(hit & m0)) - 1));
+    else if (!(emp & m0))
+        slot0 = table_find_from(c, key0, h0, 1);
     if (want1) {
-        int r1 = probe_window(k1, key1, h1, c.cmask, slot1);
-        if (r1 < 0) slot1 = table_find_from(c, key1, h1, 1);
+        if (hit & m1)
+            slot1 = (int)(((h1 & ~(BUCKET - 1)) & c.cmask) + (__ffsll((long long)(hit & m1)) - 1 - (int)BUCKET));
+        else if (!(emp & m1))
+            slot1 = table_find_from(c, key1, h1, 1);
     }
 }
 
-// claim a slot for a key that is known to be absent; returns slot or -1 (table full)
+// claim a slot for a key that is known to be absent: the first free (EMPTY or TOMB) slot in bucket order; -1 = full
 __device__ int table_claim(const Ctx &c, unsigned long long key, uint32_t h) {
-    int lane = lane_id();
-    for (uint32_t w = 0; w < c.windows; ++w) {
-        uint32_t s = (h + w * WAVE + lane) & c.cmask;
+    const int lane = lane_id();
+    const uint32_t b0 = h & ~(BUCKET - 1);
+    for (uint32_t w = 0; w < c.windows + 1; ++w) {
+        uint32_t s = (b0 + w * WAVE + lane) & c.cmask;
         unsigned long long kk = c.hkey[s];
         unsigned long long avail = __ballot(kk == KEY_EMPTY || kk == KEY_TOMB);
         while (avail) {
@@ -255,7 +263,7 @@ __device__ int table_claim(const Ctx &c, unsigned long long key, uint32_t h) {
                 if (ok && kk == KEY_EMPTY) atomicAdd(&c.g->n_used, 1u);
             }
             ok = __shfl(ok, l);
-            if (ok) return (int)((h + w * WAVE + l) & c.cmask);
+            if (ok) return (int)((b0 + w * WAVE + l) & c.cmask);
         }
     }
     return -1;
@@ -289,7 +297,10 @@ __device__ bool table_insert(const Ctx &c, uint32_t lo, uint32_t hi, const RowIn
         c.hstat[slot] = HStat{ov, dl};
         c.hrank[slot] = rank;
         c.hidx[slot] = (uint8_t)(best & 0xFF);
-        if (rank) atomicMax(&c.ub[slot >> c.gs_log2], bound_word(rank, tie_word(lo, hi, (int)(best & 0xFF))));
+        if (rank) {
+            atomicMax(&c.ub[slot >> c.gs_log2], bound_word(rank, tie_word(lo, hi, (int)(best & 0xFF))));
+            c.gdirty[slot >> c.gs_log2] = 1;
+        }
         unsigned int live = atomicAdd(&c.g->n_live, 1u) + 1;
         atomicMax(&c.g->live_peak, live);
     }
@@ -301,7 +312,7 @@ template <class CntFn>
 __device__ void table_update(const Ctx &c, int slot, unsigned long long key, CntFn new_cnt) {
     int lane = lane_id();
     HStat st = c.hstat[slot];
-    uint32_t prev = c.hrank[slot];
+    uint32_t prev = c.hrank[slot], prev_idx = c.hidx[slot];
     unsigned long long best = 0;
     int alive = 0;
     for (int k = lane; k < c.K; k += WAVE) {
@@ -320,12 +331,14 @@ __device__ void table_update(const Ctx &c, int slot, unsigned long long key, Cnt
             c.hrank[slot] = 0;
             c.hkey[slot] = KEY_TOMB;
             atomicSub(&c.g->n_live, 1u);
+            if (prev) c.gdirty[slot >> c.gs_log2] = 1;
         } else {
-            uint32_t rank = (uint32_t)(best >> 8);
+            uint32_t rank = (uint32_t)(best >> 8), idx = (uint32_t)(best & 0xFF);
             if (rank != prev) c.hrank[slot] = rank;
-            c.hidx[slot] = (uint8_t)(best & 0xFF);
+            if (idx != prev_idx) c.hidx[slot] = (uint8_t)idx;
             if (rank > prev)
-                atomicMax(&c.ub[slot >> c.gs_log2], bound_word(rank, tie_word((uint32_t)key, (uint32_t)(key >> 32), (int)(best & 0xFF))));
+                atomicMax(&c.ub[slot >> c.gs_log2], bound_word(rank, tie_word((uint32_t)key, (uint32_t)(key >> 32), (int)idx)));
+            if (rank != prev || (rank && idx != prev_idx)) c.gdirty[slot >> c.gs_log2] = 1;
         }
     }
 }
@@ -338,6 +351,7 @@ __device__ __forceinline__ void table_update_pair(const Ctx &c, int slot0, unsig
     const bool h0 = slot0 >= 0, h1 = slot1 >= 0;
     HStat st0 = h0 ? c.hstat[slot0] : HStat{0, 0.0f}, st1 = h1 ? c.hstat[slot1] : HStat{0, 0.0f};
     uint32_t prev0 = h0 ? c.hrank[slot0] : 0u, prev1 = h1 ? c.hrank[slot1] : 0u;
+    uint32_t pidx0 = h0 ? c.hidx[slot0] : 0u, pidx1 = h1 ? c.hidx[slot1] : 0u;
     uint32_t o0[2] = {0, 0}, o1[2] = {0, 0};
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -381,12 +395,14 @@ __device__ __forceinline__ void table_update_pair(const Ctx &c, int slot0, unsig
                 c.hrank[slot0] = 0;
                 c.hkey[slot0] = KEY_TOMB;
                 atomicSub(&c.g->n_live, 1u);
+                if (prev0) c.gdirty[slot0 >> c.gs_log2] = 1;
             } else {
-                uint32_t rank = (uint32_t)(best0 >> 8);
+                uint32_t rank = (uint32_t)(best0 >> 8), idx = (uint32_t)(best0 & 0xFF);
                 if (rank != prev0) c.hrank[slot0] = rank;
-                c.hidx[slot0] = (uint8_t)(best0 & 0xFF);
+                if (idx != pidx0) c.hidx[slot0] = (uint8_t)idx;
                 if (rank > prev0)
-                    atomicMax(&c.ub[slot0 >> c.gs_log2], bound_word(rank, tie_word((uint32_t)key0, (uint32_t)(key0 >> 32), (int)(best0 & 0xFF))));
+                    atomicMax(&c.ub[slot0 >> c.gs_log2], bound_word(rank, tie_word((uint32_t)key0, (uint32_t)(key0 >> 32), (int)idx)));
+                if (rank != prev0 || (rank && idx != pidx0)) c.gdirty[slot0 >> c.gs_log2] = 1;
             }
         }
         if (h1) {
@@ -394,12 +410,14 @@ __device__ __forceinline__ void table_update_pair(const Ctx &c, int slot0, unsig
                 c.hrank[slot1] = 0;
                 c.hkey[slot1] = KEY_TOMB;
                 atomicSub(&c.g->n_live, 1u);
+                if (prev1) c.gdirty[slot1 >> c.gs_log2] = 1;
             } else {
-                uint32_t rank = (uint32_t)(best1 >> 8);
+                uint32_t rank = (uint32_t)(best1 >> 8), idx = (uint32_t)(best1 & 0xFF);
                 if (rank != prev1) c.hrank[slot1] = rank;
-                c.hidx[slot1] = (uint8_t)(best1 & 0xFF);
+                if (idx != pidx1) c.hidx[slot1] = (uint8_t)idx;
                 if (rank > prev1)
-                    atomicMax(&c.ub[slot1 >> c.gs_log2], bound_word(rank, tie_word((uint32_t)key1, (uint32_t)(key1 >> 32), (int)(best1 & 0xFF))));
+                    atomicMax(&c.ub[slot1 >> c.gs_log2], bound_word(rank, tie_word((uint32_t)key1, (uint32_t)(key1 >> 32), (int)idx)));
+                if (rank != prev1 || (rank && idx != pidx1)) c.gdirty[slot1 >> c.gs_log2] = 1;
             }
         }
     }
@@ -563,13 +581,13 @@ template <class Cell> __global__ void __launch_bounds__(SEL_THREADS) k_iter_sele
     // dynamic LDS carve: bound copy | verified flags | special-pair counters | per-matched-column scratch
     unsigned long long *s_ub = reinterpret_cast<unsigned long long *>(smem);          // [n_groups]
     uint8_t *s_seen = reinterpret_cast<uint8_t *>(s_ub + n_groups);                   // [n_groups] (padded to 8)
-    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_seen + ((n_groups + 7) & ~7));   // [6][Kpad]
+    uint16_t *s_work = reinterpret_cast<uint16_t *>(s_seen + ((n_groups + 7) & ~7));  // [n_groups] groups to inspect
+    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_work + ((n_groups + 3) & ~3));  // [6][Kpad]
     int *s_len = reinterpret_cast<int *>(s_cnt + 6 * Kpad);                           // [n_out + 1] list lengths -> offsets
     int *s_col = s_len + n_out + 1;                                                   // [n_out] matched columns
     constexpr int NW = SEL_THREADS / WAVE;
-    __shared__ unsigned long long s_prop_b[NW], s_q_tie[NW];
-    __shared__ int s_prop_g[NW];
-    __shared__ uint32_t s_q_rank[NW];
+    __shared__ unsigned long long s_red_tie[NW], s_floor0, s_floor;
+    __shared__ uint32_t s_red_rank[NW], s_nwork;
     __shared__ uint32_t s_best_rank;
     __shared__ unsigned long long s_best_tie;
     __shared__ int s_m, s_np, s_part[NW];
@@ -589,123 +607,138 @@ template <class Cell> __global__ void __launch_bounds__(SEL_THREADS) k_iter_sele
         return;
     }
 
-    // ---------------- (1) selection.  Bounds are cached in LDS.  Per round every wave proposes its highest unverified
-    // bound (groups g == wid mod NW), the four highest proposals are verified -- each by a quarter of the block, all
-    // four in flight together -- and the loop ends when no unverified bound can beat or tie the best verified entry.
+    // ---------------- (1) selection.  A group is CLEAN when no block in it changed its best (rank, key) since the
+    // group was last verified; then its bound word and stored tie word are exact.  The best clean bound is a lower
+    // bound of the answer, so only dirty groups whose (possibly stale) bound reaches it need to be re-read -- all of
+    // them in one parallel round, one wave per group.
     for (int q = tid; q < n_groups; q += SEL_THREADS) {
         s_ub[q] = c.ub[q];
-        s_seen[q] = 0;
+        s_seen[q] = c.gdirty[q];
     }
     if (tid == 0) {
         s_best_rank = 0;
         s_best_tie = 0;
         s_m = 0;
         s_np = 0;
+        s_nwork = 0;
+        s_floor0 = 0;
     }
     __syncthreads();
     tp[1] = clock64();
     {
-        constexpr int QT = SEL_THREADS / 4, QW = QT / WAVE;  // threads / waves per quarter
-        const int quarter = tid / QT, qtid = tid % QT, qwid = wid % QW;
+        // floor: the best bound among clean groups is attained by a real entry, so nothing below it can win
+        unsigned long long cl = 0;
+        for (int q = tid; q < n_groups; q += SEL_THREADS)
+            if (!s_seen[q]) cl = max(cl, s_ub[q]);
+        cl = wave_max_u64(cl);
+        if (lane == 0 && cl) atomicMax(&s_floor0, cl);
+        __syncthreads();
+        const unsigned long long floor0 = s_floor0;
+        if (tid == 0) s_floor = floor0;
+        __syncthreads();
+        // every wave owns the groups g == wid (mod NW): it re-reads its highest dirty bound while that bound can
+        // still beat or tie the (rising) floor
+        uint32_t wrank = 0;
+        unsigned long long wtie = 0;
         unsigned int rescans = 0;
+        unsigned long long *gtie_arr = g->gtie;
         while (true) {
             unsigned long long top = 0;
             int top_g = 0;
             for (int q = wid + lane * NW; q < n_groups; q += NW * WAVE) {
-                unsigned long long v = s_seen[q] ? 0ull : s_ub[q];
+                unsigned long long v = s_seen[q] == 1 ? s_ub[q] : 0ull;
                 if (v > top) {
                     top = v;
                     top_g = q;
                 }
             }
-            unsigned long long wtop = wave_max_u64(top);
-            unsigned long long who = __ballot(top == wtop);
-            int wg = __shfl(top_g, __ffsll((long long)who) - 1);
-            if (lane == 0) {
-                s_prop_b[wid] = wtop;
-                s_prop_g[wid] = wg;
-            }
-            __syncthreads();
-            // every thread ranks the NW proposals identically and keeps the four highest
-            unsigned long long cb[4] = {0, 0, 0, 0};
-            int cg[4] = {-1, -1, -1, -1};
-            for (int w = 0; w < NW; ++w) {
-                unsigned long long v = s_prop_b[w];
-                int gg = s_prop_g[w];
-                for (int t = 0; t < 4; ++t)
-                    if (v > cb[t]) {
-                        unsigned long long tv = cb[t];
-                        int tg = cg[t];
-                        cb[t] = v;
-                        cg[t] = gg;
-                        v = tv;
-                        gg = tg;
-                    }
-            }
-            const unsigned long long floor_now = s_best_rank ? bound_word(s_best_rank, s_best_tie) : 0ull;
-            if (cb[0] == 0 || cb[0] < floor_now) break;  // uniform: all threads see the same proposals
-            // verify candidate `quarter` with this quarter of the block
-            const unsigned long long my_b = cb[quarter];
-            const int my_g = cg[quarter];
-            const bool work = my_b != 0 && my_b >= floor_now;
+            const unsigned long long wtop = wave_max_u64(top);
+            if (wtop == 0 || wtop < *(volatile unsigned long long *)&s_floor) break;
+            const unsigned long long who = __ballot(top == wtop);
+            const uint32_t grp = (uint32_t)__shfl(top_g, __ffsll((long long)who) - 1);
+            const uint32_t base = grp * gs;
             uint32_t rk[8];
             uint32_t grank = 0;
-            const uint32_t base = work ? (uint32_t)my_g * gs : 0u;
-            if (work) {
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    int o = qtid + u * QT;
-                    rk[u] = o < gs ? c.hrank[base + o] : 0u;
-                    grank = max(grank, rk[u]);
-                }
+            for (int u = 0; u < 8; ++u) {
+                int o = lane + u * WAVE;
+                rk[u] = o < gs ? c.hrank[base + o] : 0u;
+                grank = max(grank, rk[u]);
             }
+            for (int o = lane + 8 * WAVE; o < gs; o += WAVE) grank = max(grank, c.hrank[base + o]);
             grank = wave_max_u32(grank);
-            if (lane == 0) s_q_rank[quarter * QW + qwid] = grank;
-            __syncthreads();
-            grank = 0;
-            for (int w = 0; w < QW; ++w) grank = max(grank, s_q_rank[quarter * QW + w]);
-            unsigned long long gtie = 0;
-            if (work && grank) {
+            unsigned long long gt = 0;
+            if (grank) {
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    int o = qtid + u * QT;
+                    int o = lane + u * WAVE;
                     if (o < gs && rk[u] == grank) {
                         unsigned long long kk = c.hkey[base + o];
                         unsigned long long tw = tie_word((uint32_t)kk, (uint32_t)(kk >> 32), c.hidx[base + o]);
-                        gtie = tw > gtie ? tw : gtie;
+                        gt = tw > gt ? tw : gt;
                     }
                 }
-            }
-            gtie = wave_max_u64(gtie);
-            if (lane == 0) s_q_tie[quarter * QW + qwid] = gtie;
-            __syncthreads();
-            if (tid == 0) {
-                uint32_t br = s_best_rank;
-                unsigned long long bt = s_best_tie;
-                for (int t = 0; t < 4; ++t) {
-                    if (cb[t] == 0 || cb[t] < floor_now) continue;
-                    uint32_t r = 0;
-                    unsigned long long tw = 0;
-                    for (int w = 0; w < QW; ++w) {
-                        r = max(r, s_q_rank[t * QW + w]);
-                        tw = s_q_tie[t * QW + w] > tw ? s_q_tie[t * QW + w] : tw;
+                for (int o = lane + 8 * WAVE; o < gs; o += WAVE)
+                    if (c.hrank[base + o] == grank) {
+                        unsigned long long kk = c.hkey[base + o];
+                        unsigned long long tw = tie_word((uint32_t)kk, (uint32_t)(kk >> 32), c.hidx[base + o]);
+                        gt = tw > gt ? tw : gt;
                     }
-                    unsigned long long exact = r ? bound_word(r, tw) : 0ull;
-                    s_ub[cg[t]] = exact;
-                    s_seen[cg[t]] = 1;
-                    c.ub[cg[t]] = exact;  // no writer races with this kernel: the bound is now tight
-                    if (r > br || (r == br && tw > bt)) {
-                        br = r;
-                        bt = tw;
-                    }
-                    ++rescans;
-                }
-                s_best_rank = br;
-                s_best_tie = bt;
+                gt = wave_max_u64(gt);
             }
-            __syncthreads();
+            const unsigned long long exact = grank ? bound_word(grank, gt) : 0ull;
+            if (lane == 0) {  // no writer races with this kernel: bound and tie are exact, the group is clean again
+                s_ub[grp] = exact;
+                s_seen[grp] = 2;
+                c.ub[grp] = exact;
+                gtie_arr[grp] = gt;
+                c.gdirty[grp] = 0;
+                if (exact) atomicMax(&s_floor, exact);
+            }
+            lds_fence();
+            if (grank > wrank || (grank == wrank && gt > wtie)) {
+                wrank = grank;
+                wtie = gt;
+            }
+            ++rescans;
         }
-        if (tid == 0 && rescans) g->st_rescans += rescans;
+        // groups that were clean on entry and tie the floor: their stored tie word decides
+        if (floor0) {
+            unsigned long long ct = 0;
+            bool any = false;
+            for (int q = wid + lane * NW; q < n_groups; q += NW * WAVE)
+                if (s_seen[q] == 0 && s_ub[q] == floor0) {
+                    unsigned long long t = gtie_arr[q];
+                    ct = t > ct ? t : ct;
+                    any = true;
+                }
+            ct = wave_max_u64(ct);
+            if (__any(any)) {
+                const uint32_t r0 = (uint32_t)(floor0 >> 32);
+                if (r0 > wrank || (r0 == wrank && ct > wtie)) {
+                    wrank = r0;
+                    wtie = ct;
+                }
+            }
+        }
+        if (lane == 0) {
+            s_red_rank[wid] = wrank;
+            s_red_tie[wid] = wtie;
+            if (rescans) atomicAdd(&g->st_rescans, (unsigned long long)rescans);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t br = 0;
+            unsigned long long bt = 0;
+            for (int w = 0; w < NW; ++w)
+                if (s_red_rank[w] > br || (s_red_rank[w] == br && s_red_tie[w] > bt)) {
+                    br = s_red_rank[w];
+                    bt = s_red_tie[w];
+                }
+            s_best_rank = br;
+            s_best_tie = bt;
+        }
+        __syncthreads();
     }
     tp[2] = clock64();
     const uint32_t best_rank = s_best_rank;
@@ -816,17 +849,31 @@ template <class Cell> __global__ void __launch_bounds__(SEL_THREADS) k_iter_sele
     {
         uint32_t *stamp = g->stamp, *plist = g->plist;
         const uint32_t tag = (uint32_t)iter + 1u;
-        for (int f = tid; f < total; f += SEL_THREADS) {
-            int lo = 0, hi = m;
-            while (hi - lo > 1) {
-                int mid = (lo + hi) >> 1;
-                if (s_len[mid] <= f)
-                    lo = mid;
-                else
-                    hi = mid;
+        for (int f0 = tid; f0 < total; f0 += 4 * SEL_THREADS) {
+            uint32_t r[4];
+            bool ok[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {  // four independent list reads in flight
+                const int f = f0 + u * SEL_THREADS;
+                ok[u] = f < total;
+                r[u] = 0;
+                if (ok[u]) {
+                    int lo = 0, hi = m;
+                    while (hi - lo > 1) {
+                        int mid = (lo + hi) >> 1;
+                        if (s_len[mid] <= f)
+                            lo = mid;
+                        else
+                            hi = mid;
+                    }
+                    r[u] = collist[(size_t)s_col[lo] * lcap + (f - s_len[lo])];
+                }
             }
-            uint32_t r = collist[(size_t)s_col[lo] * lcap + (f - s_len[lo])];
-            if (r != A && r != B && atomicExch(&stamp[r], tag) != tag) plist[atomicAdd(&s_np, 1)] = r;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) ok[u] = ok[u] && r[u] != A && r[u] != B && atomicExch(&stamp[r[u]], tag) != tag;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (ok[u]) plist[atomicAdd(&s_np, 1)] = r[u];
         }
     }
     tp[6] = clock64();
@@ -1151,6 +1198,8 @@ size_t carve_chain(unsigned char *base, const ChainJob &job, const Geometry &g, 
     d.hstat = c.take<HStat>(g.C);
     d.hcnt = c.take<uint16_t>((size_t)g.C * g.Kpad);
     d.ub = c.take<unsigned long long>(g.n_groups);
+    d.gtie = c.take<unsigned long long>(g.n_groups);
+    d.gdirty = c.take<uint8_t>(g.n_groups);
     d.mcol = c.take<int>(n_out);
     d.mA = c.take<unsigned char>(n_out * cell);
     d.mB = c.take<unsigned char>(n_out * cell);
@@ -1278,6 +1327,7 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
         HIP_CHECK(hipMemsetAsync(d.hkey, 0xFF, sizeof(unsigned long long) * (size_t)g.C, st));
         HIP_CHECK(hipMemsetAsync(d.hrank, 0, sizeof(uint32_t) * (size_t)g.C, st));
         HIP_CHECK(hipMemsetAsync(d.ub, 0, sizeof(unsigned long long) * (size_t)g.n_groups, st));
+        HIP_CHECK(hipMemsetAsync(d.gdirty, 1, (size_t)g.n_groups, st));
         // rows beyond n_in start with empty cells: new rows are fully written by k_iter_select
     }
     HIP_CHECK(hipMemcpyAsync(d_desc, desc.data(), sizeof(ChainDev) * (size_t)n, hipMemcpyHostToDevice, st));
@@ -1309,8 +1359,8 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
     long long max_pairs[2] = {0, 0};
     for (int i = 0; i < n; ++i) {
         int w = geo[i].wide;
-        size_t s = (size_t)geo[i].n_groups * 8 + (((size_t)geo[i].n_groups + 7) & ~(size_t)7) + 6 * (size_t)geo[i].Kpad * 4 +
-                   (2 * (size_t)jobs[i].n_out + 1) * 4;
+        size_t s = (size_t)geo[i].n_groups * 8 + (((size_t)geo[i].n_groups + 7) & ~(size_t)7) + (((size_t)geo[i].n_groups + 3) & ~(size_t)3) * 2 +
+                   6 * (size_t)geo[i].Kpad * 4 + (2 * (size_t)jobs[i].n_out + 1) * 4;
         s = align_up(s, 16);
         sel_lds[w] = std::max(sel_lds[w], s);
         upd_lds[w] = std::max(upd_lds[w], align_up((size_t)UPD_WAVES * 3 * geo[i].Kpad * 4 + (((size_t)jobs[i].n_out + 1) & ~(size_t)1) * 4 + 2 * (size_t)jobs[i].n_out * (geo[i].wide ? 8 : 4), 16));
