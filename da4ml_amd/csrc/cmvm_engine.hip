@@ -587,7 +587,7 @@ template <class Cell> __global__ void __launch_bounds__(SEL_THREADS) k_iter_sele
     int *s_col = s_len + n_out + 1;                                                   // [n_out] matched columns
     constexpr int NW = SEL_THREADS / WAVE;
     __shared__ unsigned long long s_red_tie[NW], s_floor0, s_floor;
-    __shared__ uint32_t s_red_rank[NW], s_nwork;
+    __shared__ uint32_t s_red_rank[NW];
     __shared__ uint32_t s_best_rank;
     __shared__ unsigned long long s_best_tie;
     __shared__ int s_m, s_np, s_part[NW];
@@ -620,7 +620,6 @@ template <class Cell> __global__ void __launch_bounds__(SEL_THREADS) k_iter_sele
         s_best_tie = 0;
         s_m = 0;
         s_np = 0;
-        s_nwork = 0;
         s_floor0 = 0;
     }
     __syncthreads();
@@ -1137,10 +1136,11 @@ uint32_t pow2_ceil(uint64_t v) {
 struct HipBackend::Impl {
     int device = 0;
     hipStream_t stream = nullptr;
-    static constexpr int MAX_LANES = 4;
-    hipStream_t lanes[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};  // greedy-loop streams of the chain groups
-    int n_lanes = 2;
+    static constexpr int MAX_LANES = 8;
+    hipStream_t lanes[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // greedy-loop streams of the chain groups
+    int n_lanes = 3;
     bool use_graph = false;
+    int upd_total_blocks = 2048;  // k_iter_update blocks over all chains of a batch (4 waves each)
     bool mt_launch = false;
     DeviceBuffer arena, desc_buf, io_buf;
     unsigned int *d_done = nullptr;
@@ -1153,7 +1153,11 @@ HipBackend::HipBackend(int device) : impl_(new Impl) {
     impl_->device = device;
     HIP_CHECK(hipSetDevice(device));
     HIP_CHECK(hipStreamCreateWithFlags(&impl_->stream, hipStreamNonBlocking));
-    for (auto &l : impl_->lanes) HIP_CHECK(hipStreamCreateWithFlags(&l, hipStreamNonBlocking));
+    impl_->lanes[0] = impl_->stream;  // the first group runs on the main stream (hardware queues are a scarce resource)
+    for (int l = 1; l < Impl::MAX_LANES; ++l) HIP_CHECK(hipStreamCreateWithFlags(&impl_->lanes[l], hipStreamNonBlocking));
+    if (const char *e = std::getenv("DA4ML_HIP_TABLE_SCALE")) impl_->table_scale = std::max(1e-4, std::atof(e));
+    if (const char *e = std::getenv("DA4ML_HIP_ROW_SCALE")) row_scale_ = std::max(1e-4, std::atof(e));
+    if (const char *e = std::getenv("DA4ML_HIP_UPD_BLOCKS")) impl_->upd_total_blocks = std::max(64, std::atoi(e));
     if (const char *e = std::getenv("DA4ML_HIP_MT")) impl_->mt_launch = std::atoi(e) != 0;
     if (const char *e = std::getenv("DA4ML_HIP_GRAPH")) impl_->use_graph = std::atoi(e) != 0;
     if (const char *e = std::getenv("DA4ML_HIP_LANES")) impl_->n_lanes = std::max(1, std::min((int)Impl::MAX_LANES, std::atoi(e)));
@@ -1167,8 +1171,8 @@ HipBackend::~HipBackend() {
     if (impl_->d_done) (void)hipFree(impl_->d_done);
     if (impl_->h_done) (void)hipHostFree(impl_->h_done);
     if (impl_->stream) (void)hipStreamDestroy(impl_->stream);
-    for (auto &l : impl_->lanes)
-        if (l) (void)hipStreamDestroy(l);
+    for (int l = 1; l < Impl::MAX_LANES; ++l)
+        if (impl_->lanes[l]) (void)hipStreamDestroy(impl_->lanes[l]);
 }
 const GpuTimings &HipBackend::timings() const { return impl_->timings; }
 void HipBackend::reset_timings() { impl_->timings = GpuTimings{}; }
@@ -1371,7 +1375,7 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
         int cnt = ranges[w].count;
         if (cnt == 0) continue;
         // keep the whole chip busy: ~4 blocks per CU in total, at least 2 and at most 32 per chain
-        upd_blocks[w] = std::max(2, std::min(64, (2048 + cnt - 1) / std::max(cnt, 1)));
+        upd_blocks[w] = std::max(2, std::min(64, (im.upd_total_blocks + cnt - 1) / std::max(cnt, 1)));
     }
     for (int w = 0; w < 2; ++w) {
         const Range &r = ranges[w];
@@ -1569,6 +1573,7 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
     if (need_retry && retry_depth_ < 4) {
         // some chain outgrew its arena: rerun the whole group with larger capacities (rare; sizes are heuristics)
         ++retry_depth_;
+        im.timings.retries += 1;
         double keep_t = im.table_scale, keep_r = row_scale_;
         im.table_scale *= 4.0;
         row_scale_ *= 4.0;

@@ -90,3 +90,63 @@ def test_errors(hip):
         hip.solve(int_matrix(0, 8, 8, -8, 8), method0='nope', search_all_decompose_dc=False)
     with pytest.raises(ValueError):
         hip.solve(np.eye(3, dtype=np.float32), qintervals=[(-1.0, 1.0, 0.3)] * 3)
+
+
+def test_capacity_retry(oracle):
+    """arena heuristics far too small -> the chain reports a capacity error and is rerun with larger arenas"""
+    import os
+    import subprocess
+    import sys
+
+    code = (
+        "import sys; sys.path.insert(0, '.'); sys.path.insert(0, 'tests')\n"
+        "from cases import int_matrix\nfrom da4ml_amd import _binary as hip\nimport json\n"
+        "k = int_matrix(0, 48, 48, -128, 128)\n"
+        "p = hip.solve(k, method0='wmc', method1='wmc', decompose_dc=-1, search_all_decompose_dc=False)\n"
+        "print(json.dumps({'cost': p.cost, 'n_ops': [len(s.ops) for s in p.solutions], 'retries': hip.timings()['retries']}))\n"
+    )
+    env = dict(os.environ, DA4ML_HIP_TABLE_SCALE='0.02', DA4ML_HIP_ROW_SCALE='0.05')
+    out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, cwd=str(__import__('pathlib').Path(__file__).resolve().parent.parent))
+    assert out.returncode == 0, out.stderr
+    import json
+
+    r = json.loads(out.stdout.strip().splitlines()[-1])
+    want = oracle.solve(int_matrix(0, 48, 48, -128, 128), method0='wmc', method1='wmc', decompose_dc=-1, search_all_decompose_dc=False)
+    assert r['retries'] >= 1
+    assert r['cost'] == want.cost and r['n_ops'] == [len(s.ops) for s in want.solutions]
+
+
+def test_c3_256x256_seed0_against_oracle_record(hip):
+    """BASELINE C3 matrix: digest of the full GPU result against the record of the 65-minute CPU oracle run"""
+    import hashlib
+    import json
+    from pathlib import Path
+
+    path = Path(__file__).parent / 'golden' / 'large_chain_golden.json'
+    gold = json.loads(path.read_text()) if path.exists() else {}
+    for n in (128, 256):
+        rec = gold.get(f'{n}x{n}_seed0_single_chain')
+        if rec is None:
+            continue
+        p = hip.solve(int_matrix(0, n, n, -128, 128), **rec['opts'])
+        dump = json.loads(json.dumps(p, default=lambda o: o.to_dict()))
+        assert p.cost == rec['cost'] and [len(s.ops) for s in p.solutions] == rec['n_ops']
+        assert hashlib.sha256(json.dumps(dump, separators=(',', ':')).encode()).hexdigest() == rec['sha256']
+
+
+def test_default_search_96(hip, oracle):
+    """full default solve (all decompose_dc candidates, both stages) on a 96x96 int8 matrix"""
+    k = int_matrix(5, 96, 96, -128, 128)
+    got = hip.solve(k)
+    assert got == oracle.solve(k)
+    assert np.all(got.kernel == k)
+
+
+def test_default_search_256_functional(hip):
+    """BASELINE C3 (i): default solve of the 256x256 int8 matrix; the CPU oracle needs hours for this one, so the check is
+    the reference's own functional criterion (tests/test_cmvm.py:55) plus agreement of two runs"""
+    k = int_matrix(0, 256, 256, -128, 128)
+    a = hip.solve(k)
+    assert np.all(a.kernel == k)
+    b = hip.solve_many([k, k])
+    assert b[0] == a and b[1] == a
