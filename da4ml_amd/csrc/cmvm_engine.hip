@@ -144,7 +144,14 @@ __device__ __forceinline__ long long wave_sum_i64(long long v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
 }
-__device__ __forceinline__ void lds_fence() { __threadfence_block(); }
+// Make this wave's LDS traffic visible to its own lanes: wait for outstanding LDS operations only (lgkmcnt(0));
+// global loads stay in flight.  LDS operations of one wave complete in order, so no wider fence is needed for the
+// per-wave counters; the wave barriers stop the compiler from moving LDS accesses across.
+__device__ __forceinline__ void lds_fence() {
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+}
 
 __device__ __forceinline__ uint32_t hash_pair(uint32_t lo, uint32_t hi) {
     unsigned long long k = ((unsigned long long)hi << 32) | lo;
@@ -952,21 +959,59 @@ template <class Cell> __global__ void __launch_bounds__(UPD_THREADS) k_iter_upda
     uint32_t *dA = s_cnt + (size_t)wid * 3 * Kpad, *dB = dA + Kpad, *cN = dB + Kpad;
     unsigned int partners = 0, found = 0, inserts = 0;
     long long up[5] = {0, 0, 0, 0, 0}, u0 = clock64(), u1;
-    // static striding over the partner list (no work counter: partners cost about the same), next entry prefetched
+    // static striding over the partner list (no work counter: partners cost about the same).  Software pipeline: the
+    // cell and probe loads of the NEXT partner are issued before the current partner's blocks are read, so the two
+    // dependent memory round-trips of consecutive partners overlap.
     const int total_waves = (int)gridDim.x * UPD_WAVES;
     const int first = (int)blockIdx.x * UPD_WAVES + wid;
-    uint32_t pr_next = first < n_partners ? plist[first] : 0u;
+    const bool second = lane >= (int)BUCKET;
+    const bool probing = lane < (int)BUCKET || (!same && lane < 2 * (int)BUCKET);
+    auto issue = [&](uint32_t row, Cell &x0, unsigned long long &kk) {
+        x0 = lane < m ? cells[(size_t)row * n_out + s_col[lane]] : (Cell)0;
+        const uint32_t other = second ? B : A;
+        const uint32_t h = hash_pair(min(other, row), max(other, row));
+        kk = probing ? c.hkey[((h & ~(BUCKET - 1)) & c.cmask) + (lane & (BUCKET - 1))] : KEY_TOMB;
+    };
+    uint32_t pr = 0, pr_next = 0;
+    Cell x0 = 0;
+    unsigned long long kk = KEY_TOMB;
+    if (first < n_partners) {
+        pr = plist[first];
+        issue(pr, x0, kk);
+        if (first + total_waves < n_partners) pr_next = plist[first + total_waves];
+    }
     for (int q = first; q < n_partners; q += total_waves) {
-        const uint32_t pr = pr_next;
-        if (q + total_waves < n_partners) pr_next = plist[q + total_waves];
+        // next partner: loads in flight during this partner's processing
+        const bool has_next = q + total_waves < n_partners;
+        const uint32_t prn = pr_next;
+        Cell x0n = 0;
+        unsigned long long kkn = KEY_TOMB;
+        if (has_next) {
+            if (q + 2 * total_waves < n_partners) pr_next = plist[q + 2 * total_waves];
+            issue(prn, x0n, kkn);
+        }
         ++partners;
-        // independent loads first: the partner's cells in the first 64 substituted columns and both table probes
         const Cell *rowR = cells + (size_t)pr * n_out;
-        const Cell x0 = lane < m ? rowR[s_col[lane]] : (Cell)0;
         const uint32_t lA = min(A, pr), hA = max(A, pr), lB = min(B, pr), hB = max(B, pr);
         const unsigned long long keyA = pack_pair(lA, hA), keyB = pack_pair(lB, hB);
-        int slotA, slotB;
-        table_find2(c, keyA, hash_pair(lA, hA), keyB, hash_pair(lB, hB), !same, slotA, slotB);
+        // resolve the two first-bucket probes (lanes 0-15: block with A, lanes 16-31: block with B)
+        int slotA = -1, slotB = -1;
+        {
+            const unsigned long long want = second ? keyB : keyA;
+            const unsigned long long hit = __ballot(probing && kk == want), emp = __ballot(probing && kk == KEY_EMPTY);
+            const unsigned long long m0 = 0xFFFFull, m1 = 0xFFFF0000ull;
+            const uint32_t hhA = hash_pair(lA, hA), hhB = hash_pair(lB, hB);
+            if (hit & m0)
+                slotA = (int)(((hhA & ~(BUCKET - 1)) & c.cmask) + (__ffsll((long long)(hit & m0)) - 1));
+            else if (!(emp & m0))
+                slotA = table_find_from(c, keyA, hhA, 1);
+            if (!same) {
+                if (hit & m1)
+                    slotB = (int)(((hhB & ~(BUCKET - 1)) & c.cmask) + (__ffsll((long long)(hit & m1)) - 1 - (int)BUCKET));
+                else if (!(emp & m1))
+                    slotB = table_find_from(c, keyB, hhB, 1);
+            }
+        }
         u1 = clock64();
         up[1] += u1 - u0;  // list entry + two table probes
         u0 = u1;
@@ -1000,6 +1045,9 @@ template <class Cell> __global__ void __launch_bounds__(UPD_THREADS) k_iter_upda
         u1 = clock64();
         up[4] += u1 - u0;  // block creation
         u0 = u1;
+        pr = prn;
+        x0 = x0n;
+        kk = kkn;
     }
     if (lane == 0)
         for (int q = 0; q < 5; ++q) atomicAdd(&g->st_phase[7 + q], (unsigned long long)up[q]);
