@@ -363,7 +363,7 @@ struct ProblemState {
     const Problem *p = nullptr;
     std::vector<QInt> qints;
     std::vector<float> lats;
-    Stage1 s1;
+    std::shared_ptr<Stage1> s1p;  // shared by the problems of a batch that have the same matrix (the tracer's row loop)
     bool minlat_known = false;
     float minlat = 0.0f;
     std::vector<int> cand;  // indices into the candidate array
@@ -388,7 +388,16 @@ std::vector<PipeResult> solve_batch(Backend &be, const std::vector<Problem> &pro
         s.lats = p.opt.lats.empty() ? std::vector<float>(p.n_in, 0.0f) : p.opt.lats;
         if ((int)s.qints.size() != p.n_in || (int)s.lats.size() != p.n_in)
             throw std::invalid_argument("qintervals / latencies must have one entry per kernel row");
-        stage1_prepare(s.s1, p.kernel, p.n_in, p.n_out);
+        for (size_t j = 0; j < i && !s.s1p; ++j) {
+            const Problem &o = problems[j];
+            if (o.n_in == p.n_in && o.n_out == p.n_out &&
+                (o.kernel == p.kernel || std::memcmp(o.kernel, p.kernel, sizeof(float) * (size_t)p.n_in * p.n_out) == 0))
+                s.s1p = ps[j].s1p;
+        }
+        if (!s.s1p) {
+            s.s1p = std::make_shared<Stage1>();
+            stage1_prepare(*s.s1p, p.kernel, p.n_in, p.n_out);
+        }
         int log2_n = (int)std::ceil(std::log2((float)p.n_in));
         std::vector<std::pair<int, int>> tries;  // (hard_dc, decompose_dc)
         if (!p.opt.search_all)
@@ -415,7 +424,7 @@ std::vector<PipeResult> solve_batch(Backend &be, const std::vector<Problem> &pro
     auto prepare_stage0 = [&](Candidate &c) {
         ProblemState &s = ps[c.problem];
         if (c.decompose_dc < 0 && c.hard_dc >= 0) c.method0 = c.method1 = (c.method0 != "dummy") ? "wmc-dc" : "dummy";
-        stage1_split(be, s.s1, c.decompose_dc, c.m0, c.m1);
+        stage1_split(be, *s.s1p, c.decompose_dc, c.m0, c.m1);
     };
 
     struct Pending {
@@ -438,7 +447,7 @@ std::vector<PipeResult> solve_batch(Backend &be, const std::vector<Problem> &pro
                 if (!ready) continue;
                 todo.push_back(ci);
                 int ddc = c.decompose_dc;
-                if (ddc != -1) stage1_distances(be, s.s1);
+                if (ddc != -1) stage1_distances(be, *s.s1p);
             }
             parallel_for(todo.size(), [&](size_t k) {
                 Candidate &c = cands[todo[k]];

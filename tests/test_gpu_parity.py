@@ -150,3 +150,37 @@ def test_default_search_256_functional(hip):
     assert np.all(a.kernel == k)
     b = hip.solve_many([k, k])
     assert b[0] == a and b[1] == a
+
+
+C5_LAYERS = [(16, 64), (64, 64), (64, 64), (64, 32), (32, 8)]  # synthetic stand-in for a JEDI-linear style model (BASELINE C5)
+
+
+def test_c5_model_batch(hip, oracle):
+    """all layers of a (synthetic) model solved concurrently, tracer-default cost model; every layer equals the oracle"""
+    ks = [int_matrix(10 + i, a, b, -128, 128) for i, (a, b) in enumerate(C5_LAYERS)]
+    got = hip.solve_many(ks, adder_size=1, carry_size=-1)
+    for k, g in zip(ks, got):
+        assert g == oracle.solve(k, adder_size=1, carry_size=-1)
+        assert np.all(g.kernel == k)
+
+
+def test_same_matrix_different_intervals(hip, oracle):
+    """the tracer's row loop (reference trace/fixed_variable_array.py:368-371): one matrix, per-row-vector intervals/latencies"""
+    k = int_matrix(21, 24, 16, -64, 64)
+    rng = np.random.default_rng(3)
+    qs, ls = [], []
+    for _ in range(4):
+        lo = rng.integers(-64, 1, 24)
+        hi = lo + rng.integers(1, 200, 24)
+        st = 2.0 ** rng.integers(-3, 2, 24)
+        qs.append([(float(a * s), float(b * s), float(s)) for a, b, s in zip(lo, hi, st)])
+        ls.append([float(v) for v in rng.integers(0, 3, 24)])
+    got = hip.solve_many([k] * 4, qintervals=qs, latencies=ls, adder_size=1, carry_size=-1)
+    for q, l, g in zip(qs, ls, got):
+        assert g == oracle.solve(k, qintervals=q, latencies=l, adder_size=1, carry_size=-1)
+
+
+@pytest.mark.parametrize('shape', [(3, 200), (200, 3), (1, 1), (130, 70)])
+def test_ragged_shapes(hip, oracle, shape):
+    k = int_matrix(shape[0] * 7 + shape[1], shape[0], shape[1], -32, 32)
+    assert hip.solve(k) == oracle.solve(k)
