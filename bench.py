@@ -43,10 +43,13 @@ def make_batch(n_in, n_out, batch, first_seed):
 def cpu_baseline(n_in, n_out, opts, budget_s):
     """Oracle (restated reference, single thread) on a bounded sample: state + pair-table creation and the first greedy
     iterations of the seed-0 chain, scaled to a full chain with the calibration recorded in tests/golden/."""
-    from oracle.oracle import Oracle, sample_chain
+    from oracle.oracle import HERE, Oracle, sample_chain
 
+    # the reference's own sources (built against the container shim, oracle/README.md) when the prebuilt library travelled
+    # with the snapshot, else the restated port (same algorithm, op-for-op identical results)
+    kind = 'reference' if (HERE / '_ref' / 'libref.so').exists() else 'port'
     k = make_batch(n_in, n_out, 1, 0)[0]
-    s = sample_chain(Oracle('port'), k, opts.get('method0', 'wmc'), budget_s)
+    s = sample_chain(Oracle('ref' if kind == 'reference' else 'port'), k, opts.get('method0', 'wmc'), budget_s)
     cal_path = ROOT / 'tests' / 'golden' / 'cpu_calibration.json'
     cal = json.loads(cal_path.read_text()) if cal_path.exists() else {}
     key = f'{n_in}x{n_out}'
@@ -66,7 +69,7 @@ def cpu_baseline(n_in, n_out, opts, budget_s):
     else:
         total = float('nan')
         sample += '; no calibration available to scale to a full chain'
-    return {'value': (1.0 / total) if total == total else None, 'unit': 'solves/s', 'cores': 1, 'kind': 'port', 'sample': sample,
+    return {'value': (1.0 / total) if total == total else None, 'unit': 'solves/s', 'cores': 1, 'kind': kind, 'sample': sample,
             'est_seconds_per_solve': total if total == total else None}  # fmt: skip
 
 

@@ -1350,7 +1350,7 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
         g.C = pow2_ceil((uint64_t)want);
         g.gs_log2 = 8;
         while ((g.C >> g.gs_log2) > (uint32_t)MAX_GROUPS) ++g.gs_log2;
-        if (g.gs_log2 > 11) throw std::runtime_error("pair table larger than 8M slots is not supported yet");
+        if (g.gs_log2 > 14) throw std::runtime_error("pair table larger than 64M slots is not supported");
         if (g.C < 256) g.C = 256;
         g.n_groups = (int)(g.C >> g.gs_log2);
         ChainDev tmp;

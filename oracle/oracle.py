@@ -62,11 +62,13 @@ class Oracle:
         g('stage_info').argtypes = [C.c_void_p, C.c_int, _i64p]
         g('stage_copy').argtypes = [C.c_void_p, C.c_int, _i64p, _i64p, _i64p, _i64p, _i64p, _f32p]
         g('free').argtypes = [C.c_void_p]
+        if kind in ('port', 'ref'):
+            g('sample_chain').argtypes = [_f32p, C.c_int64, C.c_int64, C.c_char_p, C.c_double, np.ctypeslib.ndpointer(np.float64)]
         if kind == 'port':
             g('solve_single').restype = C.c_void_p
             g('solve_single').argtypes = [_f32p, C.c_int64, C.c_int64, C.c_char_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
             g('stage_stats').argtypes = [C.c_void_p, C.c_int, _i64p]
-            g('sample_chain').argtypes = [_f32p, C.c_int64, C.c_int64, C.c_char_p, C.c_double, np.ctypeslib.ndpointer(np.float64)]
+
         self.g = g
 
     # ---- scalar helpers -------------------------------------------------

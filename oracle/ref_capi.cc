@@ -7,6 +7,7 @@
 #include "mat_decompose.hh"
 #include "state_opr.hh"
 
+#include <chrono>
 #include <cstring>
 #include <string>
 
@@ -69,6 +70,40 @@ void *ref_solve(const float *kernel, int64_t n_in, int64_t n_out, const char *me
         return nullptr;
     }
 }
+// Bounded CPU timing sample with the reference's own functions (create_state, idx_*, update_state): state + pair
+// table creation, then greedy iterations until `budget_s` seconds are spent.  Same contract as orc_sample_chain.
+int ref_sample_chain(const float *kernel, int64_t n_in, int64_t n_out, const char *method, double budget_s, double *out) {
+    try {
+        std::vector<QInterval> q(n_in, QInterval{-128.0f, 127.0f, 1.0f});
+        std::vector<float> l(n_in, 0.0f);
+        std::string m(method);
+        auto t0 = std::chrono::steady_clock::now();
+        DAState s = create_state(as_kernel(kernel, n_in, n_out), q, l);
+        auto t1 = std::chrono::steady_clock::now();
+        out[0] = std::chrono::duration<double>(t1 - t0).count();
+        out[1] = out[2] = out[3] = 0;
+        while (true) {
+            if (s.freq_stat.empty()) {
+                out[3] = 1;
+                break;
+            }
+            Pair pick = m == "mc" ? idx_mc(s) : m == "wmc" ? idx_wmc(s) : m == "wmc-dc" ? idx_wmc_dc(s, true) : idx_mc_dc(s, true);
+            if (pick.id0 == -1 || pick.id1 == -1) {
+                out[3] = 1;
+                break;
+            }
+            update_state(s, pick, -1, -1);
+            out[1] += 1;
+            out[2] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
+            if (out[2] >= budget_s) break;
+        }
+        return 0;
+    } catch (const std::exception &e) {
+        g_err = e.what();
+        return -1;
+    }
+}
+
 int ref_n_stages(void *h) { return (int)((RefResult *)h)->pipe.solutions.size(); }
 int ref_picked(void *) { return -1; }
 void ref_stage_info(void *h, int s, int64_t *info) {
