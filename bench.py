@@ -36,6 +36,23 @@ WORKLOADS = {
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
+def pmc_traffic_per_chain():
+    """HBM bytes per chain and k_iter_update launch from the committed rocprofv3 PMC passes (profiles/rNN_pmc_FETCH_SIZE.txt,
+    ..._WRITE_SIZE.txt; collected with --batch 16, i.e. 8 chains per launch; KiB units, uncorrected).  None if absent."""
+    import re
+
+    total = 0.0
+    for name in ('FETCH_SIZE', 'WRITE_SIZE'):
+        files = sorted((ROOT / 'profiles').glob(f'r*_pmc_{name}.txt'))
+        if not files:
+            return None
+        m = re.search(r'k_iter_update.*?per_dispatch=([0-9.eE+-]+)', files[-1].read_text(), re.S)
+        if not m:
+            return None
+        total += float(m.group(1)) * 1024.0
+    return total / 8.0
+
+
 def make_batch(n_in, n_out, batch, first_seed):
     return [np.random.default_rng(first_seed + i).integers(-128, 128, (n_in, n_out)).astype(np.float32) for i in range(batch)]
 
@@ -130,16 +147,22 @@ def main():
 
     if rank != 0:
         return
-    launches = max(tm['lockstep_iters'], 1.0)
-    upd_avg_us = 1e3 * tm['update_ms_sampled'] / max(tm['samples'], 1.0)
-    sel_avg_us = 1e3 * tm['select_ms_sampled'] / max(tm['samples'], 1.0)
+    samples = max(tm['samples'], 1.0)
+    upd_avg_us = 1e3 * tm['update_ms_sampled'] / samples
+    sel_avg_us = 1e3 * tm['select_ms_sampled'] / samples
+    chains_per_launch = tm['sampled_chain_launches'] / samples  # the batch runs as a few chain groups on separate streams
     # algorithmic bytes of k_iter_update: per partner row its cells in the substituted columns
     # and two 8-byte pair keys; per touched count block its interval record, rank and K u16 counts read + written;
-    # per created block key + record + rank + index + K counts + the partner's interval
+    # per created block key + record + rank + index + K counts + the partner's interval.  Counted on the device,
+    # summed over all chains and iterations; one launch covers `chains_per_launch` chains for one iteration.
     K = 2 * (2 * 8 - 1)
     alg_bytes = tm['cell_bytes'] + 16.0 * tm['partners'] + tm['found'] * (12.0 + 4.0 * K) + tm['inserts'] * (37.0 + 2.0 * K)
-    alg_per_launch = alg_bytes / launches
+    alg_per_chain_iter = alg_bytes / max(tm['iterations'], 1.0)
+    alg_per_launch = alg_per_chain_iter * chains_per_launch
     achieved = alg_per_launch / (upd_avg_us * 1e-6) / 1e9 if upd_avg_us > 0 else 0.0
+    per_chain = pmc_traffic_per_chain()
+    traffic = per_chain * chains_per_launch if per_chain else None
+    launches = tm['lockstep_iters'] * max(1.0, round(batch / max(chains_per_launch, 1.0)))
     line = {
         'metric': 'CMVM solves/sec, 256x256 int8 matrix' if n_in == 256 else f'CMVM solves/sec, {n_in}x{n_out} int8 matrix',
         'value': total_solves / elapsed,
@@ -156,7 +179,8 @@ def main():
         'config': {'workload': args.workload, 'matrix': f'{n_in}x{n_out} int8 (default_rng(seed).integers(-128,128))', 'batch_per_gpu': batch,
                    'solve_options': opts, 'parallelism': f'{world} x independent-instance shard, no data-path collective'},  # fmt: skip
         'roofline': {'kernel': 'k_iter_update', 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                     'traffic': None, 'alg_bytes_per_launch': alg_per_launch, 'avg_launch_us': upd_avg_us, 'launches': launches,
+                     'traffic': traffic, 'traffic_source': 'profiles/ PMC passes (FETCH_SIZE + WRITE_SIZE per chain) x chains per launch' if traffic else None,
+                     'alg_bytes_per_launch': alg_per_launch, 'chains_per_launch': chains_per_launch, 'avg_launch_us': upd_avg_us, 'launches': launches,
                      'select_avg_launch_us': sel_avg_us, 'note': 'latency-bound random access into an HBM/L2-resident pair table; see DESIGN.md section 5'},  # fmt: skip
         'engine': {'greedy_loop_ms_per_step': tm['loop_ms'] / args.steps, 'library_ms_per_step': tm['total_ms'] / args.steps,
                    'greedy_iterations_per_step': tm['iterations'] / args.steps, 'lockstep_iterations_per_step': tm['lockstep_iters'] / args.steps,

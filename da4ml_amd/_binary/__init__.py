@@ -300,14 +300,14 @@ def solve_many_raw(kernels, method0='wmc', method1='auto', hard_dc=-1, decompose
 
 def timings(reset: bool = False) -> dict:
     """Accumulated device-side timings / counters of the greedy loops (benchmark instrumentation)."""
-    t = np.zeros(31, np.float64)
+    t = np.zeros(32, np.float64)
     rc = lib().da_timings(t, int(reset))
     if rc != 0:
         _raise(rc)
     names = ('loop_ms', 'dist_ms', 'total_ms', 'lockstep_iters', 'iterations', 'rescans', 'partners', 'chains', 'table_bytes', 'arena_bytes',
              'select_ms_sampled', 'update_ms_sampled', 'samples', 'found', 'inserts', 'cell_reads', 'block_bytes', 'cell_bytes',
              'sel_load_bounds', 'sel_argmax', 'sel_newrow', 'sel_substitute', 'sel_prefix', 'sel_claims', 'sel_special',
-             'upd_fetch', 'upd_probe', 'upd_cells', 'upd_blocks', 'upd_create', 'retries')
+             'upd_fetch', 'upd_probe', 'upd_cells', 'upd_blocks', 'upd_create', 'retries', 'sampled_chain_launches')
     return dict(zip(names, t.tolist()))
 
 

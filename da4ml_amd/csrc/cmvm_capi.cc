@@ -202,12 +202,13 @@ int da_timings(double *t, int reset) {
     try {
         da::gpu::HipBackend &be = backend();
         const da::gpu::GpuTimings &g = be.timings();
-        double v[31] = {g.loop_ms,          g.dist_ms,         g.total_ms,         (double)g.lockstep_iters, (double)g.iterations,
+        double v[32] = {g.loop_ms,          g.dist_ms,         g.total_ms,         (double)g.lockstep_iters, (double)g.iterations,
                         (double)g.rescans, (double)g.partners, (double)g.chains, g.table_bytes,            g.arena_bytes,
                         g.select_ms_sampled, g.update_ms_sampled, (double)g.samples, (double)g.found, (double)g.inserts,
                         (double)g.cell_reads, g.key_bytes, g.cell_bytes};
         for (int q = 0; q < 12; ++q) v[18 + q] = g.phase_cycles[q];
         v[30] = (double)g.retries;
+        v[31] = g.sampled_chain_launches;
         std::memcpy(t, v, sizeof v);
         if (reset) be.reset_timings();
         return DA_OK;

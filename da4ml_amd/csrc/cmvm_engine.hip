@@ -1603,6 +1603,7 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
         im.timings.update_ms_sampled += b;
     }
     im.timings.samples += n_samples;
+    im.timings.sampled_chain_launches += (double)n_samples * (groups.empty() ? 0 : groups[0].count);
     for (hipEvent_t e : sample_ev) (void)hipEventDestroy(e);
     (void)hipEventDestroy(ev0);
     (void)hipEventDestroy(ev1);

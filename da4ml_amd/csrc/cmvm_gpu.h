@@ -23,6 +23,7 @@ struct GpuTimings {  // accumulated since the last reset; read by the benchmark 
     // sampled per-kernel durations (HIP events around every 16th lockstep iteration)
     double select_ms_sampled = 0, update_ms_sampled = 0;
     long long samples = 0;
+    double sampled_chain_launches = 0;  // sum over sampled launches of the number of chains in that launch
     // algorithmic-traffic counters of k_iter_update, summed over chains
     long long found = 0, inserts = 0, cell_reads = 0;
     double key_bytes = 0;     // 2 * K bytes per touched count block (u16 counts)

@@ -85,7 +85,7 @@ int da_result_stats(const da_result *r, int64_t *stats);
 void da_free(da_result *r);
 
 /* ---- instrumentation for the benchmark harness ------------------------------------------------------------- */
-/* t[30] = capacity retries; t[18..29] = shader-clock cycles per kernel phase (7 of k_iter_select, 5 of k_iter_update);
+/* t[31] = chains summed over the sampled launches; t[30] = capacity retries; t[18..29] = shader-clock cycles per kernel phase (7 of k_iter_select, 5 of k_iter_update);
  * t[0..17] = loop_ms (HIP events around the greedy-loop launches), dist_ms, total_ms, lockstep iterations,
  * greedy iterations, table groups re-read, partner rows, chains, table bytes, arena bytes, sampled k_iter_select ms,
  * sampled k_iter_update ms, number of samples, count blocks found, count blocks inserted, partner cells read,
