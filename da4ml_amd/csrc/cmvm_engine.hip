@@ -308,8 +308,7 @@ __device__ bool table_insert(const Ctx &c, uint32_t lo, uint32_t hi, const RowIn
             atomicMax(&c.ub[slot >> c.gs_log2], bound_word(rank, tie_word(lo, hi, (int)(best & 0xFF))));
             c.gdirty[slot >> c.gs_log2] = 1;
         }
-        unsigned int live = atomicAdd(&c.g->n_live, 1u) + 1;
-        atomicMax(&c.g->live_peak, live);
+        atomicAdd(&c.g->n_live, 1u);  // no return value: fire-and-forget (the peak is sampled by k_iter_select)
     }
     return true;
 }
@@ -777,6 +776,7 @@ template <class Cell> __global__ void __launch_bounds__(SEL_THREADS) k_iter_sele
         g->rows[Nw] = rn;
         s_new = rn;
         g->picks[iter] = make_int4((int)A, (int)B, sub, shift);
+        if (g->n_live > g->live_peak) g->live_peak = g->n_live;
     }
     for (int k = tid; k < 6 * Kpad; k += SEL_THREADS) s_cnt[k] = 0;
     __syncthreads();
