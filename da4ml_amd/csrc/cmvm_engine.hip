@@ -65,6 +65,23 @@ constexpr int UPD_THREADS = 256;   // k_iter_update block
 constexpr int UPD_WAVES = UPD_THREADS / WAVE;
 constexpr int MAX_GROUPS = 4096;   // ub[] copy held in LDS by k_iter_select (32 KiB of u64)
 
+// Per-phase shader-clock timers of k_iter_update (tests/gpu_profile.py).  They cost SGPRs and VALU time, so they are
+// compiled in only with -DDA_PHASE_TIMERS (make PHASE_TIMERS=1).
+#ifdef DA_PHASE_TIMERS
+#define UPD_TIMER_DECL long long up[5] = {0, 0, 0, 0, 0}, u0 = clock64(), u1;
+#define UPD_TIMER_MARK(i) \
+    u1 = clock64();       \
+    up[i] += u1 - u0;     \
+    u0 = u1;
+#define UPD_TIMER_FLUSH \
+    if (lane == 0)      \
+        for (int q = 0; q < 5; ++q) atomicAdd(&g->st_phase[7 + q], (unsigned long long)up[q]);
+#else
+#define UPD_TIMER_DECL
+#define UPD_TIMER_MARK(i)
+#define UPD_TIMER_FLUSH
+#endif
+
 struct HStat {
     int ov;
     float dl;
@@ -927,7 +944,8 @@ template <class Cell> __global__ void __launch_bounds__(SEL_THREADS) k_iter_sele
 // grid (U, n_chains).  Every partner row (a row other than A, B, new that shares a substituted column) is handled
 // by ONE wavefront, fetched from the chain's work list with an atomic counter: it subtracts the pair occurrences
 // lost with A's / B's consumed digits from the blocks (A,r), (B,r) and creates the block (r,new).
-template <class Cell> __global__ void __launch_bounds__(UPD_THREADS) k_iter_update(ChainDev *chains) {
+template <class Cell>
+__global__ void __launch_bounds__(UPD_THREADS, 8) __attribute__((amdgpu_num_sgpr(80))) k_iter_update(ChainDev *chains) {
     ChainDev *g = &chains[blockIdx.y];
     if (g->done) return;
     const int n_partners = g->n_partners;
@@ -958,7 +976,7 @@ template <class Cell> __global__ void __launch_bounds__(UPD_THREADS) k_iter_upda
     const RowInfo rnew = c.rows[Nw];
     uint32_t *dA = s_cnt + (size_t)wid * 3 * Kpad, *dB = dA + Kpad, *cN = dB + Kpad;
     unsigned int partners = 0, found = 0, inserts = 0;
-    long long up[5] = {0, 0, 0, 0, 0}, u0 = clock64(), u1;
+    UPD_TIMER_DECL
     // static striding over the partner list (no work counter: partners cost about the same).  Software pipeline: the
     // cell and probe loads of the NEXT partner are issued before the current partner's blocks are read, so the two
     // dependent memory round-trips of consecutive partners overlap.
@@ -1012,9 +1030,7 @@ template <class Cell> __global__ void __launch_bounds__(UPD_THREADS) k_iter_upda
                     slotB = table_find_from(c, keyB, hhB, 1);
             }
         }
-        u1 = clock64();
-        up[1] += u1 - u0;  // list entry + two table probes
-        u0 = u1;
+        UPD_TIMER_MARK(1)  // list entry + two table probes
         for (int k = lane; k < 3 * Kpad; k += WAVE) dA[k] = 0;
         lds_fence();
         int got_new = 0;
@@ -1030,27 +1046,20 @@ template <class Cell> __global__ void __launch_bounds__(UPD_THREADS) k_iter_upda
             for_pairs_cross<Cell>(x, ma, nb, [&](int k) { got_new |= atomicAdd(&cN[k], 1u) >= 1u; });
         }
         lds_fence();
-        u1 = clock64();
-        up[2] += u1 - u0;  // cells + pair enumeration
-        u0 = u1;
+        UPD_TIMER_MARK(2)  // cells + pair enumeration
         if (slotA >= 0 || slotB >= 0) table_update_pair(c, slotA, keyA, dA, slotB, keyB, dB);
         found += (slotA >= 0) + (slotB >= 0);
-        u1 = clock64();
-        up[3] += u1 - u0;  // block updates
-        u0 = u1;
+        UPD_TIMER_MARK(3)  // block updates
         if (__any(got_new)) {
             table_insert(c, pr, Nw, c.rows[pr], rnew, [&](int k) { return cN[k]; });
             ++inserts;
         }
-        u1 = clock64();
-        up[4] += u1 - u0;  // block creation
-        u0 = u1;
+        UPD_TIMER_MARK(4)  // block creation
         pr = prn;
         x0 = x0n;
         kk = kkn;
     }
-    if (lane == 0)
-        for (int q = 0; q < 5; ++q) atomicAdd(&g->st_phase[7 + q], (unsigned long long)up[q]);
+    UPD_TIMER_FLUSH
     if (lane == 0 && partners) {
         atomicAdd(&g->st_partners, (unsigned long long)partners);
         atomicAdd(&g->st_cells, (unsigned long long)partners * (unsigned)m);

@@ -17,3 +17,5 @@ ph = {k: v for k, v in tm.items() if k.startswith('sel_') or k.startswith('upd_'
 its = max(tm['iterations'], 1); pa = max(tm['partners'], 1)
 print('select cycles/iteration:', {k: round(v / its) for k, v in ph.items() if k.startswith('sel_')})
 print('update cycles/partner  :', {k: round(v / pa) for k, v in ph.items() if k.startswith('upd_')}, 'partners/iter', round(pa / its), 'found/partner %.2f' % (tm['found'] / pa), 'inserts/partner %.3f' % (tm['inserts'] / pa))
+sm = max(tm['samples'], 1)
+print('sampled per-launch: select %.1f us, update %.1f us, chains/launch %.1f' % (1e3 * tm['select_ms_sampled'] / sm, 1e3 * tm['update_ms_sampled'] / sm, tm['sampled_chain_launches'] / sm))
