@@ -1195,13 +1195,14 @@ struct HipBackend::Impl {
     hipStream_t stream = nullptr;
     static constexpr int MAX_LANES = 8;
     hipStream_t lanes[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // greedy-loop streams of the chain groups
-    int n_lanes = 3;
+    int n_lanes = 3;  // + the poll stream = 4 hardware queues
     bool use_graph = false;
     int upd_total_blocks = 2048;  // k_iter_update blocks over all chains of a batch (4 waves each)
     bool mt_launch = false;
     DeviceBuffer arena, desc_buf, io_buf;
     unsigned int *d_done = nullptr;
-    unsigned int *h_done = nullptr;  // pinned
+    unsigned int *h_done = nullptr;  // pinned, two words: done counters of alternating poll windows
+    hipStream_t poll_stream = nullptr;
     GpuTimings timings;
     double table_scale = 1.0;  // grows on E_TABLE_CAPACITY retries
 };
@@ -1219,7 +1220,8 @@ HipBackend::HipBackend(int device) : impl_(new Impl) {
     if (const char *e = std::getenv("DA4ML_HIP_GRAPH")) impl_->use_graph = std::atoi(e) != 0;
     if (const char *e = std::getenv("DA4ML_HIP_LANES")) impl_->n_lanes = std::max(1, std::min((int)Impl::MAX_LANES, std::atoi(e)));
     HIP_CHECK(hipMalloc(&impl_->d_done, sizeof(unsigned int)));
-    HIP_CHECK(hipHostMalloc(&impl_->h_done, sizeof(unsigned int), hipHostMallocDefault));
+    HIP_CHECK(hipHostMalloc(&impl_->h_done, 2 * sizeof(unsigned int), hipHostMallocDefault));
+    HIP_CHECK(hipStreamCreateWithFlags(&impl_->poll_stream, hipStreamNonBlocking));
     Log2Table t = measure_log2_table();
     HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_log2), &t, sizeof t));
 }
@@ -1227,6 +1229,7 @@ HipBackend::~HipBackend() {
     (void)hipSetDevice(impl_->device);
     if (impl_->d_done) (void)hipFree(impl_->d_done);
     if (impl_->h_done) (void)hipHostFree(impl_->h_done);
+    if (impl_->poll_stream) (void)hipStreamDestroy(impl_->poll_stream);
     if (impl_->stream) (void)hipStreamDestroy(impl_->stream);
     for (int l = 1; l < Impl::MAX_LANES; ++l)
         if (impl_->lanes[l]) (void)hipStreamDestroy(impl_->lanes[l]);
@@ -1535,8 +1538,21 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
     long long launched_iters = 0, iter_cap = 0;
     for (int i = 0; i < n; ++i) iter_cap = std::max<long long>(iter_cap, geo[i].rcap - jobs[i].n_in + 2);
     const int poll_every = GRAPH_ITERS + 1;
+    int pre_done = 0;
+    for (int i = 0; i < n; ++i) pre_done += (jobs[i].method == M_DUMMY || jobs[i].method < 0) ? 1 : 0;
+    // The done counter is read back ONE WINDOW BEHIND on a separate stream: after window w is queued, the poll stream
+    // waits for every group's end-of-window event and copies the counter; the host looks at the copy of window w-1 only
+    // after window w has been queued, so the queues never drain while the host decides whether to go on.
+    hipEvent_t win_ev[2][Impl::MAX_LANES], copy_ev[2];
+    for (int p = 0; p < 2; ++p) {
+        HIP_CHECK(hipEventCreateWithFlags(&copy_ev[p], hipEventDisableTiming));
+        for (size_t gi = 0; gi < groups.size(); ++gi) HIP_CHECK(hipEventCreateWithFlags(&win_ev[p][gi], hipEventDisableTiming));
+    }
+    im.h_done[0] = im.h_done[1] = 0;
+    long long window = 0;
     while (active > 0) {
-        if (launched_iters > iter_cap + poll_every) throw std::runtime_error("greedy loop did not terminate within its row capacity (internal error)");
+        if (launched_iters > iter_cap + 2 * poll_every) throw std::runtime_error("greedy loop did not terminate within its row capacity (internal error)");
+        int this_window = GRAPH_ITERS;
         // sampled eager iteration (all groups; the first group's kernels are bracketed by events on its stream)
         for (size_t gi = 0; gi < groups.size(); ++gi) {
             hipEvent_t se[3];
@@ -1554,7 +1570,7 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
             for (const Group &gr : groups) HIP_CHECK(hipStreamSynchronize(gr.stream));
             HIP_CHECK(hipGraphLaunch(graph_exec, st));
         } else if (im.mt_launch && groups.size() > 1) {
-            // one host thread per group: the launch rate of a single thread limits 4 streams x 2 kernels per iteration
+            // one host thread per group
             std::vector<std::thread> th;
             std::exception_ptr err;
             std::mutex mu;
@@ -1571,17 +1587,31 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
             for (auto &t : th) t.join();
             if (err) std::rethrow_exception(err);
         } else {
-            for (int it = 0; it < GRAPH_ITERS; ++it)
+            // small problems finish within a few iterations: start with short windows, double up to the full length
+            this_window = (int)std::min<long long>(GRAPH_ITERS, (8ll << std::min<long long>(window, 8)) - 1);
+            for (int it = 0; it < this_window; ++it)
                 for (const Group &gr : groups) launch_pair(gr, nullptr);
         }
-        launched_iters += poll_every;
+        launched_iters += this_window + 1;
         HIP_CHECK(hipGetLastError());
-        for (const Group &gr : groups) HIP_CHECK(hipStreamSynchronize(gr.stream));
-        HIP_CHECK(hipMemcpyAsync(im.h_done, im.d_done, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
-        HIP_CHECK(hipStreamSynchronize(st));
-        int pre_done = 0;
-        for (int i = 0; i < n; ++i) pre_done += (jobs[i].method == M_DUMMY || jobs[i].method < 0) ? 1 : 0;
-        active = n - pre_done - (int)*im.h_done;
+        const int p = (int)(window & 1);
+        for (size_t gi = 0; gi < groups.size(); ++gi) {
+            HIP_CHECK(hipEventRecord(win_ev[p][gi], groups[gi].stream));
+            HIP_CHECK(hipStreamWaitEvent(im.poll_stream, win_ev[p][gi], 0));
+        }
+        HIP_CHECK(hipMemcpyAsync(&im.h_done[p], im.d_done, sizeof(unsigned int), hipMemcpyDeviceToHost, im.poll_stream));
+        HIP_CHECK(hipEventRecord(copy_ev[p], im.poll_stream));
+        if (window > 0) {
+            HIP_CHECK(hipEventSynchronize(copy_ev[p ^ 1]));
+            active = n - pre_done - (int)im.h_done[p ^ 1];
+        }
+        ++window;
+    }
+    for (const Group &gr : groups) HIP_CHECK(hipStreamSynchronize(gr.stream));
+    HIP_CHECK(hipStreamSynchronize(im.poll_stream));
+    for (int p = 0; p < 2; ++p) {
+        (void)hipEventDestroy(copy_ev[p]);
+        for (size_t gi = 0; gi < groups.size(); ++gi) (void)hipEventDestroy(win_ev[p][gi]);
     }
     if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
     if (graph) (void)hipGraphDestroy(graph);
