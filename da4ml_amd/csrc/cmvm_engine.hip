@@ -131,6 +131,11 @@ struct ChainDev {
     uint32_t *fin_row;
     unsigned long long *fin_cell;
     uint32_t *fin_count;
+    uint32_t *fin_start;           // [n_out + 1] exclusive prefix of fin_count
+    uint32_t *pk_row;              // packed surviving digits, column major ...
+    unsigned long long *pk_cell;   // ... and their cells
+    float *pk_lat;                 // [n_rows] latency of every row
+    int pk_cap;
     // statistics
     unsigned long long st_rescans, st_partners, st_matches, st_found, st_inserts, st_cells;
     unsigned long long st_phase[12];  // shader-clock cycles per kernel phase (select: 0-6, update: 7-11)
@@ -1096,6 +1101,46 @@ template <class Cell> __global__ void __launch_bounds__(256) k_extract(ChainDev 
     if (lane == 0) ch.fin_count[j] = (uint32_t)out;
 }
 
+// ------------------------------------------------------------------------------------------------ k_pack
+// grid (n_chains): prefix sum of the per-column counts and a dense copy of the surviving digits and of the row
+// latencies, so that the download is proportional to the result instead of to the list capacities.
+__global__ void __launch_bounds__(256) k_pack(ChainDev *chains) {
+    ChainDev &ch = chains[blockIdx.x];
+    __shared__ uint32_t s_total;
+    const int n_out = ch.n_out, tid = threadIdx.x, lane = lane_id(), nw = blockDim.x / WAVE;
+    if (tid < WAVE) {  // exclusive prefix by the first wave, 64 columns per step
+        uint32_t run = 0;
+        for (int base = 0; base < n_out; base += WAVE) {
+            int j = base + lane;
+            uint32_t v = j < n_out ? ch.fin_count[j] : 0u, inc = v;
+            for (int o = 1; o < WAVE; o <<= 1) {
+                uint32_t t = (uint32_t)__shfl_up((int)inc, o);
+                if (lane >= o) inc += t;
+            }
+            if (j < n_out) ch.fin_start[j] = run + inc - v;
+            run += (uint32_t)__shfl((int)inc, WAVE - 1);
+        }
+        if (lane == 0) {
+            ch.fin_start[n_out] = run;
+            s_total = run;
+        }
+    }
+    __syncthreads();
+    if (s_total > (uint32_t)ch.pk_cap) {
+        if (tid == 0) ch.error = E_LIST_CAPACITY;
+        return;
+    }
+    for (int j = wave_id(); j < n_out; j += nw) {
+        const uint32_t cnt = ch.fin_count[j], dst = ch.fin_start[j];
+        const size_t src = (size_t)j * ch.lcap;
+        for (uint32_t e = lane; e < cnt; e += WAVE) {
+            ch.pk_row[dst + e] = ch.fin_row[src + e];
+            ch.pk_cell[dst + e] = ch.fin_cell[src + e];
+        }
+    }
+    for (int r = tid; r < ch.n_rows; r += blockDim.x) ch.pk_lat[r] = ch.rows[r].lat;
+}
+
 // ------------------------------------------------------------------------------------------------ k_col_dist
 // Stage-1 distance matrix: d0[a][b] = sum_i nnzNAF(M[i,a] - M[i,b]), d1 with '+'.  grid (ceil(W/16), ceil(W/16)),
 // block 16x16: a 16x16 tile of (a,b); the two 16-column strips of M are staged through LDS 64 rows at a time.
@@ -1190,8 +1235,28 @@ uint32_t pow2_ceil(uint64_t v) {
 
 }  // namespace
 
+struct PinnedBuffer {  // grow-only pinned host allocation reused across calls
+    void *ptr = nullptr;
+    size_t cap = 0;
+    void *get(size_t bytes) {
+        if (bytes > cap) {
+            if (ptr) (void)hipHostFree(ptr);
+            ptr = nullptr;
+            cap = 0;
+            size_t want = bytes + bytes / 4 + 4096;
+            HIP_CHECK(hipHostMalloc(&ptr, want, hipHostMallocDefault));
+            cap = want;
+        }
+        return ptr;
+    }
+    ~PinnedBuffer() {
+        if (ptr) (void)hipHostFree(ptr);
+    }
+};
+
 struct HipBackend::Impl {
     int device = 0;
+    PinnedBuffer pinned;
     hipStream_t stream = nullptr;
     static constexpr int MAX_LANES = 8;
     hipStream_t lanes[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // greedy-loop streams of the chain groups
@@ -1242,7 +1307,7 @@ namespace {
 
 struct Geometry {
     bool wide;  // 64-bit cells
-    int n_bits, K, Kpad, rcap, lcap, gs_log2, n_groups;
+    int n_bits, K, Kpad, rcap, lcap, gs_log2, n_groups, pk_cap;
     uint32_t C;
 };
 
@@ -1272,6 +1337,11 @@ size_t carve_chain(unsigned char *base, const ChainJob &job, const Geometry &g, 
     d.fin_row = c.take<uint32_t>(n_out * (size_t)g.lcap);
     d.fin_cell = c.take<unsigned long long>(n_out * (size_t)g.lcap);
     d.fin_count = c.take<uint32_t>(n_out);
+    d.fin_start = c.take<uint32_t>(n_out + 1);
+    d.pk_cap = g.pk_cap;
+    d.pk_row = c.take<uint32_t>((size_t)g.pk_cap);
+    d.pk_cell = c.take<unsigned long long>((size_t)g.pk_cap);
+    d.pk_lat = c.take<float>(g.rcap);
     (void)n_in;
     return align_up(c.off, 256);
 }
@@ -1285,6 +1355,12 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
     HIP_CHECK(hipSetDevice(im.device));
     hipStream_t st = im.stream;
     auto t_begin = std::chrono::steady_clock::now();
+    const bool verbose = std::getenv("DA4ML_HIP_VERBOSE") != nullptr;
+    auto lap = [&, last = t_begin](const char *what) mutable {
+        auto now = std::chrono::steady_clock::now();
+        if (verbose) std::fprintf(stderr, "[da4ml_hip] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - last).count());
+        last = now;
+    };
 
     // ---- 1. inputs to the device, k_prepare
     std::vector<size_t> in_off(n);
@@ -1336,6 +1412,7 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
     HIP_CHECK(hipMemcpyAsync(desc.data(), d_desc, sizeof(ChainDev) * (size_t)n, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
 
+    lap("upload + k_prepare");
     // ---- 2. geometry and arena
     std::vector<Geometry> geo(n);
     std::vector<size_t> a_off(n);
@@ -1354,6 +1431,7 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
         if (steps > D0) steps = std::max<long long>(D0, 1);
         g.rcap = jobs[i].n_in + (int)steps + 1;
         g.lcap = jobs[i].n_in + d.prep_maxdcol + 1;
+        g.pk_cap = (int)std::min<long long>(D0 + 1, (long long)1 << 30);  // digits only ever disappear
         // table capacity: blocks peak well above the initial pair count when rows are dense
         long long pairs0 = std::min<long long>((long long)jobs[i].n_in * (jobs[i].n_in + 1) / 2, std::max<long long>(d.prep_pairs, 1));
         double growth = std::max(4.0, jobs[i].n_in / 5.0);
@@ -1458,6 +1536,8 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
     if (ranges[1].count)
         HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_iter_select<uint64_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sel_lds[1]));
 
+    HIP_CHECK(hipStreamSynchronize(st));
+    lap("arena + init kernels");
     // ---- 4. greedy loop: two kernels per iteration.  The chains are split into up to four groups, each advancing
     // in lockstep on its own stream, so that the one-block-per-chain select kernel of one group overlaps the update
     // kernel of the others.
@@ -1618,6 +1698,7 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
     im.timings.graph_used += graph_exec ? 1 : 0;
     HIP_CHECK(hipEventRecord(ev1, st));
 
+    lap("greedy loop");
     // ---- 5. extraction and download
     for (int w = 0; w < 2; ++w) {
         const Range &r = ranges[w];
@@ -1628,6 +1709,7 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
         else
             hipLaunchKernelGGL(k_extract<uint64_t>, colgrid, dim3(256), 0, st, d_desc + r.first);
     }
+    hipLaunchKernelGGL(k_pack, dim3(n), dim3(256), 0, st, d_desc);
     HIP_CHECK(hipGetLastError());
     std::vector<ChainDev> fin(n);
     HIP_CHECK(hipMemcpyAsync(fin.data(), d_desc, sizeof(ChainDev) * (size_t)n, hipMemcpyDeviceToHost, st));
@@ -1693,41 +1775,56 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
         if (iters) HIP_CHECK(hipMemcpyAsync(o.picks.data(), d.picks, iters * sizeof(int4), hipMemcpyDeviceToHost, st));
         down_bytes += iters * 16;
     }
-    // row latencies and surviving digits need staging (strided on the device)
-    std::vector<std::vector<RowInfo>> rowbuf(n);
-    std::vector<std::vector<uint32_t>> cntbuf(n), frow(n);
-    std::vector<std::vector<unsigned long long>> fcell(n);
+    // packed results through one pinned staging buffer: first the column offsets (sizes), then exactly the digits
+    std::vector<size_t> st_off(n), lat_off(n), row_off(n), cell_off(n);
+    size_t pin_bytes = 0;
+    for (int s = 0; s < n; ++s) {
+        const ChainJob &j = jobs[order[s]];
+        st_off[s] = pin_bytes;
+        pin_bytes += align_up(((size_t)j.n_out + 1) * 4, 64);
+    }
+    unsigned char *pin = static_cast<unsigned char *>(im.pinned.get(pin_bytes));
+    for (int s = 0; s < n; ++s) {
+        const ChainJob &j = jobs[order[s]];
+        HIP_CHECK(hipMemcpyAsync(pin + st_off[s], fin[s].fin_start, ((size_t)j.n_out + 1) * 4, hipMemcpyDeviceToHost, st));
+    }
+    HIP_CHECK(hipStreamSynchronize(st));
+    std::vector<uint32_t> totals(n);
+    size_t pin2 = 0;
+    for (int s = 0; s < n; ++s) {
+        const ChainJob &j = jobs[order[s]];
+        ChainOut &o = outs[order[s]];
+        const uint32_t *cs = reinterpret_cast<const uint32_t *>(pin + st_off[s]);
+        o.col_start.assign(cs, cs + j.n_out + 1);
+        totals[s] = cs[j.n_out];
+        lat_off[s] = pin2;
+        pin2 += align_up((size_t)fin[s].n_rows * 4, 64);
+        row_off[s] = pin2;
+        pin2 += align_up((size_t)totals[s] * 4, 64);
+        cell_off[s] = pin2;
+        pin2 += align_up((size_t)totals[s] * 8, 64);
+    }
+    pin = static_cast<unsigned char *>(im.pinned.get(pin2));
     for (int s = 0; s < n; ++s) {
         const ChainDev &d = fin[s];
-        int i = order[s];
-        const ChainJob &j = jobs[i];
-        rowbuf[s].resize(d.n_rows);
-        HIP_CHECK(hipMemcpyAsync(rowbuf[s].data(), d.rows, sizeof(RowInfo) * (size_t)d.n_rows, hipMemcpyDeviceToHost, st));
-        cntbuf[s].resize(j.n_out);
-        HIP_CHECK(hipMemcpyAsync(cntbuf[s].data(), d.fin_count, 4 * (size_t)j.n_out, hipMemcpyDeviceToHost, st));
-        frow[s].resize((size_t)j.n_out * d.lcap);
-        fcell[s].resize((size_t)j.n_out * d.lcap);
-        HIP_CHECK(hipMemcpyAsync(frow[s].data(), d.fin_row, 4 * frow[s].size(), hipMemcpyDeviceToHost, st));
-        HIP_CHECK(hipMemcpyAsync(fcell[s].data(), d.fin_cell, 8 * fcell[s].size(), hipMemcpyDeviceToHost, st));
-        down_bytes += 12 * frow[s].size();
-        (void)i;
+        HIP_CHECK(hipMemcpyAsync(pin + lat_off[s], d.pk_lat, (size_t)d.n_rows * 4, hipMemcpyDeviceToHost, st));
+        if (totals[s]) {
+            HIP_CHECK(hipMemcpyAsync(pin + row_off[s], d.pk_row, (size_t)totals[s] * 4, hipMemcpyDeviceToHost, st));
+            HIP_CHECK(hipMemcpyAsync(pin + cell_off[s], d.pk_cell, (size_t)totals[s] * 8, hipMemcpyDeviceToHost, st));
+        }
+        down_bytes += (size_t)totals[s] * 12;
     }
     HIP_CHECK(hipStreamSynchronize(st));
     for (int s = 0; s < n; ++s) {
         const ChainDev &d = fin[s];
         int i = order[s];
-        const ChainJob &j = jobs[i];
         ChainOut &o = outs[i];
-        o.row_lat.resize(d.n_rows);
-        for (int r = 0; r < d.n_rows; ++r) o.row_lat[r] = rowbuf[s][r].lat;
-        o.col_start.assign(j.n_out + 1, 0);
-        for (int c = 0; c < j.n_out; ++c) o.col_start[c + 1] = o.col_start[c] + cntbuf[s][c];
-        o.dig_row.resize(o.col_start[j.n_out]);
-        o.dig_cell.resize(o.col_start[j.n_out]);
-        for (int c = 0; c < j.n_out; ++c) {
-            std::copy_n(&frow[s][(size_t)c * d.lcap], cntbuf[s][c], &o.dig_row[o.col_start[c]]);
-            std::copy_n(&fcell[s][(size_t)c * d.lcap], cntbuf[s][c], &o.dig_cell[o.col_start[c]]);
-        }
+        const float *lat = reinterpret_cast<const float *>(pin + lat_off[s]);
+        o.row_lat.assign(lat, lat + d.n_rows);
+        const uint32_t *pr = reinterpret_cast<const uint32_t *>(pin + row_off[s]);
+        const unsigned long long *pc = reinterpret_cast<const unsigned long long *>(pin + cell_off[s]);
+        o.dig_row.assign(pr, pr + totals[s]);
+        o.dig_cell.assign(pc, pc + totals[s]);
         o.stats.iterations = d.iter;
         o.stats.digits0 = d.prep_digits;
         o.stats.table_peak = d.live_peak;
@@ -1745,6 +1842,7 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
         im.timings.partners += (long long)d.st_partners;
         im.timings.table_bytes += (double)d.C * (8 + 4 + 1 + 8 + 2.0 * d.Kpad);
     }
+    lap("extract + download + unpack");
     im.timings.loop_ms += loop_ms;
     im.timings.lockstep_iters += launched_iters;
     im.timings.chains += n;

@@ -8,6 +8,9 @@
 #include <cmath>
 #include <cstring>
 #include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <exception>
 #include <limits>
 #include <memory>
@@ -321,7 +324,7 @@ namespace {
 // run fn(i) for i in [0, n) on a few host threads (the per-chain host work -- MST, adder trees -- is independent)
 template <class Fn> void parallel_for(size_t n, Fn &&fn) {
     unsigned hw = std::thread::hardware_concurrency();
-    size_t workers = std::min<size_t>(n, std::max(1u, std::min(hw ? hw : 1u, 32u)));
+    size_t workers = std::min<size_t>(n, std::max(1u, std::min(hw ? hw : 1u, 64u)));
     if (workers <= 1) {
         for (size_t i = 0; i < n; ++i) fn(i);
         return;
@@ -486,7 +489,9 @@ std::vector<PipeResult> solve_batch(Backend &be, const std::vector<Problem> &pro
         }
         if (jobs.empty()) break;
         std::vector<ChainOut> outs(jobs.size());
+        auto t_rc = std::chrono::steady_clock::now();
         be.run_chains(jobs.data(), outs.data(), (int)jobs.size());
+        auto t_fin = std::chrono::steady_clock::now();
         for (size_t k = 0; k < jobs.size(); ++k)
             if (outs[k].unknown_method_hit) {
                 Candidate &c = cands[owners[k].cand];
@@ -494,6 +499,10 @@ std::vector<PipeResult> solve_batch(Backend &be, const std::vector<Problem> &pro
             }
         std::vector<StageResult> sols(jobs.size());
         parallel_for(jobs.size(), [&](size_t k) { sols[k] = finalize_chain(jobs[k], outs[k]); });
+        if (std::getenv("DA4ML_HIP_VERBOSE"))
+            std::fprintf(stderr, "[da4ml_hip] round of %zu chains: run_chains %.2f ms, adder trees %.2f ms\n", jobs.size(),
+                         std::chrono::duration<double, std::milli>(t_fin - t_rc).count(),
+                         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_fin).count());
         for (size_t k = 0; k < jobs.size(); ++k) {
             Candidate &c = cands[owners[k].cand];
             ProblemState &s = ps[c.problem];
