@@ -1447,6 +1447,20 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
         a_off[i] = arena_bytes;
         arena_bytes += carve_chain(nullptr, jobs[i], g, tmp);
     }
+    // a batch whose arena does not fit into (most of) the free device memory is processed in two halves
+    {
+        size_t free_b = 0, total_b = 0;
+        HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
+        size_t budget = (size_t)(0.85 * (double)(free_b + im.arena.cap));
+        if (const char *e = std::getenv("DA4ML_HIP_MEM_BUDGET_MB")) budget = (size_t)std::atoll(e) << 20;  // test hook
+        if (arena_bytes > budget) {
+            if (n == 1) throw std::runtime_error("a single chain needs " + std::to_string(arena_bytes >> 20) + " MiB of device memory, more than is free");
+            const int half_n = n / 2;
+            run_chains(jobs, outs, half_n);
+            run_chains(jobs + half_n, outs + half_n, n - half_n);
+            return;
+        }
+    }
     unsigned char *arena = static_cast<unsigned char *>(im.arena.get(arena_bytes));
     for (int i = 0; i < n; ++i) {
         ChainDev &d = desc[i];

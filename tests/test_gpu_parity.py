@@ -184,3 +184,27 @@ def test_same_matrix_different_intervals(hip, oracle):
 def test_ragged_shapes(hip, oracle, shape):
     k = int_matrix(shape[0] * 7 + shape[1], shape[0], shape[1], -32, 32)
     assert hip.solve(k) == oracle.solve(k)
+
+
+def test_sub_batching_under_memory_pressure(oracle):
+    """a batch whose arena exceeds the device-memory budget is split recursively; results are unchanged"""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    code = (
+        "import sys; sys.path.insert(0, '.'); sys.path.insert(0, 'tests')\n"
+        "from cases import int_matrix\nfrom da4ml_amd import _binary as hip\nimport json\n"
+        "ks = [int_matrix(s, 40, 40, -128, 128) for s in range(6)]\n"
+        "ps = hip.solve_many(ks, method0='wmc', method1='wmc', decompose_dc=-1, search_all_decompose_dc=False)\n"
+        "print(json.dumps([[p.cost, [len(s.ops) for s in p.solutions]] for p in ps]))\n"
+    )
+    env = dict(os.environ, DA4ML_HIP_MEM_BUDGET_MB='24')
+    out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, cwd=str(Path(__file__).resolve().parent.parent))
+    assert out.returncode == 0, out.stderr
+    got = json.loads(out.stdout.strip().splitlines()[-1])
+    for s, (cost, n_ops) in enumerate(got):
+        want = oracle.solve(int_matrix(s, 40, 40, -128, 128), method0='wmc', method1='wmc', decompose_dc=-1, search_all_decompose_dc=False)
+        assert cost == want.cost and n_ops == [len(x.ops) for x in want.solutions]
