@@ -252,10 +252,12 @@ class CombLogic(NamedTuple):
         self.to_binary(version).tofile(str(path))
 
     def predict(self, data, n_threads: int = 0):
-        """Integer-exact batch execution of the adder graph (the reference routes this to its C++ DAIS
-        interpreter, ``types.py:549-581``); for the add/sub-only graphs of the CMVM path the float64 replay is exact."""
-        data = np.asarray(data, dtype=np.float64).reshape(-1, self.shape[0])
-        return np.asarray(self(data), dtype=np.float64)
+        """Integer-exact batch execution through the DAIS binary program, like the reference (``types.py:549-581``)."""
+        from ._binary import dais_interp_run
+
+        if isinstance(data, (list, tuple)):
+            data = np.concatenate([np.asarray(a).reshape(len(a), -1) for a in data], axis=-1)
+        return dais_interp_run(self.to_binary(), np.asarray(data, dtype=np.float64), n_threads)
 
 
 class Pipeline(NamedTuple):

@@ -14,7 +14,10 @@ def test_replay_and_roundtrip(oracle, tmp_path):
     x = np.random.default_rng(0).integers(-128, 128, (50, 12)).astype(np.float64)
     assert np.array_equal(p(x), x @ k.astype(np.float64))
     assert np.array_equal(p(x[3]), x[3] @ k.astype(np.float64))
-    assert np.array_equal(p.solutions[0].predict(x), p.solutions[0](x))
+    assert np.array_equal(p.solutions[0].predict(x), p.solutions[0](x))  # DAIS binary program + integer interpreter
+    from da4ml_amd._binary import dais_interp_run
+
+    assert np.array_equal(dais_interp_run(p.solutions[0].to_binary(), x.ravel()), p.solutions[0](x))
     p.save(tmp_path / 'p.json')
     assert Pipeline.load(tmp_path / 'p.json') == p
     p.solutions[0].save(tmp_path / 's.json')
