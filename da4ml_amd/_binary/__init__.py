@@ -35,6 +35,15 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    csrc = _LIB_PATH.parent / 'csrc'
+    sources = [p for p in csrc.glob('*') if p.suffix in ('.hip', '.cc', '.h')] + [_LIB_PATH.parent.parent / 'include' / 'da4ml_hip.h']
+    stale = not _LIB_PATH.exists() or any(p.exists() and p.stat().st_mtime > _LIB_PATH.stat().st_mtime for p in sources)
+    if stale:  # build in-tree (hipcc cross-compiles for gfx950 without a GPU); never fall back to anything else
+        import shutil
+        import subprocess
+
+        if shutil.which('make') and (shutil.which('hipcc') or Path('/opt/rocm/bin/hipcc').exists()):
+            subprocess.run(['make', '-C', str(csrc)], check=False, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     if not _LIB_PATH.exists():
         raise ImportError(f'{_LIB_PATH} is missing: build it with `python -c "import __graft_entry__ as g; g.build()"` or `make -C da4ml_amd/csrc`')
     L = C.CDLL(str(_LIB_PATH))
