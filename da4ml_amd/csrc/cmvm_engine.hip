@@ -118,6 +118,7 @@ struct ChainDev {
     void *mA, *mB;
     uint32_t *plist;
     int m, n_partners;
+    int claim_words;   // words of the LDS claim bitmap in k_iter_select (0: use the global stamp array)
     unsigned int work_ctr;
     uint32_t A, B, Nw;
     // progress
@@ -613,6 +614,8 @@ template <class Cell> __global__ void __launch_bounds__(SEL_THREADS) k_iter_sele
     uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_work + ((n_groups + 3) & ~3));  // [6][Kpad]
     int *s_len = reinterpret_cast<int *>(s_cnt + 6 * Kpad);                           // [n_out + 1] list lengths -> offsets
     int *s_col = s_len + n_out + 1;                                                   // [n_out] matched columns
+    uint32_t *s_bits = reinterpret_cast<uint32_t *>(s_col + n_out);                  // [claim_words] rows already claimed (if it fits)
+    const int claim_words = g->claim_words;
     constexpr int NW = SEL_THREADS / WAVE;
     __shared__ unsigned long long s_red_tie[NW], s_floor0, s_floor;
     __shared__ uint32_t s_red_rank[NW];
@@ -847,8 +850,20 @@ template <class Cell> __global__ void __launch_bounds__(SEL_THREADS) k_iter_sele
     __syncthreads();
     tp[4] = clock64();
     const int m = s_m;
-    // exclusive prefix sum of the list lengths of the matched columns (m <= n_out): chunked block scan
-    {
+    // exclusive prefix sum of the list lengths of the matched columns (m <= n_out)
+    for (int k = tid; k < claim_words; k += SEL_THREADS) s_bits[k] = 0;
+    if (m <= WAVE) {  // the common case: one wave, shuffle scan
+        if (wid == 0) {
+            int v = lane < m ? s_len[lane] : 0, inc = v;
+            for (int o = 1; o < WAVE; o <<= 1) {
+                int t = __shfl_up(inc, o);
+                if (lane >= o) inc += t;
+            }
+            if (lane < m) s_len[lane] = inc - v;
+            if (lane == WAVE - 1) s_len[m] = inc;
+        }
+        __syncthreads();
+    } else {  // chunked block scan
         int per = (m + SEL_THREADS - 1) / SEL_THREADS;
         int lo = min(tid * per, m), hi = min(lo + per, m), sum = 0;
         for (int q = lo; q < hi; ++q) sum += s_len[q];
@@ -873,16 +888,18 @@ template <class Cell> __global__ void __launch_bounds__(SEL_THREADS) k_iter_sele
     }
     const int total = s_len[m];
     tp[5] = clock64();
-    // ---------------- (4) partner rows: every row listed in a matched column, claimed once (stamp) and appended
-    {
+    // ---------------- (4) partner rows: every row listed in a matched column, claimed once and appended to the
+    // partner list -- by the first NW-6 waves; the last six waves store the six special pairs meanwhile.
+    constexpr int CLAIM_WAVES = NW - 6, CLAIM_THREADS = CLAIM_WAVES * WAVE;
+    if (wid < CLAIM_WAVES) {
         uint32_t *stamp = g->stamp, *plist = g->plist;
         const uint32_t tag = (uint32_t)iter + 1u;
-        for (int f0 = tid; f0 < total; f0 += 4 * SEL_THREADS) {
+        for (int f0 = tid; f0 < total; f0 += 4 * CLAIM_THREADS) {
             uint32_t r[4];
             bool ok[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {  // four independent list reads in flight
-                const int f = f0 + u * SEL_THREADS;
+                const int f = f0 + u * CLAIM_THREADS;
                 ok[u] = f < total;
                 r[u] = 0;
                 if (ok[u]) {
@@ -898,19 +915,27 @@ template <class Cell> __global__ void __launch_bounds__(SEL_THREADS) k_iter_sele
                 }
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) ok[u] = ok[u] && r[u] != A && r[u] != B && atomicExch(&stamp[r[u]], tag) != tag;
+            for (int u = 0; u < 4; ++u) {
+                if (!ok[u] || r[u] == A || r[u] == B) {
+                    ok[u] = false;
+                    continue;
+                }
+                if (claim_words) {  // de-duplicate in the LDS bitmap: no global round trip
+                    const uint32_t bit = 1u << (r[u] & 31);
+                    ok[u] = (atomicOr(&s_bits[r[u] >> 5], bit) & bit) == 0;
+                } else
+                    ok[u] = atomicExch(&stamp[r[u]], tag) != tag;
+            }
 #pragma unroll
             for (int u = 0; u < 4; ++u)
                 if (ok[u]) plist[atomicAdd(&s_np, 1)] = r[u];
         }
-    }
-    tp[6] = clock64();
-    // six special pairs, one wave each (runs concurrently with the claims above on the other waves)
-    if (wid < 6) {
+    } else {
+        const int sp = wid - CLAIM_WAVES;
         uint32_t lo = A, hi = A;
-        const uint32_t *cnt = s_cnt + wid * Kpad;
+        const uint32_t *cnt = s_cnt + sp * Kpad;
         bool active = true, existed = false;
-        switch (wid) {
+        switch (sp) {
         case 0: lo = A, hi = A, existed = true; break;
         case 1: lo = A, hi = B, existed = true, active = !same; break;
         case 2: lo = B, hi = B, existed = true, active = !same; break;
@@ -930,6 +955,7 @@ template <class Cell> __global__ void __launch_bounds__(SEL_THREADS) k_iter_sele
             }
         }
     }
+    tp[6] = clock64();
     __syncthreads();
     tp[7] = clock64();
     if (tid == 0) {
@@ -1476,6 +1502,7 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
         d.C = g.C;
         d.cmask = g.C - 1;
         d.n_rows = jobs[i].n_in;
+        d.claim_words = (g.rcap + 31) / 32 * 4 <= 64 * 1024 ? (g.rcap + 31) / 32 : 0;
         d.iter = 0;
         d.done = (jobs[i].method == M_DUMMY || jobs[i].method < 0) ? 1 : 0;
         // zero-initialised state: stamp, hrank, ub; hkey = EMPTY (all ones)
@@ -1515,8 +1542,10 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
     long long max_pairs[2] = {0, 0};
     for (int i = 0; i < n; ++i) {
         int w = geo[i].wide;
+        size_t claim_bytes = ((size_t)geo[i].rcap + 31) / 32 * 4;
+        if (claim_bytes > 64 * 1024) claim_bytes = 0;
         size_t s = (size_t)geo[i].n_groups * 8 + (((size_t)geo[i].n_groups + 7) & ~(size_t)7) + (((size_t)geo[i].n_groups + 3) & ~(size_t)3) * 2 +
-                   6 * (size_t)geo[i].Kpad * 4 + (2 * (size_t)jobs[i].n_out + 1) * 4;
+                   6 * (size_t)geo[i].Kpad * 4 + (2 * (size_t)jobs[i].n_out + 1) * 4 + claim_bytes;
         s = align_up(s, 16);
         sel_lds[w] = std::max(sel_lds[w], s);
         upd_lds[w] = std::max(upd_lds[w], align_up((size_t)UPD_WAVES * 3 * geo[i].Kpad * 4 + (((size_t)jobs[i].n_out + 1) & ~(size_t)1) * 4 + 2 * (size_t)jobs[i].n_out * (geo[i].wide ? 8 : 4), 16));
