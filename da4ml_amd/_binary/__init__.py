@@ -16,7 +16,9 @@ import numpy as np
 
 from .._marshal import pipeline_from_stages, stage_from_arrays
 
-_LIB_PATH = Path(__file__).resolve().parent.parent / 'libda4ml_hip.so'
+import os as _os
+
+_LIB_PATH = Path(_os.environ['DA4ML_HIP_LIB']).resolve() if _os.environ.get('DA4ML_HIP_LIB') else Path(__file__).resolve().parent.parent / 'libda4ml_hip.so'
 _lib = None
 
 _f32p = np.ctypeslib.ndpointer(np.float32, flags='C_CONTIGUOUS')
@@ -35,9 +37,9 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
-    csrc = _LIB_PATH.parent / 'csrc'
+    csrc = Path(__file__).resolve().parent.parent / 'csrc'
     sources = [p for p in csrc.glob('*') if p.suffix in ('.hip', '.cc', '.h')] + [_LIB_PATH.parent.parent / 'include' / 'da4ml_hip.h']
-    stale = not _LIB_PATH.exists() or any(p.exists() and p.stat().st_mtime > _LIB_PATH.stat().st_mtime for p in sources)
+    stale = not _os.environ.get('DA4ML_HIP_LIB') and (not _LIB_PATH.exists() or any(p.exists() and p.stat().st_mtime > _LIB_PATH.stat().st_mtime for p in sources))
     if stale:  # build in-tree (hipcc cross-compiles for gfx950 without a GPU); never fall back to anything else
         import shutil
         import subprocess

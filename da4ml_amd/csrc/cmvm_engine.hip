@@ -58,12 +58,17 @@ namespace gpu {
     } while (0)
 
 constexpr uint64_t KEY_EMPTY = ~0ull;
+// Tombstones carry the low two bits of the launch that wrote them (KEY_TOMB - id, id = 0..3).  A slot freed in a
+// launch is never re-used within the SAME launch: the deleting wave's stores to the slot (counts, rank, tombstone)
+// and a re-using wave's stores would otherwise be unordered (different waves, possibly different XCD L2s).  Kernel
+// boundaries order everything, so the slot is claimable from the next launch on.
 constexpr uint64_t KEY_TOMB = ~0ull - 1;
+constexpr uint64_t KEY_TOMB_LO = KEY_TOMB - 3;  // keys >= KEY_TOMB_LO and != KEY_EMPTY are tombstones
 constexpr int WAVE = 64;
 constexpr int SEL_THREADS = 1024;  // k_iter_select block (16 waves)
 constexpr int UPD_THREADS = 256;   // k_iter_update block
 constexpr int UPD_WAVES = UPD_THREADS / WAVE;
-constexpr int MAX_GROUPS = 4096;   // ub[] copy held in LDS by k_iter_select (32 KiB of u64)
+constexpr int MAX_GROUPS = 4096;   // 16 waves x 64 lanes x 4 register-resident bounds in k_iter_select
 
 // Per-phase shader-clock timers of k_iter_update (tests/gpu_profile.py).  They cost SGPRs and VALU time, so they are
 // compiled in only with -DDA_PHASE_TIMERS (make PHASE_TIMERS=1).
@@ -209,9 +214,12 @@ struct Ctx {
     uint8_t *gdirty;
     const RowInfo *rows;
     ChainDev *g;
+    unsigned long long tomb;  // this launch's tombstone value
 };
-__device__ __forceinline__ Ctx make_ctx(ChainDev *g) {
+// launch_id: 2 * iteration for k_iter_select, 2 * iteration + 1 for k_iter_update (only the low two bits are used)
+__device__ __forceinline__ Ctx make_ctx(ChainDev *g, int launch_id) {
     Ctx c;
+    c.tomb = KEY_TOMB - (unsigned long long)(launch_id & 3);
     c.n_out = g->n_out;
     c.n_bits = g->n_bits;
     c.K = g->K;
@@ -283,7 +291,7 @@ __device__ int table_claim(const Ctx &c, unsigned long long key, uint32_t h) {
     for (uint32_t w = 0; w < c.windows + 1; ++w) {
         uint32_t s = (b0 + w * WAVE + lane) & c.cmask;
         unsigned long long kk = c.hkey[s];
-        unsigned long long avail = __ballot(kk == KEY_EMPTY || kk == KEY_TOMB);
+        unsigned long long avail = __ballot(kk == KEY_EMPTY || (kk >= KEY_TOMB_LO && kk != c.tomb));
         while (avail) {
             int l = __ffsll((long long)avail) - 1;
             avail &= avail - 1;
@@ -358,7 +366,7 @@ __device__ void table_update(const Ctx &c, int slot, unsigned long long key, Cnt
     if (lane == 0) {
         if (!alive) {
             c.hrank[slot] = 0;
-            c.hkey[slot] = KEY_TOMB;
+            c.hkey[slot] = c.tomb;
             atomicSub(&c.g->n_live, 1u);
             if (prev) c.gdirty[slot >> c.gs_log2] = 1;
         } else {
@@ -422,7 +430,7 @@ __device__ __forceinline__ void table_update_pair(const Ctx &c, int slot0, unsig
         if (h0) {
             if (!alive0) {
                 c.hrank[slot0] = 0;
-                c.hkey[slot0] = KEY_TOMB;
+                c.hkey[slot0] = c.tomb;
                 atomicSub(&c.g->n_live, 1u);
                 if (prev0) c.gdirty[slot0 >> c.gs_log2] = 1;
             } else {
@@ -437,7 +445,7 @@ __device__ __forceinline__ void table_update_pair(const Ctx &c, int slot0, unsig
         if (h1) {
             if (!alive1) {
                 c.hrank[slot1] = 0;
-                c.hkey[slot1] = KEY_TOMB;
+                c.hkey[slot1] = c.tomb;
                 atomicSub(&c.g->n_live, 1u);
                 if (prev1) c.gdirty[slot1 >> c.gs_log2] = 1;
             } else {
@@ -574,7 +582,7 @@ __device__ __forceinline__ bool wave_any_ge2(const uint32_t *cnt, int K) {
 template <class Cell> __global__ void __launch_bounds__(256) k_init_pairs(ChainDev *chains) {
     ChainDev *g = &chains[blockIdx.y];
     if (g->method == M_DUMMY) return;
-    const Ctx c = make_ctx(g);
+    const Ctx c = make_ctx(g, 0);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *cnt = reinterpret_cast<uint32_t *>(smem) + (size_t)wave_id() * c.Kpad;
     long long n_in = g->n_in;
@@ -604,14 +612,11 @@ template <class Cell> __global__ void __launch_bounds__(SEL_THREADS) k_iter_sele
     using O = CellOps<Cell>;
     ChainDev *g = &chains[blockIdx.x];
     if (g->done) return;
-    const Ctx c = make_ctx(g);
+    const Ctx c = make_ctx(g, 2 * g->iter);
     const int n_groups = g->n_groups, n_out = c.n_out, Kpad = c.Kpad, nb = c.n_bits, lcap = g->lcap;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // dynamic LDS carve: bound copy | verified flags | special-pair counters | per-matched-column scratch
-    unsigned long long *s_ub = reinterpret_cast<unsigned long long *>(smem);          // [n_groups]
-    uint8_t *s_seen = reinterpret_cast<uint8_t *>(s_ub + n_groups);                   // [n_groups] (padded to 8)
-    uint16_t *s_work = reinterpret_cast<uint16_t *>(s_seen + ((n_groups + 7) & ~7));  // [n_groups] groups to inspect
-    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_work + ((n_groups + 3) & ~3));  // [6][Kpad]
+    // dynamic LDS carve: special-pair counters | per-matched-column scratch | claim bitmap
+    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(smem);                             // [6][Kpad]
     int *s_len = reinterpret_cast<int *>(s_cnt + 6 * Kpad);                           // [n_out + 1] list lengths -> offsets
     int *s_col = s_len + n_out + 1;                                                   // [n_out] matched columns
     uint32_t *s_bits = reinterpret_cast<uint32_t *>(s_col + n_out);                  // [claim_words] rows already claimed (if it fits)
@@ -639,13 +644,10 @@ template <class Cell> __global__ void __launch_bounds__(SEL_THREADS) k_iter_sele
     }
 
     // ---------------- (1) selection.  A group is CLEAN when no block in it changed its best (rank, key) since the
-    // group was last verified; then its bound word and stored tie word are exact.  The best clean bound is a lower
-    // bound of the answer, so only dirty groups whose (possibly stale) bound reaches it need to be re-read -- all of
-    // them in one parallel round, one wave per group.
-    for (int q = tid; q < n_groups; q += SEL_THREADS) {
-        s_ub[q] = c.ub[q];
-        s_seen[q] = c.gdirty[q];
-    }
+    // group was last verified; then its bound word and stored tie word are exact.  The best clean bound is a floor of
+    // the answer.  Wave w owns the groups [w * GPW, (w+1) * GPW); every lane keeps the bounds and states of its (up to
+    // four) groups in registers, loaded coalesced from global memory, and the wave re-reads its highest dirty group
+    // while that group's (possibly stale) bound can still beat or tie the rising floor.
     if (tid == 0) {
         s_best_rank = 0;
         s_best_tie = 0;
@@ -653,39 +655,48 @@ template <class Cell> __global__ void __launch_bounds__(SEL_THREADS) k_iter_sele
         s_np = 0;
         s_floor0 = 0;
     }
+    const int GPW = (n_groups + NW - 1) / NW;  // groups per wave, <= 4 * WAVE
+    unsigned long long ubr[4];
+    int dr[4];  // 0 clean on entry, 1 dirty, 2 verified in this call, 3 absent
+    {
+        unsigned long long cl = 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int q = wid * GPW + lane + u * WAVE;
+            const bool in = lane + u * WAVE < GPW && q < n_groups;
+            ubr[u] = in ? c.ub[q] : 0ull;
+            dr[u] = in ? (c.gdirty[q] ? 1 : 0) : 3;
+            if (dr[u] == 0) cl = max(cl, ubr[u]);
+        }
+        __syncthreads();  // s_floor0 initialised
+        cl = wave_max_u64(cl);
+        if (lane == 0 && cl) atomicMax(&s_floor0, cl);
+    }
     __syncthreads();
     tp[1] = clock64();
     {
-        // floor: the best bound among clean groups is attained by a real entry, so nothing below it can win
-        unsigned long long cl = 0;
-        for (int q = tid; q < n_groups; q += SEL_THREADS)
-            if (!s_seen[q]) cl = max(cl, s_ub[q]);
-        cl = wave_max_u64(cl);
-        if (lane == 0 && cl) atomicMax(&s_floor0, cl);
-        __syncthreads();
         const unsigned long long floor0 = s_floor0;
         if (tid == 0) s_floor = floor0;
         __syncthreads();
-        // every wave owns the groups g == wid (mod NW): it re-reads its highest dirty bound while that bound can
-        // still beat or tie the (rising) floor
         uint32_t wrank = 0;
         unsigned long long wtie = 0;
         unsigned int rescans = 0;
         unsigned long long *gtie_arr = g->gtie;
         while (true) {
             unsigned long long top = 0;
-            int top_g = 0;
-            for (int q = wid + lane * NW; q < n_groups; q += NW * WAVE) {
-                unsigned long long v = s_seen[q] == 1 ? s_ub[q] : 0ull;
-                if (v > top) {
-                    top = v;
-                    top_g = q;
+            int top_u = 0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (dr[u] == 1 && ubr[u] > top) {
+                    top = ubr[u];
+                    top_u = u;
                 }
-            }
             const unsigned long long wtop = wave_max_u64(top);
             if (wtop == 0 || wtop < *(volatile unsigned long long *)&s_floor) break;
             const unsigned long long who = __ballot(top == wtop);
-            const uint32_t grp = (uint32_t)__shfl(top_g, __ffsll((long long)who) - 1);
+            const int owner = __ffsll((long long)who) - 1;
+            const int own_u = __shfl(top_u, owner);
+            const uint32_t grp = (uint32_t)(wid * GPW + owner + own_u * WAVE);
             const uint32_t base = grp * gs;
             uint32_t rk[8];
             uint32_t grank = 0;
@@ -717,9 +728,13 @@ template <class Cell> __global__ void __launch_bounds__(SEL_THREADS) k_iter_sele
                 gt = wave_max_u64(gt);
             }
             const unsigned long long exact = grank ? bound_word(grank, gt) : 0ull;
-            if (lane == 0) {  // no writer races with this kernel: bound and tie are exact, the group is clean again
-                s_ub[grp] = exact;
-                s_seen[grp] = 2;
+            if (lane == owner) {  // no writer races with this kernel: bound and tie are exact, the group is clean again
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (u == own_u) {
+                        ubr[u] = exact;
+                        dr[u] = 2;
+                    }
                 c.ub[grp] = exact;
                 gtie_arr[grp] = gt;
                 c.gdirty[grp] = 0;
@@ -736,9 +751,10 @@ template <class Cell> __global__ void __launch_bounds__(SEL_THREADS) k_iter_sele
         if (floor0) {
             unsigned long long ct = 0;
             bool any = false;
-            for (int q = wid + lane * NW; q < n_groups; q += NW * WAVE)
-                if (s_seen[q] == 0 && s_ub[q] == floor0) {
-                    unsigned long long t = gtie_arr[q];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (dr[u] == 0 && ubr[u] == floor0) {
+                    unsigned long long t = gtie_arr[wid * GPW + lane + u * WAVE];
                     ct = t > ct ? t : ct;
                     any = true;
                 }
@@ -981,7 +997,7 @@ __global__ void __launch_bounds__(UPD_THREADS, 8) __attribute__((amdgpu_num_sgpr
     if (g->done) return;
     const int n_partners = g->n_partners;
     if (n_partners == 0) return;
-    const Ctx c = make_ctx(g);
+    const Ctx c = make_ctx(g, 2 * g->iter - 1);
     const int m = g->m, nb = c.n_bits, Kpad = c.Kpad, n_out = c.n_out;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // LDS: per-wave counters [UPD_WAVES][3][Kpad] | matched columns [m] | consumed digits of A [m] and B [m]
@@ -1544,8 +1560,7 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
         int w = geo[i].wide;
         size_t claim_bytes = ((size_t)geo[i].rcap + 31) / 32 * 4;
         if (claim_bytes > 64 * 1024) claim_bytes = 0;
-        size_t s = (size_t)geo[i].n_groups * 8 + (((size_t)geo[i].n_groups + 7) & ~(size_t)7) + (((size_t)geo[i].n_groups + 3) & ~(size_t)3) * 2 +
-                   6 * (size_t)geo[i].Kpad * 4 + (2 * (size_t)jobs[i].n_out + 1) * 4 + claim_bytes;
+        size_t s = 6 * (size_t)geo[i].Kpad * 4 + (2 * (size_t)jobs[i].n_out + 1) * 4 + claim_bytes;
         s = align_up(s, 16);
         sel_lds[w] = std::max(sel_lds[w], s);
         upd_lds[w] = std::max(upd_lds[w], align_up((size_t)UPD_WAVES * 3 * geo[i].Kpad * 4 + (((size_t)jobs[i].n_out + 1) & ~(size_t)1) * 4 + 2 * (size_t)jobs[i].n_out * (geo[i].wide ? 8 : 4), 16));
