@@ -12,7 +12,9 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -
 cp $OUT/trace/c3_kernel_stats.csv $OUT/kernel_stats.csv 2>/dev/null
 rm -f $OUT/trace/c3_kernel_trace.csv   # large per-dispatch trace: the stats summary is what gets committed
 # PMC passes (counters only, own runs; smaller batch to bound the time)
-for SET in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_WAVES SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum"; do
+# QUICK=1: only the two HBM-traffic passes (the roofline's `traffic` field needs them)
+if [ -n "${QUICK:-}" ]; then SETS=("FETCH_SIZE" "WRITE_SIZE"); else SETS=("FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_WAVES SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum"); fi
+for SET in "${SETS[@]}"; do
   NAME=$(echo $SET | tr ' ' '_' | cut -c1-40)
   timeout 900 rocprofv3 --pmc $SET --output-format csv -d $OUT/pmc_$NAME -o pmc -- python bench.py --steps 1 --warmup 0 --cpu-seconds 0 --batch 16 > $OUT/pmc_$NAME.log 2>&1
   python tools/summarise_pmc.py $OUT/pmc_$NAME > $OUT/pmc_$NAME.summary.txt 2>&1
