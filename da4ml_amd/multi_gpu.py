@@ -114,3 +114,71 @@ def solve_many_sharded(kernels, **opts):
     if parts is None:
         return None
     return [p for part in parts for p in part]
+
+
+def candidate_list(n_in: int, hard_dc: int = -1) -> tuple[list[int], int]:
+    """The ``decompose_dc`` candidates of a searching solve and the ``hard_dc`` each one is run with
+    (reference api.cc:190-201: ``_hard_dc = hard_dc if hard_dc >= 0 else 1e9``; candidates -1 .. min(_hard_dc,
+    ceil(log2f(n_in))))."""
+    import numpy as np
+
+    eff = hard_dc if hard_dc >= 0 else 1_000_000_000
+    top = min(eff, int(np.ceil(np.log2(np.float32(n_in)))))
+    return list(range(-1, top + 1)), eff
+
+
+def pipeline_cost_f32(pipe) -> float:
+    """Candidate cost exactly as the reference accumulates it: float32, sequentially in op order over both stages
+    (api.cc:222-229)."""
+    import numpy as np
+
+    acc = np.float32(0.0)
+    for sol in pipe.solutions:
+        for op in sol.ops:
+            acc = np.float32(acc + np.float32(op.cost))
+    return float(acc)
+
+
+def solve_candidates_sharded(kernel, method0: str = 'wmc', method1: str = 'auto', hard_dc: int = -1, qintervals=None, latencies=None,
+                             adder_size: int = -1, carry_size: int = -1, solver=None):
+    """One searching ``solve`` (``search_all_decompose_dc=True``) with its candidates sharded over the ranks
+    (BASELINE config C4, candidate-sharded variant).
+
+    Candidate ``i`` of the reference's search is exactly ``solve(..., hard_dc=_hard_dc, decompose_dc=dc_i,
+    search_all_decompose_dc=False)`` (api.cc:207-220), so rank ``r`` solves the candidates ``i % world == r`` on its own
+    GPU.  The only exchange steps are the real ones: one all-reduce(MIN) over the candidate cost vector followed by the
+    first-strict-minimum rule (api.cc:243-247), and a broadcast of the winning Pipeline from the rank that owns it.
+    Every rank returns the same Pipeline, identical to the single-process ``solve``.  ``solver`` defaults to the HIP
+    path; the CPU tests inject a stand-in."""
+    import torch.distributed as dist
+
+    rank, world, local, device = init()
+    if solver is None:
+        from . import _binary
+
+        if _binary.device_count() > 0:
+            _binary.set_device(local % _binary.device_count())
+        solver = _binary.solve
+    dcs, eff_hard_dc = candidate_list(int(kernel.shape[0]), hard_dc)
+    mine = {}
+    for i, dc in enumerate(dcs):
+        if i % world == rank:  # interleaved: the expensive low-dc candidates land on different ranks
+            mine[i] = solver(kernel, method0=method0, method1=method1, hard_dc=eff_hard_dc, decompose_dc=dc, qintervals=qintervals,
+                             latencies=latencies, adder_size=adder_size, carry_size=carry_size, search_all_decompose_dc=False)  # fmt: skip
+    import torch
+
+    costs = torch.full((len(dcs),), float('inf'), dtype=torch.float32, device=device)
+    for i, p in mine.items():
+        costs[i] = pipeline_cost_f32(p)
+    if world > 1:
+        dist.all_reduce(costs, op=dist.ReduceOp.MIN)
+    vals = costs.tolist()
+    best = 0
+    for i in range(1, len(vals)):
+        if vals[i] < vals[best]:
+            best = i
+    if world == 1:
+        return mine[best]
+    box = [mine.get(best)]
+    dist.broadcast_object_list(box, src=best % world)
+    return box[0]

@@ -46,6 +46,55 @@ def test_gloo_world2(tmp_path):
     assert r['parts'] == [{'rank': 0, 'shard': [0, 4]}, {'rank': 1, 'shard': [4, 7]}]
 
 
+CAND_WORKER = r'''
+import os, sys, json, hashlib
+sys.path.insert(0, os.environ["DA_ROOT"]); sys.path.insert(0, os.path.join(os.environ["DA_ROOT"], "tests"))
+from da4ml_amd import multi_gpu as mg
+from oracle.oracle import Oracle   # stand-in solver: this host has no GPU
+from cases import int_matrix
+rank, world, local, device = mg.init("gloo")
+O = Oracle("port")
+out = []
+for seed, kw in [(0, {}), (1, {"hard_dc": 2}), (2, {"adder_size": 1, "carry_size": -1})]:
+    k = int_matrix(seed, 16, 16, -128, 128)
+    p = mg.solve_candidates_sharded(k, solver=O.solve, **kw)
+    out.append(bool(p == O.solve(k, **kw)))
+print(json.dumps({"rank": rank, "same": out}))
+'''
+
+
+def test_candidate_sharded_solve_gloo_world2():
+    """C4, candidate-sharded: the candidates of one searching solve split over two ranks give the single-process result
+    on every rank (all-reduce(MIN) of the cost vector + broadcast of the winner)."""
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE='2', LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), DA_ROOT=str(ROOT))
+        procs.append(subprocess.Popen([sys.executable, '-c', CAND_WORKER], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300) for p in procs]
+    import json
+
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0, e
+        r = json.loads(o.strip().splitlines()[-1])
+        assert r['same'] == [True, True, True], r
+
+
+def test_candidate_list_and_cost():
+    from da4ml_amd import multi_gpu as mg
+    from da4ml_amd.types import CombLogic, Op, Pipeline, QInterval
+
+    assert mg.candidate_list(256) == (list(range(-1, 9)), 1_000_000_000)  # reference api.cc:190-201
+    assert mg.candidate_list(16, 2) == ([-1, 0, 1, 2], 2)
+    assert mg.candidate_list(1) == ([-1, 0], 1_000_000_000)
+    q = QInterval(0.0, 1.0, 1.0)
+    ops = [Op(0, -1, -1, 0, q, 0.0, 0.0)] + [Op(0, 0, 0, 0, q, 1.0, 16777216.0), Op(0, 0, 0, 0, q, 1.0, 1.0), Op(0, 0, 0, 0, q, 1.0, 1.0)]
+    pipe = Pipeline((CombLogic((1, 1), [0], [3], [0], [False], ops, -1, -1),))
+    assert mg.pipeline_cost_f32(pipe) == 16777216.0  # float32 accumulation in op order, like api.cc:222-229 (2**24 + 1 rounds back)
+
+
 def test_shard_bounds_cover():
     from da4ml_amd.multi_gpu import shard_bounds
 
