@@ -92,6 +92,30 @@ struct HStat {
     float dl;
 };
 
+// Pointers read from a chain descriptor are "generic" pointers to the compiler, which emits FLAT memory instructions
+// for them.  FLAT operations count in BOTH vmcnt and lgkmcnt, so every LDS wait (lgkmcnt(0)) would also wait for all
+// global loads in flight and serialise the software-pipelined loads of the greedy-loop kernels.  The hot kernels
+// therefore keep their table / cell / list pointers in the global address space (GLOBAL instructions, vmcnt only).
+#define DA_GLOBAL __attribute__((address_space(1)))
+template <class T> __device__ __forceinline__ T *gen(DA_GLOBAL T *p) { return (T *)p; }  // for the HIP atomic API
+typedef float da_f4 __attribute__((ext_vector_type(4)));
+typedef int da_i4 __attribute__((ext_vector_type(4)));
+typedef unsigned int da_u2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ RowInfo load_row(const DA_GLOBAL RowInfo *rows, size_t i) {
+    const da_f4 v = *reinterpret_cast<const DA_GLOBAL da_f4 *>(rows + i);
+    return RowInfo{v.x, v.y, v.z, v.w};
+}
+__device__ __forceinline__ void store_row(DA_GLOBAL RowInfo *rows, size_t i, const RowInfo &r) {
+    *reinterpret_cast<DA_GLOBAL da_f4 *>(rows + i) = da_f4{r.lo, r.hi, r.step, r.lat};
+}
+__device__ __forceinline__ HStat load_hstat(const DA_GLOBAL HStat *p, size_t i) {
+    const da_u2 v = *reinterpret_cast<const DA_GLOBAL da_u2 *>(p + i);
+    return HStat{(int)v.x, __uint_as_float(v.y)};
+}
+__device__ __forceinline__ void store_hstat(DA_GLOBAL HStat *p, size_t i, int ov, float dl) {
+    *reinterpret_cast<DA_GLOBAL da_u2 *>(p + i) = da_u2{(unsigned)ov, __float_as_uint(dl)};
+}
+
 // Per-chain descriptor in device memory.  Pointers are raw device addresses into the arena.
 struct ChainDev {
     // geometry (constant after set-up)
@@ -205,15 +229,15 @@ __device__ __forceinline__ unsigned long long bound_word(uint32_t rank, unsigned
 struct Ctx {
     int n_out, n_bits, K, Kpad, method, gs_log2;
     uint32_t cmask, windows;
-    unsigned long long *hkey;
-    uint32_t *hrank;
-    uint8_t *hidx;
-    HStat *hstat;
-    uint16_t *hcnt;
-    unsigned long long *ub;
-    uint8_t *gdirty;
-    const RowInfo *rows;
-    ChainDev *g;
+    DA_GLOBAL unsigned long long *hkey;
+    DA_GLOBAL uint32_t *hrank;
+    DA_GLOBAL uint8_t *hidx;
+    DA_GLOBAL HStat *hstat;
+    DA_GLOBAL uint16_t *hcnt;
+    DA_GLOBAL unsigned long long *ub;
+    DA_GLOBAL uint8_t *gdirty;
+    const DA_GLOBAL RowInfo *rows;
+    ChainDev *g;  // derived from the kernel argument: already known to be global
     unsigned long long tomb;  // this launch's tombstone value
 };
 // launch_id: 2 * iteration for k_iter_select, 2 * iteration + 1 for k_iter_update (only the low two bits are used)
@@ -228,14 +252,14 @@ __device__ __forceinline__ Ctx make_ctx(ChainDev *g, int launch_id) {
     c.gs_log2 = g->gs_log2;
     c.cmask = g->cmask;
     c.windows = g->C / WAVE ? g->C / WAVE : 1;
-    c.hkey = g->hkey;
-    c.hrank = g->hrank;
-    c.hidx = g->hidx;
-    c.hstat = g->hstat;
-    c.hcnt = g->hcnt;
-    c.ub = g->ub;
-    c.gdirty = g->gdirty;
-    c.rows = g->rows;
+    c.hkey = (DA_GLOBAL unsigned long long *)g->hkey;
+    c.hrank = (DA_GLOBAL uint32_t *)g->hrank;
+    c.hidx = (DA_GLOBAL uint8_t *)g->hidx;
+    c.hstat = (DA_GLOBAL HStat *)g->hstat;
+    c.hcnt = (DA_GLOBAL uint16_t *)g->hcnt;
+    c.ub = (DA_GLOBAL unsigned long long *)g->ub;
+    c.gdirty = (DA_GLOBAL uint8_t *)g->gdirty;
+    c.rows = (const DA_GLOBAL RowInfo *)g->rows;
     c.g = g;
     return c;
 }
@@ -297,7 +321,7 @@ __device__ int table_claim(const Ctx &c, unsigned long long key, uint32_t h) {
             avail &= avail - 1;
             int ok = 0;
             if (lane == l) {
-                ok = atomicCAS(&c.hkey[s], kk, key) == kk;
+                ok = atomicCAS(gen(&c.hkey[s]), kk, key) == kk;
                 if (ok && kk == KEY_EMPTY) atomicAdd(&c.g->n_used, 1u);
             }
             ok = __shfl(ok, l);
@@ -332,11 +356,11 @@ __device__ bool table_insert(const Ctx &c, uint32_t lo, uint32_t hi, const RowIn
     best = wave_max_u64(best);
     if (lane == 0) {
         uint32_t rank = (uint32_t)(best >> 8);
-        c.hstat[slot] = HStat{ov, dl};
+        store_hstat(c.hstat, slot, ov, dl);
         c.hrank[slot] = rank;
         c.hidx[slot] = (uint8_t)(best & 0xFF);
         if (rank) {
-            atomicMax(&c.ub[slot >> c.gs_log2], bound_word(rank, tie_word(lo, hi, (int)(best & 0xFF))));
+            atomicMax(gen(&c.ub[slot >> c.gs_log2]), bound_word(rank, tie_word(lo, hi, (int)(best & 0xFF))));
             c.gdirty[slot >> c.gs_log2] = 1;
         }
         atomicAdd(&c.g->n_live, 1u);  // no return value: fire-and-forget (the peak is sampled by k_iter_select)
@@ -348,7 +372,7 @@ __device__ bool table_insert(const Ctx &c, uint32_t lo, uint32_t hi, const RowIn
 template <class CntFn>
 __device__ void table_update(const Ctx &c, int slot, unsigned long long key, CntFn new_cnt) {
     int lane = lane_id();
-    HStat st = c.hstat[slot];
+    HStat st = load_hstat(c.hstat, slot);
     uint32_t prev = c.hrank[slot], prev_idx = c.hidx[slot];
     unsigned long long best = 0;
     int alive = 0;
@@ -374,7 +398,7 @@ __device__ void table_update(const Ctx &c, int slot, unsigned long long key, Cnt
             if (rank != prev) c.hrank[slot] = rank;
             if (idx != prev_idx) c.hidx[slot] = (uint8_t)idx;
             if (rank > prev)
-                atomicMax(&c.ub[slot >> c.gs_log2], bound_word(rank, tie_word((uint32_t)key, (uint32_t)(key >> 32), (int)idx)));
+                atomicMax(gen(&c.ub[slot >> c.gs_log2]), bound_word(rank, tie_word((uint32_t)key, (uint32_t)(key >> 32), (int)idx)));
             if (rank != prev || (rank && idx != prev_idx)) c.gdirty[slot >> c.gs_log2] = 1;
         }
     }
@@ -386,7 +410,7 @@ __device__ __forceinline__ void table_update_pair(const Ctx &c, int slot0, unsig
                                                   unsigned long long key1, const uint32_t *d1) {
     const int lane = lane_id();
     const bool h0 = slot0 >= 0, h1 = slot1 >= 0;
-    HStat st0 = h0 ? c.hstat[slot0] : HStat{0, 0.0f}, st1 = h1 ? c.hstat[slot1] : HStat{0, 0.0f};
+    HStat st0 = h0 ? load_hstat(c.hstat, slot0) : HStat{0, 0.0f}, st1 = h1 ? load_hstat(c.hstat, slot1) : HStat{0, 0.0f};
     uint32_t prev0 = h0 ? c.hrank[slot0] : 0u, prev1 = h1 ? c.hrank[slot1] : 0u;
     uint32_t pidx0 = h0 ? c.hidx[slot0] : 0u, pidx1 = h1 ? c.hidx[slot1] : 0u;
     uint32_t o0[2] = {0, 0}, o1[2] = {0, 0};
@@ -438,7 +462,7 @@ __device__ __forceinline__ void table_update_pair(const Ctx &c, int slot0, unsig
                 if (rank != prev0) c.hrank[slot0] = rank;
                 if (idx != pidx0) c.hidx[slot0] = (uint8_t)idx;
                 if (rank > prev0)
-                    atomicMax(&c.ub[slot0 >> c.gs_log2], bound_word(rank, tie_word((uint32_t)key0, (uint32_t)(key0 >> 32), (int)idx)));
+                    atomicMax(gen(&c.ub[slot0 >> c.gs_log2]), bound_word(rank, tie_word((uint32_t)key0, (uint32_t)(key0 >> 32), (int)idx)));
                 if (rank != prev0 || (rank && idx != pidx0)) c.gdirty[slot0 >> c.gs_log2] = 1;
             }
         }
@@ -453,7 +477,7 @@ __device__ __forceinline__ void table_update_pair(const Ctx &c, int slot0, unsig
                 if (rank != prev1) c.hrank[slot1] = rank;
                 if (idx != pidx1) c.hidx[slot1] = (uint8_t)idx;
                 if (rank > prev1)
-                    atomicMax(&c.ub[slot1 >> c.gs_log2], bound_word(rank, tie_word((uint32_t)key1, (uint32_t)(key1 >> 32), (int)idx)));
+                    atomicMax(gen(&c.ub[slot1 >> c.gs_log2]), bound_word(rank, tie_word((uint32_t)key1, (uint32_t)(key1 >> 32), (int)idx)));
                 if (rank != prev1 || (rank && idx != pidx1)) c.gdirty[slot1 >> c.gs_log2] = 1;
             }
         }
@@ -601,7 +625,7 @@ template <class Cell> __global__ void __launch_bounds__(256) k_init_pairs(ChainD
         if (lane_id() == 0) g->unknown_hit = 1;
         return;
     }
-    table_insert(c, lo, hi, c.rows[lo], c.rows[hi], [&](int k) { return cnt[k]; });
+    table_insert(c, lo, hi, load_row(c.rows, lo), load_row(c.rows, hi), [&](int k) { return cnt[k]; });
 }
 
 // ------------------------------------------------------------------------------------------------ k_iter_select
@@ -681,7 +705,7 @@ template <class Cell> __global__ void __launch_bounds__(SEL_THREADS) k_iter_sele
         uint32_t wrank = 0;
         unsigned long long wtie = 0;
         unsigned int rescans = 0;
-        unsigned long long *gtie_arr = g->gtie;
+        DA_GLOBAL unsigned long long *gtie_arr = (DA_GLOBAL unsigned long long *)g->gtie;
         while (true) {
             unsigned long long top = 0;
             int top_u = 0;
@@ -808,25 +832,25 @@ template <class Cell> __global__ void __launch_bounds__(SEL_THREADS) k_iter_sele
 
     // ---------------- (2) new row record + substitution
     if (tid == 0) {
-        RowInfo ra = c.rows[A], rb = c.rows[B], rn;
+        RowInfo ra = load_row(c.rows, A), rb = load_row(c.rows, B), rn;
         int derr = 0;
         qint_add_pair(ra, rb, shift, sub, rn.lo, rn.hi, rn.step);
         float dlat = adder_dlat(ra, rb, shift, sub, g->adder_size, g->carry_size, c_log2, derr);
         rn.lat = (ra.lat < rb.lat ? rb.lat : ra.lat) + dlat;
         if (derr) g->error = E_FLOAT_DOMAIN;
-        g->rows[Nw] = rn;
+        store_row((DA_GLOBAL RowInfo *)g->rows, Nw, rn);
         s_new = rn;
-        g->picks[iter] = make_int4((int)A, (int)B, sub, shift);
+        reinterpret_cast<DA_GLOBAL da_i4 *>((DA_GLOBAL int4 *)g->picks)[iter] = da_i4{(int)A, (int)B, sub, shift};
         if (g->n_live > g->live_peak) g->live_peak = g->n_live;
     }
     for (int k = tid; k < 6 * Kpad; k += SEL_THREADS) s_cnt[k] = 0;
     __syncthreads();
     tp[3] = clock64();
-    Cell *cells = reinterpret_cast<Cell *>(g->cells);
-    Cell *rowA = cells + (size_t)A * n_out, *rowB = cells + (size_t)B * n_out, *rowN = cells + (size_t)Nw * n_out;
-    Cell *mA = reinterpret_cast<Cell *>(g->mA), *mB = reinterpret_cast<Cell *>(g->mB);
-    int *mcol = g->mcol, *collen = g->collen;
-    uint32_t *collist = g->collist;
+    DA_GLOBAL Cell *cells = (DA_GLOBAL Cell *)g->cells;
+    DA_GLOBAL Cell *rowA = cells + (size_t)A * n_out, *rowB = cells + (size_t)B * n_out, *rowN = cells + (size_t)Nw * n_out;
+    DA_GLOBAL Cell *mA = (DA_GLOBAL Cell *)g->mA, *mB = (DA_GLOBAL Cell *)g->mB;
+    DA_GLOBAL int *mcol = (DA_GLOBAL int *)g->mcol, *collen = (DA_GLOBAL int *)g->collen;
+    DA_GLOBAL uint32_t *collist = (DA_GLOBAL uint32_t *)g->collist;
     uint32_t *cAA = s_cnt, *cAB = s_cnt + Kpad, *cBB = s_cnt + 2 * Kpad, *cAN = s_cnt + 3 * Kpad, *cBN = s_cnt + 4 * Kpad,
              *cNN = s_cnt + 5 * Kpad;
     unsigned int my_matches = 0;
@@ -908,7 +932,7 @@ template <class Cell> __global__ void __launch_bounds__(SEL_THREADS) k_iter_sele
     // partner list -- by the first NW-6 waves; the last six waves store the six special pairs meanwhile.
     constexpr int CLAIM_WAVES = NW - 6, CLAIM_THREADS = CLAIM_WAVES * WAVE;
     if (wid < CLAIM_WAVES) {
-        uint32_t *stamp = g->stamp, *plist = g->plist;
+        DA_GLOBAL uint32_t *stamp = (DA_GLOBAL uint32_t *)g->stamp, *plist = (DA_GLOBAL uint32_t *)g->plist;
         const uint32_t tag = (uint32_t)iter + 1u;
         for (int f0 = tid; f0 < total; f0 += 4 * CLAIM_THREADS) {
             uint32_t r[4];
@@ -940,7 +964,7 @@ template <class Cell> __global__ void __launch_bounds__(SEL_THREADS) k_iter_sele
                     const uint32_t bit = 1u << (r[u] & 31);
                     ok[u] = (atomicOr(&s_bits[r[u] >> 5], bit) & bit) == 0;
                 } else
-                    ok[u] = atomicExch(&stamp[r[u]], tag) != tag;
+                    ok[u] = atomicExch(gen(&stamp[r[u]]), tag) != tag;
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u)
@@ -965,7 +989,7 @@ template <class Cell> __global__ void __launch_bounds__(SEL_THREADS) k_iter_sele
             if (slot >= 0)
                 table_update(c, slot, key, [&](int k, uint32_t) { return cnt[k]; });
             else if (wave_any_ge2(cnt, c.K)) {
-                RowInfo ra = c.rows[lo], rb = hi == Nw ? s_new : c.rows[hi];
+                RowInfo ra = load_row(c.rows, lo), rb = hi == Nw ? s_new : load_row(c.rows, hi);
                 if (lo == Nw) ra = s_new;
                 table_insert(c, lo, hi, ra, rb, [&](int k) { return cnt[k]; });
             }
@@ -1007,8 +1031,8 @@ __global__ void __launch_bounds__(UPD_THREADS, 8) __attribute__((amdgpu_num_sgpr
     Cell *s_mB = s_mA + n_out;
     const int tid = threadIdx.x, lane = lane_id(), wid = wave_id();
     {
-        const int *mcol = g->mcol;
-        const Cell *mA = reinterpret_cast<const Cell *>(g->mA), *mB = reinterpret_cast<const Cell *>(g->mB);
+        const DA_GLOBAL int *mcol = (const DA_GLOBAL int *)g->mcol;
+        const DA_GLOBAL Cell *mA = (const DA_GLOBAL Cell *)g->mA, *mB = (const DA_GLOBAL Cell *)g->mB;
         for (int j = tid; j < m; j += UPD_THREADS) {
             s_col[j] = mcol[j];
             s_mA[j] = mA[j];
@@ -1018,9 +1042,9 @@ __global__ void __launch_bounds__(UPD_THREADS, 8) __attribute__((amdgpu_num_sgpr
     __syncthreads();
     const uint32_t A = g->A, B = g->B, Nw = g->Nw;
     const bool same = A == B;
-    const Cell *cells = reinterpret_cast<const Cell *>(g->cells);
-    const uint32_t *plist = g->plist;
-    const RowInfo rnew = c.rows[Nw];
+    const DA_GLOBAL Cell *cells = (const DA_GLOBAL Cell *)g->cells;
+    const DA_GLOBAL uint32_t *plist = (const DA_GLOBAL uint32_t *)g->plist;
+    const RowInfo rnew = load_row(c.rows, Nw);
     uint32_t *dA = s_cnt + (size_t)wid * 3 * Kpad, *dB = dA + Kpad, *cN = dB + Kpad;
     unsigned int partners = 0, found = 0, inserts = 0;
     UPD_TIMER_DECL
@@ -1056,7 +1080,7 @@ __global__ void __launch_bounds__(UPD_THREADS, 8) __attribute__((amdgpu_num_sgpr
             issue(prn, x0n, kkn);
         }
         ++partners;
-        const Cell *rowR = cells + (size_t)pr * n_out;
+        const DA_GLOBAL Cell *rowR = cells + (size_t)pr * n_out;
         const uint32_t lA = min(A, pr), hA = max(A, pr), lB = min(B, pr), hB = max(B, pr);
         const unsigned long long keyA = pack_pair(lA, hA), keyB = pack_pair(lB, hB);
         // resolve the two first-bucket probes (lanes 0-15: block with A, lanes 16-31: block with B)
@@ -1098,7 +1122,7 @@ __global__ void __launch_bounds__(UPD_THREADS, 8) __attribute__((amdgpu_num_sgpr
         found += (slotA >= 0) + (slotB >= 0);
         UPD_TIMER_MARK(3)  // block updates
         if (__any(got_new)) {
-            table_insert(c, pr, Nw, c.rows[pr], rnew, [&](int k) { return cN[k]; });
+            table_insert(c, pr, Nw, load_row(c.rows, pr), rnew, [&](int k) { return cN[k]; });
             ++inserts;
         }
         UPD_TIMER_MARK(4)  // block creation
