@@ -1056,10 +1056,21 @@ __global__ void __launch_bounds__(UPD_THREADS, 8) __attribute__((amdgpu_num_sgpr
     const bool second = lane >= (int)BUCKET;
     const bool probing = lane < (int)BUCKET || (!same && lane < 2 * (int)BUCKET);
     auto issue = [&](uint32_t row, Cell &x0, unsigned long long &kk) {
+#ifdef DA_UNCOND_PREFETCH
+        // EXPERIMENT (not yet measured): every lane loads, with clamped indices and no branch around the loads.  The
+        // loads of the NEXT partner then no longer sit behind exec-masked branches, and the first enumeration pass
+        // (below) uses the prefetched cell without any load, so nothing forces a vmcnt(0) wait on the loads issued
+        // just before for the next partner.
+        const uint32_t other = second ? B : A;
+        const uint32_t h = hash_pair(min(other, row), max(other, row));
+        x0 = cells[(size_t)row * n_out + s_col[min(lane, m - 1)]];  // lanes >= m: a valid but unused cell
+        kk = c.hkey[((h & ~(BUCKET - 1)) & c.cmask) + (lane & (BUCKET - 1))];
+#else
         x0 = lane < m ? cells[(size_t)row * n_out + s_col[lane]] : (Cell)0;
         const uint32_t other = second ? B : A;
         const uint32_t h = hash_pair(min(other, row), max(other, row));
         kk = probing ? c.hkey[((h & ~(BUCKET - 1)) & c.cmask) + (lane & (BUCKET - 1))] : KEY_TOMB;
+#endif
     };
     uint32_t pr = 0, pr_next = 0;
     Cell x0 = 0;
@@ -1067,7 +1078,11 @@ __global__ void __launch_bounds__(UPD_THREADS, 8) __attribute__((amdgpu_num_sgpr
     if (first < n_partners) {
         pr = plist[first];
         issue(pr, x0, kk);
+#ifdef DA_UNCOND_PREFETCH
+        pr_next = plist[min(first + total_waves, n_partners - 1)];
+#else
         if (first + total_waves < n_partners) pr_next = plist[first + total_waves];
+#endif
     }
     for (int q = first; q < n_partners; q += total_waves) {
         // next partner: loads in flight during this partner's processing
@@ -1075,10 +1090,16 @@ __global__ void __launch_bounds__(UPD_THREADS, 8) __attribute__((amdgpu_num_sgpr
         const uint32_t prn = pr_next;
         Cell x0n = 0;
         unsigned long long kkn = KEY_TOMB;
+#ifdef DA_UNCOND_PREFETCH
+        pr_next = plist[min(q + 2 * total_waves, n_partners - 1)];  // past the end: re-reads the last entry, unused
+        issue(prn, x0n, kkn);
+        (void)has_next;
+#else
         if (has_next) {
             if (q + 2 * total_waves < n_partners) pr_next = plist[q + 2 * total_waves];
             issue(prn, x0n, kkn);
         }
+#endif
         ++partners;
         const DA_GLOBAL Cell *rowR = cells + (size_t)pr * n_out;
         const uint32_t lA = min(A, pr), hA = max(A, pr), lB = min(B, pr), hB = max(B, pr);
@@ -1105,6 +1126,24 @@ __global__ void __launch_bounds__(UPD_THREADS, 8) __attribute__((amdgpu_num_sgpr
         for (int k = lane; k < 3 * Kpad; k += WAVE) dA[k] = 0;
         lds_fence();
         int got_new = 0;
+#ifdef DA_UNCOND_PREFETCH
+        auto enumerate = [&](int j, Cell x) {
+            if (!x) return;
+            Cell ma = s_mA[j], mb = s_mB[j];
+            if (slotA >= 0) {
+                for_pairs_part<Cell>(ma, x, A < pr, nb, [&](int k) { atomicAdd(&dA[k], 1u); });
+                if (same) for_pairs_part<Cell>(mb, x, A < pr, nb, [&](int k) { atomicAdd(&dA[k], 1u); });
+            }
+            if (!same && slotB >= 0) for_pairs_part<Cell>(mb, x, B < pr, nb, [&](int k) { atomicAdd(&dB[k], 1u); });
+#ifdef DA_NORTN_ATOMICS
+            for_pairs_cross<Cell>(x, ma, nb, [&](int k) { atomicAdd(&cN[k], 1u); });  // no return value: not waited for
+#else
+            for_pairs_cross<Cell>(x, ma, nb, [&](int k) { got_new |= atomicAdd(&cN[k], 1u) >= 1u; });
+#endif
+        };
+        if (lane < m) enumerate(lane, x0);  // the prefetched cell: no load, no wait on the younger loads
+        for (int j = lane + WAVE; j < m; j += WAVE) enumerate(j, rowR[s_col[j]]);  // m > 64 only
+#else
         for (int j = lane; j < m; j += WAVE) {
             Cell x = j == lane ? x0 : rowR[s_col[j]];
             if (!x) continue;
@@ -1114,9 +1153,18 @@ __global__ void __launch_bounds__(UPD_THREADS, 8) __attribute__((amdgpu_num_sgpr
                 if (same) for_pairs_part<Cell>(mb, x, A < pr, nb, [&](int k) { atomicAdd(&dA[k], 1u); });
             }
             if (!same && slotB >= 0) for_pairs_part<Cell>(mb, x, B < pr, nb, [&](int k) { atomicAdd(&dB[k], 1u); });
+#ifdef DA_NORTN_ATOMICS
+            for_pairs_cross<Cell>(x, ma, nb, [&](int k) { atomicAdd(&cN[k], 1u); });
+#else
             for_pairs_cross<Cell>(x, ma, nb, [&](int k) { got_new |= atomicAdd(&cN[k], 1u) >= 1u; });
+#endif
         }
+#endif
         lds_fence();
+#ifdef DA_NORTN_ATOMICS
+        // EXPERIMENT (not yet measured): fire-and-forget LDS adds above, one scan of the new block's counters here
+        for (int k = lane; k < c.K; k += WAVE) got_new |= cN[k] >= 2u;
+#endif
         UPD_TIMER_MARK(2)  // cells + pair enumeration
         if (slotA >= 0 || slotB >= 0) table_update_pair(c, slotA, keyA, dA, slotB, keyB, dB);
         found += (slotA >= 0) + (slotB >= 0);
