@@ -15,6 +15,7 @@
 #include <limits>
 #include <memory>
 #include <mutex>
+#include <unordered_map>
 #include <thread>
 
 namespace da {
@@ -380,7 +381,76 @@ float max_out_latency(const StageResult &s) {
 
 }  // namespace
 
+namespace {
+std::vector<PipeResult> solve_batch_unique(Backend &be, const std::vector<Problem> &problems, std::vector<ChainStats> *stats);
+
+bool same_problem(const Problem &a, const Problem &b) {
+    const SolveOptions &x = a.opt, &y = b.opt;
+    if (a.n_in != b.n_in || a.n_out != b.n_out || x.hard_dc != y.hard_dc || x.decompose_dc != y.decompose_dc || x.adder_size != y.adder_size ||
+        x.carry_size != y.carry_size || x.search_all != y.search_all || x.method0 != y.method0 || x.method1 != y.method1 ||
+        x.qints.size() != y.qints.size() || x.lats.size() != y.lats.size())
+        return false;
+    // bitwise comparisons: anything that is not literally the same input is simply solved again
+    if (!x.qints.empty() && std::memcmp(x.qints.data(), y.qints.data(), sizeof(QInt) * x.qints.size()) != 0) return false;
+    if (!x.lats.empty() && std::memcmp(x.lats.data(), y.lats.data(), sizeof(float) * x.lats.size()) != 0) return false;
+    return a.kernel == b.kernel || std::memcmp(a.kernel, b.kernel, sizeof(float) * (size_t)a.n_in * a.n_out) == 0;
+}
+uint64_t problem_hash(const Problem &p) {
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&](const void *data, size_t n) {
+        const unsigned char *b = static_cast<const unsigned char *>(data);
+        for (size_t i = 0; i < n; ++i) h = (h ^ b[i]) * 1099511628211ull;
+    };
+    mix(&p.n_in, sizeof p.n_in);
+    mix(&p.n_out, sizeof p.n_out);
+    mix(p.kernel, sizeof(float) * (size_t)p.n_in * p.n_out);
+    if (!p.opt.qints.empty()) mix(p.opt.qints.data(), sizeof(QInt) * p.opt.qints.size());
+    if (!p.opt.lats.empty()) mix(p.opt.lats.data(), sizeof(float) * p.opt.lats.size());
+    return h;
+}
+}  // namespace
+
+// Identical problems of a batch (same matrix, options, intervals and latencies -- the tracer's loop over the row
+// vectors of a traced tensor, reference trace/fixed_variable_array.py:368-371, produces many) are solved once and the
+// result is copied.  The solver is deterministic, so this cannot change any result.
 std::vector<PipeResult> solve_batch(Backend &be, const std::vector<Problem> &problems, std::vector<ChainStats> *stats) {
+    const size_t n = problems.size();
+    std::vector<int> rep(n);
+    std::vector<Problem> uniq;
+    std::unordered_multimap<uint64_t, int> seen;
+    for (size_t i = 0; i < n; ++i) {
+        if (problems[i].n_in <= 0 || problems[i].n_out <= 0 || !problems[i].kernel) throw std::invalid_argument("kernel must be a non-empty 2-D matrix");
+        const uint64_t h = problem_hash(problems[i]);
+        int found = -1;
+        auto range = seen.equal_range(h);
+        for (auto it = range.first; it != range.second && found < 0; ++it)
+            if (same_problem(uniq[it->second], problems[i])) found = it->second;
+        if (found < 0) {
+            found = (int)uniq.size();
+            uniq.push_back(problems[i]);
+            seen.emplace(h, found);
+        }
+        rep[i] = found;
+    }
+    if (uniq.size() == n) return solve_batch_unique(be, problems, stats);
+    std::vector<ChainStats> ustats;
+    std::vector<PipeResult> ures = solve_batch_unique(be, uniq, &ustats);
+    std::vector<PipeResult> res(n);
+    if (stats) stats->assign(n, ChainStats{});
+    for (size_t i = n; i-- > 0;) {  // the first occurrence (visited last) takes the original, later ones copies
+        bool first = true;
+        for (size_t j = 0; j < i && first; ++j) first = rep[j] != rep[i];
+        if (first) {
+            res[i] = std::move(ures[rep[i]]);
+            if (stats && rep[i] < (int)ustats.size()) (*stats)[i] = ustats[rep[i]];  // work is attributed to the first occurrence only
+        } else
+            res[i] = ures[rep[i]];
+    }
+    return res;
+}
+
+namespace {
+std::vector<PipeResult> solve_batch_unique(Backend &be, const std::vector<Problem> &problems, std::vector<ChainStats> *stats) {
     std::vector<ProblemState> ps(problems.size());
     std::vector<Candidate> cands;
     for (size_t i = 0; i < problems.size(); ++i) {
@@ -572,5 +642,7 @@ std::vector<PipeResult> solve_batch(Backend &be, const std::vector<Problem> &pro
     }
     return results;
 }
+
+}  // namespace
 
 }  // namespace da

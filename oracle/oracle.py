@@ -147,6 +147,33 @@ class Oracle:
                             adder_size, carry_size, int(search_all_decompose_dc))  # fmt: skip
         return self._collect(h, stats)
 
+    def solve_many(self, kernels, method0='wmc', method1='auto', hard_dc=-1, decompose_dc=-2, qintervals=None, latencies=None,
+                   adder_size=-1, carry_size=-1, search_all_decompose_dc=True):  # fmt: skip
+        """Batch through the product's host logic (``da::solve_batch``) on the sequential engine model; 'model' only.
+        ``qintervals`` / ``latencies``: None or one entry (possibly None) per kernel."""
+        assert self.kind == 'model'
+        ks = [np.ascontiguousarray(k, dtype=np.float32) for k in kernels]
+        n = len(ks)
+        qs, ls = [], []
+        for i, k in enumerate(ks):
+            q, l = self._opt(None if qintervals is None else qintervals[i], None if latencies is None else latencies[i], k.shape[0])
+            qs.append(q)
+            ls.append(l)
+        ptr = lambda arrs: (C.c_void_p * n)(*[None if a is None else a.ctypes.data for a in arrs])  # noqa: E731
+        fn = self.lib.mdl_solve_batch
+        fn.argtypes = [C.c_int, C.c_void_p, _i64p, _i64p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]  # fmt: skip
+        res = (C.c_void_p * n)()
+        rc = fn(n, ptr(ks), np.array([k.shape[0] for k in ks], np.int64), np.array([k.shape[1] for k in ks], np.int64), method0.encode(),
+                method1.encode(), hard_dc, decompose_dc, ptr(qs), ptr(ls), adder_size, carry_size, int(search_all_decompose_dc), res)  # fmt: skip
+        if rc != 0:
+            raise RuntimeError(self.g('last_error')().decode())
+        return [self._collect(res[i]) for i in range(n)]
+
+    def chains_run(self, reset=True) -> int:
+        """Chains handed to the model backend since the last reset ('model' only)."""
+        self.lib.mdl_chains_run.restype = C.c_longlong
+        return int(self.lib.mdl_chains_run(int(reset)))
+
     def solve_single(self, kernel, method='wmc', qintervals=None, latencies=None, adder_size=-1, carry_size=-1, stats=False):
         """One greedy chain + adder tree on ``kernel`` (reference cmvm_core.cc:227-237); 'port' only."""
         k = np.ascontiguousarray(kernel, dtype=np.float32)

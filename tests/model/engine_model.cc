@@ -252,9 +252,12 @@ template <class Cell> struct Chain {
     }
 };
 
+long long g_chains_run = 0;  // chains handed to the backend since the last reset (memoisation test)
+
 class ModelBackend : public Backend {
   public:
     void run_chains(const ChainJob *jobs, ChainOut *outs, int n) override {
+        g_chains_run += n;
         for (int i = 0; i < n; ++i) {
             // pick the cell width from the digit width, as the device does
             std::vector<float> a(jobs[i].kernel, jobs[i].kernel + (size_t)jobs[i].n_in * jobs[i].n_out);
@@ -372,6 +375,43 @@ void *mdl_solve(const float *kernel, int64_t n_in, int64_t n_out, const char *me
         g_err = e.what();
         return nullptr;
     }
+}
+// batch of problems sharing the option set (the shape of da_solve_batch); qints3 / lats: per-problem pointers or NULL
+int mdl_solve_batch(int count, const float *const *kernels, const int64_t *n_in, const int64_t *n_out, const char *method0, const char *method1,
+                    int hard_dc, int decompose_dc, const float *const *qints3, const float *const *lats, int adder_size, int carry_size,
+                    int search_all, void **results) {
+    try {
+        ModelBackend be;
+        std::vector<da::Problem> probs((size_t)count);
+        for (int i = 0; i < count; ++i) {
+            da::Problem &p = probs[i];
+            p.kernel = kernels[i];
+            p.n_in = (int)n_in[i];
+            p.n_out = (int)n_out[i];
+            p.opt.method0 = method0;
+            p.opt.method1 = method1;
+            p.opt.hard_dc = hard_dc;
+            p.opt.decompose_dc = decompose_dc;
+            if (qints3 && qints3[i])
+                for (int64_t r = 0; r < n_in[i]; ++r) p.opt.qints.push_back(da::QInt{qints3[i][3 * r], qints3[i][3 * r + 1], qints3[i][3 * r + 2]});
+            if (lats && lats[i]) p.opt.lats.assign(lats[i], lats[i] + n_in[i]);
+            p.opt.adder_size = adder_size;
+            p.opt.carry_size = carry_size;
+            p.opt.search_all = search_all != 0;
+        }
+        std::vector<da::ChainStats> st;
+        auto res = da::solve_batch(be, probs, &st);
+        for (int i = 0; i < count; ++i) results[i] = new Result{std::move(res[i]), i < (int)st.size() ? st[i] : da::ChainStats{}};
+        return 0;
+    } catch (const std::exception &e) {
+        g_err = e.what();
+        return -1;
+    }
+}
+long long mdl_chains_run(int reset) {
+    long long v = g_chains_run;
+    if (reset) g_chains_run = 0;
+    return v;
 }
 int mdl_n_stages(void *h) { return (int)((Result *)h)->pipe.stages.size(); }
 int mdl_picked(void *h) { return ((Result *)h)->pipe.picked; }

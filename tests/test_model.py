@@ -78,3 +78,25 @@ def test_unknown_method(model):
         model.solve(int_matrix(0, 8, 8, -8, 8), method0='nope', search_all_decompose_dc=False)
     # the reference only throws once the table is non-empty (cmvm_core.cc:36-64): a trivial matrix passes
     model.solve(np.eye(2, dtype=np.float32), method0='nope', method1='nope', search_all_decompose_dc=False)
+
+
+def test_batch_memoises_identical_problems(oracle):
+    """identical (matrix, intervals, latencies) problems of one batch are solved once; results are
+    what the individual solves give, in input order, and only the unique problems reach the backend."""
+    from oracle.oracle import Oracle
+
+    model = Oracle('model')
+    k0, k1 = int_matrix(0, 10, 8, -32, 32), int_matrix(1, 10, 8, -32, 32)
+    q_a = [(-8.0, 7.0, 1.0)] * 10
+    q_b = [(-4.0, 3.5, 0.5)] * 10
+    kernels = [k0, k1, k0.copy(), k0, k1, k0]
+    qints = [q_a, q_a, q_a, q_b, q_a, None]  # 0 == 2, 1 == 4; 3 and 5 differ from 0 in their intervals
+    model.chains_run(reset=True)
+    got = model.solve_many(kernels, qintervals=qints, adder_size=1, carry_size=-1)
+    batch_chains = model.chains_run(reset=True)
+    want = [oracle.solve(k, qintervals=q, adder_size=1, carry_size=-1) for k, q in zip(kernels, qints)]
+    assert got == want
+    uniq = [0, 1, 3, 5]
+    model.solve_many([kernels[i] for i in uniq], qintervals=[qints[i] for i in uniq], adder_size=1, carry_size=-1)
+    assert batch_chains == model.chains_run(reset=True)
+    assert got[0] == got[2] and got[1] == got[4] and got[0] != got[3]
