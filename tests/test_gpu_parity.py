@@ -144,12 +144,14 @@ def test_default_search_96(hip, oracle):
 
 def test_default_search_256_functional(hip):
     """BASELINE C3 (i): default solve of the 256x256 int8 matrix; the CPU oracle needs hours for this one, so the check is
-    the reference's own functional criterion (tests/test_cmvm.py:55) plus agreement of two runs"""
-    k = int_matrix(0, 256, 256, -128, 128)
+    the reference's own functional criterion (tests/test_cmvm.py:55) plus agreement of the single solve with the same
+    problem inside a batch (identical problems of a batch are memoised, so the batch mate is a different matrix)"""
+    k, k1 = int_matrix(0, 256, 256, -128, 128), int_matrix(1, 256, 256, -128, 128)
     a = hip.solve(k)
     assert np.all(a.kernel == k)
-    b = hip.solve_many([k, k])
-    assert b[0] == a and b[1] == a
+    b = hip.solve_many([k, k1, k])
+    assert b[0] == a and b[2] == a
+    assert np.all(b[1].kernel == k1)
 
 
 C5_LAYERS = [(16, 64), (64, 64), (64, 64), (64, 32), (32, 8)]  # synthetic stand-in for a JEDI-linear style model (BASELINE C5)
