@@ -724,12 +724,28 @@ template <class Cell> __global__ void __launch_bounds__(SEL_THREADS) k_iter_sele
             const uint32_t base = grp * gs;
             uint32_t rk[8];
             uint32_t grank = 0;
+#ifdef DA_SELECT_FAST
+            // EXPERIMENT (not yet measured): keys and key indices are loaded together with the ranks (one memory round
+            // trip per verified group instead of two; 13 instead of 4 bytes per slot)
+            unsigned long long kq[8];
+            uint32_t ix[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                int o = lane + u * WAVE;
+                rk[u] = o < gs ? c.hrank[base + o] : 0u;
+                kq[u] = o < gs ? c.hkey[base + o] : 0ull;
+                ix[u] = o < gs ? (uint32_t)c.hidx[base + o] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) grank = max(grank, rk[u]);
+#else
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 int o = lane + u * WAVE;
                 rk[u] = o < gs ? c.hrank[base + o] : 0u;
                 grank = max(grank, rk[u]);
             }
+#endif
             for (int o = lane + 8 * WAVE; o < gs; o += WAVE) grank = max(grank, c.hrank[base + o]);
             grank = wave_max_u32(grank);
             unsigned long long gt = 0;
@@ -738,8 +754,13 @@ template <class Cell> __global__ void __launch_bounds__(SEL_THREADS) k_iter_sele
                 for (int u = 0; u < 8; ++u) {
                     int o = lane + u * WAVE;
                     if (o < gs && rk[u] == grank) {
+#ifdef DA_SELECT_FAST
+                        unsigned long long kk = kq[u];
+                        unsigned long long tw = tie_word((uint32_t)kk, (uint32_t)(kk >> 32), (int)ix[u]);
+#else
                         unsigned long long kk = c.hkey[base + o];
                         unsigned long long tw = tie_word((uint32_t)kk, (uint32_t)(kk >> 32), c.hidx[base + o]);
+#endif
                         gt = tw > gt ? tw : gt;
                     }
                 }
@@ -831,6 +852,18 @@ template <class Cell> __global__ void __launch_bounds__(SEL_THREADS) k_iter_sele
     const int iter = g->iter;
 
     // ---------------- (2) new row record + substitution
+#ifdef DA_SELECT_FAST
+    // EXPERIMENT (not yet measured): the first-pass cell / list-length loads are issued before the barrier, in flight
+    // while thread 0 fetches the two row records and builds the new one (columns are private to their thread)
+    Cell pre_a = 0, pre_b = 0;
+    int pre_len = 0;
+    if (tid < n_out) {
+        const DA_GLOBAL Cell *cf = (const DA_GLOBAL Cell *)g->cells;
+        pre_a = cf[(size_t)A * n_out + tid];
+        pre_b = same ? pre_a : cf[(size_t)B * n_out + tid];
+        pre_len = ((const DA_GLOBAL int *)g->collen)[tid];
+    }
+#endif
     if (tid == 0) {
         RowInfo ra = load_row(c.rows, A), rb = load_row(c.rows, B), rn;
         int derr = 0;
@@ -855,7 +888,11 @@ template <class Cell> __global__ void __launch_bounds__(SEL_THREADS) k_iter_sele
              *cNN = s_cnt + 5 * Kpad;
     unsigned int my_matches = 0;
     for (int j = tid; j < n_out; j += SEL_THREADS) {
+#ifdef DA_SELECT_FAST
+        Cell a = j == tid ? pre_a : rowA[j], b = same ? a : (j == tid ? pre_b : rowB[j]), ma = 0, mb = 0;
+#else
         Cell a = rowA[j], b = same ? a : rowB[j], ma = 0, mb = 0;
+#endif
         if (a && b) substitute_column<Cell>(a, b, same, shift, sub, ma, mb);
         Cell na = same ? (Cell)(a & ~ma & ~mb) : (Cell)(a & ~ma), nbv = b & ~mb;
         if (ma) {
@@ -865,7 +902,11 @@ template <class Cell> __global__ void __launch_bounds__(SEL_THREADS) k_iter_sele
             mcol[at] = j;
             mA[at] = ma;
             mB[at] = mb;
+#ifdef DA_SELECT_FAST
+            int len = j == tid ? pre_len : collen[j];
+#else
             int len = collen[j];
+#endif
             s_len[at] = len;  // the pre-append length: the new row itself is not a partner
             s_col[at] = j;
             if (len < lcap) {

@@ -6,7 +6,8 @@ set -e
 cd "$(dirname "$0")/.."
 mkdir -p ab_libs
 if [ $# -eq 0 ]; then
-  set -- base="" uncond="-DDA_UNCOND_PREFETCH" nortn="-DDA_NORTN_ATOMICS" both="-DDA_UNCOND_PREFETCH -DDA_NORTN_ATOMICS"
+  set -- base="" uncond="-DDA_UNCOND_PREFETCH" nortn="-DDA_NORTN_ATOMICS" selfast="-DDA_SELECT_FAST" \
+         all="-DDA_UNCOND_PREFETCH -DDA_NORTN_ATOMICS -DDA_SELECT_FAST"
 fi
 for spec in "$@"; do
   name=${spec%%=*}; defs=${spec#*=}
