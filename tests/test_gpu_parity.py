@@ -134,6 +134,25 @@ def test_c3_256x256_seed0_against_oracle_record(hip):
         assert hashlib.sha256(json.dumps(dump, separators=(',', ':')).encode()).hexdigest() == rec['sha256']
 
 
+def test_default_search_against_oracle_records(hip):
+    """full default solves (all decompose_dc candidates, both stages) at sizes the CPU oracle needs minutes to hours for
+    (8 threads over the candidates): digest of the whole result against tests/golden/large_default_golden.json"""
+    import hashlib
+    import json
+    import re
+    from pathlib import Path
+
+    path = Path(__file__).parent / 'golden' / 'large_default_golden.json'
+    gold = json.loads(path.read_text()) if path.exists() else {}
+    assert gold, 'tests/golden/large_default_golden.json is missing'
+    for name, rec in sorted(gold.items()):
+        n, seed = (int(v) for v in re.fullmatch(r'(\d+)x\1_seed(\d+)_default', name).groups())
+        p = hip.solve(int_matrix(seed, n, n, -128, 128), **rec['opts'])
+        dump = json.loads(json.dumps(p, default=lambda o: o.to_dict()))
+        assert p.cost == rec['cost'] and [len(s.ops) for s in p.solutions] == rec['n_ops'], name
+        assert hashlib.sha256(json.dumps(dump, separators=(',', ':')).encode()).hexdigest() == rec['sha256'], name
+
+
 def test_default_search_96(hip, oracle):
     """full default solve (all decompose_dc candidates, both stages) on a 96x96 int8 matrix"""
     k = int_matrix(5, 96, 96, -128, 128)

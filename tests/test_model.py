@@ -100,3 +100,16 @@ def test_batch_memoises_identical_problems(oracle):
     model.solve_many([kernels[i] for i in uniq], qintervals=[qints[i] for i in uniq], adder_size=1, carry_size=-1)
     assert batch_chains == model.chains_run(reset=True)
     assert got[0] == got[2] and got[1] == got[4] and got[0] != got[3]
+
+
+def test_default_search_record_64(model):
+    """the 64x64 default-search record of tests/golden/large_default_golden.json through the product's host logic"""
+    import hashlib
+    import json
+    from pathlib import Path
+
+    rec = json.loads((Path(__file__).parent / 'golden' / 'large_default_golden.json').read_text())['64x64_seed0_default']
+    p = model.solve(int_matrix(0, 64, 64, -128, 128))
+    dump = json.loads(json.dumps(p, default=lambda o: o.to_dict()))
+    assert p.cost == rec['cost'] and [len(s.ops) for s in p.solutions] == rec['n_ops']
+    assert hashlib.sha256(json.dumps(dump, separators=(',', ':')).encode()).hexdigest() == rec['sha256']
