@@ -716,7 +716,12 @@ template <class Cell> __global__ void __launch_bounds__(SEL_THREADS) k_iter_sele
                     top_u = u;
                 }
             const unsigned long long wtop = wave_max_u64(top);
+#ifdef DA_SELECT_FAST
+            // an LDS atomic load (ds_read_b64) instead of a volatile generic access, which is a FLAT load
+            if (wtop == 0 || wtop < __hip_atomic_load(&s_floor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
+#else
             if (wtop == 0 || wtop < *(volatile unsigned long long *)&s_floor) break;
+#endif
             const unsigned long long who = __ballot(top == wtop);
             const int owner = __ffsll((long long)who) - 1;
             const int own_u = __shfl(top_u, owner);
