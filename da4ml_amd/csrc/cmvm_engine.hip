@@ -980,11 +980,16 @@ template <class Cell> __global__ void __launch_bounds__(SEL_THREADS) k_iter_sele
     if (wid < CLAIM_WAVES) {
         DA_GLOBAL uint32_t *stamp = (DA_GLOBAL uint32_t *)g->stamp, *plist = (DA_GLOBAL uint32_t *)g->plist;
         const uint32_t tag = (uint32_t)iter + 1u;
-        for (int f0 = tid; f0 < total; f0 += 4 * CLAIM_THREADS) {
-            uint32_t r[4];
-            bool ok[4];
+#ifdef DA_SELECT_FAST
+        constexpr int CLAIM_ILP = 8;  // EXPERIMENT: at C3 sizes (about 5.6 list entries per thread) one pass, one round trip
+#else
+        constexpr int CLAIM_ILP = 4;
+#endif
+        for (int f0 = tid; f0 < total; f0 += CLAIM_ILP * CLAIM_THREADS) {
+            uint32_t r[CLAIM_ILP];
+            bool ok[CLAIM_ILP];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {  // four independent list reads in flight
+            for (int u = 0; u < CLAIM_ILP; ++u) {  // CLAIM_ILP independent list reads in flight
                 const int f = f0 + u * CLAIM_THREADS;
                 ok[u] = f < total;
                 r[u] = 0;
@@ -1001,7 +1006,7 @@ template <class Cell> __global__ void __launch_bounds__(SEL_THREADS) k_iter_sele
                 }
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < CLAIM_ILP; ++u) {
                 if (!ok[u] || r[u] == A || r[u] == B) {
                     ok[u] = false;
                     continue;
@@ -1013,7 +1018,7 @@ template <class Cell> __global__ void __launch_bounds__(SEL_THREADS) k_iter_sele
                     ok[u] = atomicExch(gen(&stamp[r[u]]), tag) != tag;
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < CLAIM_ILP; ++u)
                 if (ok[u]) plist[atomicAdd(&s_np, 1)] = r[u];
         }
     } else {
