@@ -1067,7 +1067,11 @@ template <class Cell> __global__ void __launch_bounds__(SEL_THREADS) k_iter_sele
 // by ONE wavefront, fetched from the chain's work list with an atomic counter: it subtracts the pair occurrences
 // lost with A's / B's consumed digits from the blocks (A,r), (B,r) and creates the block (r,new).
 template <class Cell>
-__global__ void __launch_bounds__(UPD_THREADS, 8) __attribute__((amdgpu_num_sgpr(80))) k_iter_update(ChainDev *chains) {
+#ifndef DA_UPD_OCC
+#define DA_UPD_OCC 8  // blocks of 256 threads per CU the register budget is capped for (EXPERIMENT: 7 or 6 trade wave slots
+                      // for registers: at 8 the kernel spills, and every spill reload is a vmcnt(0) wait inside the partner loop)
+#endif
+__global__ void __launch_bounds__(UPD_THREADS, DA_UPD_OCC) __attribute__((amdgpu_num_sgpr(80))) k_iter_update(ChainDev *chains) {
     ChainDev *g = &chains[blockIdx.y];
     if (g->done) return;
     const int n_partners = g->n_partners;

@@ -7,7 +7,10 @@ cd "$(dirname "$0")/.."
 mkdir -p ab_libs
 if [ $# -eq 0 ]; then
   set -- base="" uncond="-DDA_UNCOND_PREFETCH" nortn="-DDA_NORTN_ATOMICS" selfast="-DDA_SELECT_FAST" \
-         all="-DDA_UNCOND_PREFETCH -DDA_NORTN_ATOMICS -DDA_SELECT_FAST"
+         occ6="-DDA_UPD_OCC=6" upd6="-DDA_UPD_OCC=6 -DDA_UNCOND_PREFETCH -DDA_NORTN_ATOMICS" \
+         upd7="-DDA_UPD_OCC=7 -DDA_UNCOND_PREFETCH -DDA_NORTN_ATOMICS" \
+         all8="-DDA_UNCOND_PREFETCH -DDA_NORTN_ATOMICS -DDA_SELECT_FAST" \
+         all6="-DDA_UPD_OCC=6 -DDA_UNCOND_PREFETCH -DDA_NORTN_ATOMICS -DDA_SELECT_FAST"
 fi
 for spec in "$@"; do
   name=${spec%%=*}; defs=${spec#*=}
