@@ -1110,6 +1110,9 @@ __global__ void __launch_bounds__(UPD_THREADS, DA_UPD_OCC) __attribute__((amdgpu
     const int first = (int)blockIdx.x * UPD_WAVES + wid;
     const bool second = lane >= (int)BUCKET;
     const bool probing = lane < (int)BUCKET || (!same && lane < 2 * (int)BUCKET);
+#ifdef DA_UNCOND_PREFETCH
+    const int my_col = s_col[min(lane, m - 1)];  // this lane's substituted column, read from LDS once (not per partner)
+#endif
     auto issue = [&](uint32_t row, Cell &x0, unsigned long long &kk) {
 #ifdef DA_UNCOND_PREFETCH
         // EXPERIMENT (not yet measured): every lane loads, with clamped indices and no branch around the loads.  The
@@ -1118,7 +1121,7 @@ __global__ void __launch_bounds__(UPD_THREADS, DA_UPD_OCC) __attribute__((amdgpu
         // just before for the next partner.
         const uint32_t other = second ? B : A;
         const uint32_t h = hash_pair(min(other, row), max(other, row));
-        x0 = cells[(size_t)row * n_out + s_col[min(lane, m - 1)]];  // lanes >= m: a valid but unused cell
+        x0 = cells[(size_t)row * n_out + my_col];  // lanes >= m: a valid but unused cell
         kk = c.hkey[((h & ~(BUCKET - 1)) & c.cmask) + (lane & (BUCKET - 1))];
 #else
         x0 = lane < m ? cells[(size_t)row * n_out + s_col[lane]] : (Cell)0;
