@@ -1071,7 +1071,14 @@ template <class Cell>
 #define DA_UPD_OCC 8  // blocks of 256 threads per CU the register budget is capped for (EXPERIMENT: 7 or 6 trade wave slots
                       // for registers: at 8 the kernel spills, and every spill reload is a vmcnt(0) wait inside the partner loop)
 #endif
-__global__ void __launch_bounds__(UPD_THREADS, DA_UPD_OCC) __attribute__((amdgpu_num_sgpr(80))) k_iter_update(ChainDev *chains) {
+#if DA_UPD_OCC >= 8
+#define DA_UPD_SGPRS 80  // 800 SGPRs per SIMD: more than 80 per wave would cap the residency below 8 waves per SIMD
+#elif DA_UPD_OCC == 7
+#define DA_UPD_SGPRS 96
+#else
+#define DA_UPD_SGPRS 102
+#endif
+__global__ void __launch_bounds__(UPD_THREADS, DA_UPD_OCC) __attribute__((amdgpu_num_sgpr(DA_UPD_SGPRS))) k_iter_update(ChainDev *chains) {
     ChainDev *g = &chains[blockIdx.y];
     if (g->done) return;
     const int n_partners = g->n_partners;
