@@ -10,5 +10,6 @@ for lib in ab_libs/lib_*.so; do
   timeout 120 python tools/gpu_stress_small.py $REPS > gpurun_out/ab/$n.stress.log 2>&1
   timeout 120 python -m pytest tests/test_gpu_parity.py -x -q -k "random_small or c3_256 or c2_64" > gpurun_out/ab/$n.parity.log 2>&1
   timeout 60 python tests/gpu_profile.py 256 64 > gpurun_out/ab/$n.perf.log 2>&1
-  echo "[$n] $(tail -1 gpurun_out/ab/$n.stress.log) | $(tail -1 gpurun_out/ab/$n.parity.log) | $(head -1 gpurun_out/ab/$n.perf.log) | $(tail -1 gpurun_out/ab/$n.perf.log)"
+  timeout 30 python tests/gpu_profile.py 256 1 > gpurun_out/ab/$n.perf1.log 2>&1
+  echo "[$n] $(tail -1 gpurun_out/ab/$n.stress.log) | $(tail -1 gpurun_out/ab/$n.parity.log) | $(head -1 gpurun_out/ab/$n.perf.log) | $(tail -1 gpurun_out/ab/$n.perf.log) | single: $(head -1 gpurun_out/ab/$n.perf1.log)"
 done
