@@ -28,7 +28,7 @@ _i32p = np.ctypeslib.ndpointer(np.int32, flags='C_CONTIGUOUS')
 EXPORTS = (
     'da_last_error da_version da_device_count da_set_device da_get_lsb_loc da_iceil_log2 da_cost_add da_int_arr_to_csd '
     'da_csd_decompose da_kernel_decompose da_solve da_solve_batch da_n_stages da_picked da_stage_info da_stage_copy '
-    'da_result_stats da_free da_timings'
+    'da_result_stats da_free da_timings da_dais_run da_dais_last_error'
 ).split()
 
 
@@ -323,55 +323,24 @@ def timings(reset: bool = False) -> dict:
 
 
 def dais_interp_run(bin_logic, data, n_threads: int = 1):
-    """Integer-exact execution of a DAIS program (layout: reference ``types.py:500-541`` / ``docs/dais.md``) on a batch of
-    samples -- the counterpart of the reference's C++ interpreter (``_binary/dais/DAISInterpreter.cc:291-388``), restated
-    with vectorised int64 numpy for the opcodes the CMVM solver emits (-1 input copy, 0 add, 1 subtract).  Host utility for
-    checking solutions; not part of the solver path.  ``n_threads`` is accepted for signature parity and ignored."""
+    """Integer-exact execution of a DAIS program (``CombLogic.to_binary()``; layout: reference ``docs/dais.md:70-95``) on a
+    batch of samples: ``data`` float64 with ``n_samples * n_in`` elements -> float64 [n_samples, n_out].  Replaces
+    ``dais_bin.run_interp`` (reference ``_binary/dais/bindings.cc:102-131``); the executor is ``da_dais_run`` in
+    ``libda4ml_hip.so`` (``csrc/dais_interp.cc``, all opcodes, host threads over the samples).  Host utility for checking
+    solutions -- the reference's interpreter runs on the host too; not part of the solver path."""
     prog = np.ascontiguousarray(np.ravel(bin_logic), dtype=np.int32)
-    _, _, n_in, n_out, n_ops, n_tables = (int(v) for v in prog[:6])
-    if n_tables:
-        raise NotImplementedError('lookup tables are outside the CMVM path')
-    p = 6
-    inp_shifts = prog[p : p + n_in].astype(np.int64)
-    out_idxs = prog[p + n_in : p + n_in + n_out].astype(np.int64)
-    out_shifts = prog[p + n_in + n_out : p + n_in + 2 * n_out].astype(np.int64)
-    out_negs = prog[p + n_in + 2 * n_out : p + n_in + 3 * n_out].astype(bool)
-    code = prog[p + n_in + 3 * n_out :].reshape(n_ops, 8)
-    x = np.asarray(data, dtype=np.float64)
-    assert x.size % max(n_in, 1) == 0, f'Input size {x.size} is not divisible by {n_in}'
-    x = x.reshape(-1, n_in)
-    keep, ints, frac = code[:, 5].astype(np.int64), code[:, 6].astype(np.int64), code[:, 7].astype(np.int64)
-    width = keep + ints + frac
-    buf = np.zeros((n_ops, x.shape[0]), dtype=np.int64)
-
-    def wrap(v, i):  # two's-complement wrap into the op's fixed-point format (DAISInterpreter.cc:139-152)
-        w = int(width[i])
-        if w <= 0:
-            return np.zeros_like(v)
-        mod = 1 << w
-        lo = -(1 << (w - 1)) if keep[i] else 0
-        return (v - lo) % mod + lo
-
-    for i in range(n_ops):
-        opcode, id0, id1 = (int(v) for v in code[i, :3])
-        if opcode == -1:
-            v = np.floor(x[:, id0] * 2.0 ** float(inp_shifts[id0] + frac[i])).astype(np.int64)
-            buf[i] = wrap(v, i)
-        elif opcode in (0, 1):
-            shift = int(np.int32(code[i, 3]))
-            v1, v2 = buf[id0], (-buf[id1] if opcode == 1 else buf[id1])
-            actual = shift + int(frac[id0]) - int(frac[id1])
-            res = v1 + (v2 << actual) if actual > 0 else (v1 << -actual) + v2
-            glob = max(int(frac[id0]), int(frac[id1]) - shift) - int(frac[i])
-            buf[i] = res >> glob if glob > 0 else res
-        else:
-            raise NotImplementedError(f'opcode {opcode} is outside the CMVM path implemented by da4ml_amd')
-    out = np.zeros((x.shape[0], n_out), dtype=np.float64)
-    for j in range(n_out):
-        if out_idxs[j] < 0:
-            continue
-        v = -buf[out_idxs[j]] if out_negs[j] else buf[out_idxs[j]]
-        out[:, j] = v.astype(np.float64) * 2.0 ** float(out_shifts[j] - frac[out_idxs[j]])
+    if prog.size < 4:
+        raise RuntimeError('Invalid binary logic data')
+    n_in, n_out = int(prog[2]), int(prog[3])
+    x = np.ascontiguousarray(np.ravel(data), dtype=np.float64)
+    assert n_in > 0 and x.size % n_in == 0, f'Input size {x.size} is not divisible by {n_in}'
+    n_samples = x.size // n_in
+    out = np.zeros((n_samples, max(n_out, 0)), dtype=np.float64)
+    L = lib()
+    L.da_dais_run.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int]
+    L.da_dais_last_error.restype = C.c_char_p
+    if L.da_dais_run(prog.ctypes.data, prog.size, x.ctypes.data, n_samples, out.ctypes.data, int(n_threads)) != 0:
+        raise RuntimeError(L.da_dais_last_error().decode())
     return out
 
 

@@ -3,9 +3,9 @@
 Field-for-field compatible with the reference's ``da4ml.types`` (reference
 ``src/da4ml/types.py:21-64`` for QInterval/Precision/Op, ``:176-215`` CombLogic fields,
 ``:584-633`` Pipeline) so that solver results can be swapped, JSON-dumped and diffed.
-Only what the CMVM solver emits is executable here: opcodes -1 (input copy), 0 (add) and
-1 (subtract); the tracer-only opcodes (relu, quantize, mux, lookup ...) are outside this
-path and raise.
+The float replay (``CombLogic.__call__``) executes what the CMVM solver emits: opcodes -1 (input copy),
+0 (add) and 1 (subtract); the tracer-only opcodes raise there.  ``CombLogic.predict`` runs the integer-exact
+DAIS executor of the native library, which implements every opcode.
 
 Unlike the reference's per-sample Python replay (``types.py:217-370``) the numeric replay
 here is vectorised over a batch, so ``CombLogic.kernel`` of a 1e5-op solution costs one

@@ -84,6 +84,16 @@ int da_stage_copy(const da_result *r, int stage, int64_t *inp_shifts, int64_t *o
 int da_result_stats(const da_result *r, int64_t *stats);
 void da_free(da_result *r);
 
+/* ---- DAIS program executor (host) -------------------------------------------------------------------------- */
+/* dais_bin.run_interp (reference src/da4ml/_binary/dais/bindings.cc:30-131 -> DAISInterpreter.cc:10-388; program layout
+ * docs/dais.md:70-95 = CombLogic.to_binary()).  Integer-exact execution of `program` (int32 [n_words]) on `n_samples`
+ * input rows (float64 [n_samples, n_in], row-major) into `outputs` (float64 [n_samples, n_out]); n_threads <= 0 = all
+ * host threads, samples are split in chunks of at least 32 like the reference.  Runs on the host (the reference's does
+ * too): the functional checker of solver results behind CombLogic.predict, not part of the solver path.
+ * Returns DA_OK or DA_ERR_RUNTIME (message: da_dais_last_error, calling thread). */
+int da_dais_run(const int32_t *program, int64_t n_words, const double *inputs, int64_t n_samples, double *outputs, int n_threads);
+const char *da_dais_last_error(void);
+
 /* ---- instrumentation for the benchmark harness ------------------------------------------------------------- */
 /* t[31] = chains summed over the sampled launches; t[30] = capacity retries; t[18..29] = shader-clock cycles per kernel phase (7 of k_iter_select, 5 of k_iter_update);
  * t[0..17] = loop_ms (HIP events around the greedy-loop launches), dist_ms, total_ms, lockstep iterations,
