@@ -189,74 +189,97 @@ Program decode(const int32_t *p, int64_t n_words) {
     return g;
 }
 
-// one sample: x[n_in] -> y[n_out]; reg[n_ops] is scratch
-void run_sample(const Program &g, const double *x, double *y, int64_t *reg) {
+// A block of nb <= BLOCK samples: x[nb][n_in] -> y[nb][n_out].  Steps outermost, samples innermost, so that every step is
+// decoded once per block and its arithmetic is a short unit-stride loop over the block (vectorised by the compiler);
+// reg[n_ops][BLOCK] is the register file of the block.
+constexpr int BLOCK = 8;
+// host-only function multiversioning (the file also passes through hipcc's device pass, where it is not available)
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+#define DA_CPU_CLONES __attribute__((target_clones("avx512f", "avx2", "default")))
+#else
+#define DA_CPU_CLONES
+#endif
+
+DA_CPU_CLONES
+void run_block(const Program &g, const double *x, double *y, int nb, int64_t *reg) {
     const Step *st = g.steps.data();
     for (int64_t i = 0; i < g.n_ops; ++i) {
         const Step &s = st[i];
-        int64_t v;
+        int64_t *__restrict r = reg + i * BLOCK;
+        const int64_t *ra = reg + (int64_t)s.a * BLOCK, *rb = reg + (int64_t)s.b * BLOCK;
         switch (s.kind) {
-        case K_INPUT: v = wrap((int64_t)std::floor(x[s.a] * s.scale), s.wrap_w, s.wrap_lo); break;
-        case K_ADDSUB: {
-            const int64_t b = (s.neg & 2) ? -reg[s.b] : reg[s.b];
-            v = ((int64_t)((uint64_t)reg[s.a] << s.sh_a) + (int64_t)((uint64_t)b << s.sh_b)) >> s.sh_out;
+        case K_INPUT:
+            for (int k = 0; k < nb; ++k) r[k] = wrap((int64_t)std::floor(x[k * g.n_in + s.a] * s.scale), s.wrap_w, s.wrap_lo);
             break;
-        }
-        case K_RELU: {
-            const int64_t a = s.neg ? -reg[s.a] : reg[s.a];
-            v = a < 0 ? 0 : wrap(a >> s.sh_out, s.wrap_w, s.wrap_lo);
+        case K_ADDSUB:
+            if (s.neg & 2)
+                for (int k = 0; k < BLOCK; ++k) r[k] = ((int64_t)((uint64_t)ra[k] << s.sh_a) - (int64_t)((uint64_t)rb[k] << s.sh_b)) >> s.sh_out;
+            else
+                for (int k = 0; k < BLOCK; ++k) r[k] = ((int64_t)((uint64_t)ra[k] << s.sh_a) + (int64_t)((uint64_t)rb[k] << s.sh_b)) >> s.sh_out;
             break;
-        }
-        case K_QUANT: {
-            const int64_t a = s.neg ? -reg[s.a] : reg[s.a];
-            v = wrap(a >> s.sh_out, s.wrap_w, s.wrap_lo);
+        case K_RELU:
+            for (int k = 0; k < BLOCK; ++k) {
+                const int64_t a = s.neg ? -ra[k] : ra[k];
+                r[k] = a < 0 ? 0 : wrap(a >> s.sh_out, s.wrap_w, s.wrap_lo);
+            }
             break;
-        }
-        case K_CADD: v = (int64_t)((uint64_t)reg[s.a] << s.sh_a) + s.imm; break;
-        case K_CONST: v = s.imm; break;
+        case K_QUANT:
+            for (int k = 0; k < BLOCK; ++k) r[k] = wrap((s.neg ? -ra[k] : ra[k]) >> s.sh_out, s.wrap_w, s.wrap_lo);
+            break;
+        case K_CADD:
+            for (int k = 0; k < BLOCK; ++k) r[k] = (int64_t)((uint64_t)ra[k] << s.sh_a) + s.imm;
+            break;
+        case K_CONST:
+            for (int k = 0; k < BLOCK; ++k) r[k] = s.imm;
+            break;
         case K_MUX: {
-            const int64_t cnd = reg[s.c];
-            const bool msb = s.aux ? cnd < 0 : cnd > s.imm;
-            const int64_t b = (s.neg & 2) ? -reg[s.b] : reg[s.b];
-            const int64_t pick = msb ? (int64_t)((uint64_t)reg[s.a] << s.sh_a) : (int64_t)((uint64_t)b << s.sh_b);
-            v = wrap(pick, s.wrap_w, s.wrap_lo);
-            break;
-        }
-        case K_MUL: v = (int64_t)((uint64_t)reg[s.a] * (uint64_t)reg[s.b]); break;
-        case K_LUT: {
-            const std::vector<int32_t> &t = g.tables[s.aux];
-            const int64_t idx = reg[s.a] - s.imm;
-            if (idx < 0 || idx >= (int64_t)t.size())
-                bad("Logic lookup index out of bounds: index=" + std::to_string(idx) + ", table_size=" + std::to_string(t.size()));
-            v = t[(size_t)idx];
-            break;
-        }
-        case K_BITU: {
-            const int64_t a = s.neg ? -reg[s.a] : reg[s.a];
-            switch (s.aux & 15) {
-            case 0: v = (s.aux & 16) ? ~a : (~a & s.imm); break;
-            case 1: v = a != 0; break;
-            default: v = (a & s.imm) == s.imm; break;
+            const int64_t *rc = reg + (int64_t)s.c * BLOCK;
+            for (int k = 0; k < BLOCK; ++k) {
+                const bool msb = s.aux ? rc[k] < 0 : rc[k] > s.imm;
+                const int64_t b = (s.neg & 2) ? -rb[k] : rb[k];
+                r[k] = wrap(msb ? (int64_t)((uint64_t)ra[k] << s.sh_a) : (int64_t)((uint64_t)b << s.sh_b), s.wrap_w, s.wrap_lo);
             }
             break;
         }
-        default: {  // K_BITB
-            int64_t a = (s.neg & 1) ? -reg[s.a] : reg[s.a], b = (s.neg & 2) ? -reg[s.b] : reg[s.b];
-            a = (int64_t)((uint64_t)a << s.sh_a), b = (int64_t)((uint64_t)b << s.sh_b);
-            v = s.aux == 0 ? (a & b) : s.aux == 1 ? (a | b) : (a ^ b);
+        case K_MUL:
+            for (int k = 0; k < BLOCK; ++k) r[k] = (int64_t)((uint64_t)ra[k] * (uint64_t)rb[k]);
+            break;
+        case K_LUT: {
+            const std::vector<int32_t> &t = g.tables[s.aux];
+            for (int k = 0; k < nb; ++k) {  // only the live samples: padding lanes may hold anything
+                const int64_t idx = ra[k] - s.imm;
+                if (idx < 0 || idx >= (int64_t)t.size())
+                    bad("Logic lookup index out of bounds: index=" + std::to_string(idx) + ", table_size=" + std::to_string(t.size()));
+                r[k] = t[(size_t)idx];
+            }
             break;
         }
+        case K_BITU:
+            for (int k = 0; k < BLOCK; ++k) {
+                const int64_t a = s.neg ? -ra[k] : ra[k];
+                const int op = s.aux & 15;
+                r[k] = op == 0 ? ((s.aux & 16) ? ~a : (~a & s.imm)) : op == 1 ? (int64_t)(a != 0) : (int64_t)((a & s.imm) == s.imm);
+            }
+            break;
+        default:  // K_BITB
+            for (int k = 0; k < BLOCK; ++k) {
+                const int64_t a = (int64_t)((uint64_t)((s.neg & 1) ? -ra[k] : ra[k]) << s.sh_a);
+                const int64_t b = (int64_t)((uint64_t)((s.neg & 2) ? -rb[k] : rb[k]) << s.sh_b);
+                r[k] = s.aux == 0 ? (a & b) : s.aux == 1 ? (a | b) : (a ^ b);
+            }
+            break;
         }
-        reg[i] = v;
     }
     for (int64_t j = 0; j < g.n_out; ++j) {
-        const int32_t k = g.out_idx[j];
-        if (k < 0) {
-            y[j] = 0.0;
-            continue;
+        const int32_t o = g.out_idx[j];
+        for (int k = 0; k < nb; ++k) {
+            if (o < 0) {
+                y[k * g.n_out + j] = 0.0;
+                continue;
+            }
+            const int64_t v = reg[(int64_t)o * BLOCK + k];
+            y[k * g.n_out + j] = (double)(g.out_neg[j] ? -v : v) * g.out_scale[j];
         }
-        const int64_t v = g.out_neg[j] ? -reg[k] : reg[k];
-        y[j] = (double)v * g.out_scale[j];
     }
 }
 
@@ -282,8 +305,9 @@ int da_dais_run(const int32_t *program, int64_t n_words, const double *inputs, i
         std::mutex mu;
         auto work = [&](int64_t lo, int64_t hi) {
             try {
-                std::vector<int64_t> reg((size_t)std::max<int64_t>(g.n_ops, 1));
-                for (int64_t s = lo; s < hi; ++s) run_sample(g, inputs + s * g.n_in, outputs + s * g.n_out, reg.data());
+                std::vector<int64_t> reg((size_t)std::max<int64_t>(g.n_ops, 1) * BLOCK, 0);
+                for (int64_t s = lo; s < hi; s += BLOCK)
+                    run_block(g, inputs + s * g.n_in, outputs + s * g.n_out, (int)std::min<int64_t>(BLOCK, hi - s), reg.data());
             } catch (...) {
                 std::lock_guard<std::mutex> lk(mu);
                 if (!err) err = std::current_exception();
