@@ -192,10 +192,6 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
     }
     return v;
 }
-__device__ __forceinline__ long long wave_sum_i64(long long v) {
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
 // Make this wave's LDS traffic visible to its own lanes: wait for outstanding LDS operations only (lgkmcnt(0));
 // global loads stay in flight.  LDS operations of one wave complete in order, so no wider fence is needed for the
 // per-wave counters; the wave barriers stop the compiler from moving LDS accesses across.
@@ -284,30 +280,6 @@ __device__ int table_find_from(const Ctx &c, unsigned long long key, uint32_t h,
     return -1;
 }
 __device__ __forceinline__ int table_find(const Ctx &c, unsigned long long key, uint32_t h) { return table_find_from(c, key, h, 0); }
-// two independent look-ups: lanes 0-15 read the first bucket of key0, lanes 16-31 that of key1 (one line each)
-__device__ __forceinline__ void table_find2(const Ctx &c, unsigned long long key0, uint32_t h0, unsigned long long key1, uint32_t h1,
-                                            bool want1, int &slot0, int &slot1) {
-    const int lane = lane_id();
-    const bool second = lane >= (int)BUCKET;
-    const bool active = lane < (int)BUCKET || (want1 && lane < 2 * (int)BUCKET);
-    const uint32_t base = ((second ? h1 : h0) & ~(BUCKET - 1)) & c.cmask;
-    const unsigned long long want = second ? key1 : key0;
-    unsigned long long kk = active ? c.hkey[base + (lane & (BUCKET - 1))] : KEY_TOMB;
-    const unsigned long long hit = __ballot(active && kk == want), emp = __ballot(active && kk == KEY_EMPTY);
-    const unsigned long long m0 = 0xFFFFull, m1 = 0xFFFF0000ull;
-    slot0 = slot1 = -1;
-    if (hit & m0)
-        slot0 = (int)(((h0 & ~(BUCKET - 1)) & c.cmask) + (__ffsll((long long)(hit & m0)) - 1));
-    else if (!(emp & m0))
-        slot0 = table_find_from(c, key0, h0, 1);
-    if (want1) {
-        if (hit & m1)
-            slot1 = (int)(((h1 & ~(BUCKET - 1)) & c.cmask) + (__ffsll((long long)(hit & m1)) - 1 - (int)BUCKET));
-        else if (!(emp & m1))
-            slot1 = table_find_from(c, key1, h1, 1);
-    }
-}
-
 // claim a slot for a key that is known to be absent: the first free (EMPTY or TOMB) slot in bucket order; -1 = full
 __device__ int table_claim(const Ctx &c, unsigned long long key, uint32_t h) {
     const int lane = lane_id();
