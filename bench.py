@@ -135,6 +135,7 @@ def main():
     tm = hip.timings(reset=True)
     elapsed = mg.max_over_ranks(elapsed, device if device.type == 'cuda' else None)
     total_solves = mg.sum_over_ranks(batch * args.steps, device if device.type == 'cuda' else None)
+    mg.shutdown()  # last collective is done: every rank leaves the group here, rank 0 goes on alone
 
     # ---- correctness anchor outside the timed region: seed-0 result against the committed oracle digest
     check = None

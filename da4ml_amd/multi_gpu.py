@@ -34,6 +34,19 @@ def init(backend: str | None = None):
     return rank, world, local, device
 
 
+def shutdown():
+    """Tear the process group down (after a last barrier) so that no backend thread outlives the interpreter:
+    a rank that exits with a live group can abort in the backend's destructors ('terminate called without an active
+    exception'), which a launcher reports as a failed job."""
+    import torch.distributed as dist
+
+    if dist.is_available() and dist.is_initialized():
+        try:
+            dist.barrier()
+        finally:
+            dist.destroy_process_group()
+
+
 def shard_bounds(n_items: int, rank: int, world: int) -> tuple[int, int]:
     """Contiguous balanced shard [lo, hi) of ``n_items`` independent units for ``rank``."""
     base, extra = divmod(n_items, world)

@@ -23,7 +23,8 @@ costs = [5.0, 3.0, 3.0, 9.0, 3.0, 8.0, 4.0]
 best = mg.argmin_first(costs[lo:hi], lo, len(costs))
 parts = mg.gather_to_rank0({"rank": rank, "shard": [lo, hi]})
 if rank == 0:
-    print(json.dumps({"t": t, "s": s, "best": best, "parts": parts}))
+    print(json.dumps({"t": t, "s": s, "best": best, "parts": parts}), flush=True)
+mg.shutdown()
 '''
 
 
@@ -59,7 +60,8 @@ for seed, kw in [(0, {}), (1, {"hard_dc": 2}), (2, {"adder_size": 1, "carry_size
     k = int_matrix(seed, 16, 16, -128, 128)
     p = mg.solve_candidates_sharded(k, solver=O.solve, **kw)
     out.append(bool(p == O.solve(k, **kw)))
-print(json.dumps({"rank": rank, "same": out}))
+print(json.dumps({"rank": rank, "same": out}), flush=True)
+mg.shutdown()
 '''
 
 
