@@ -1,0 +1,73 @@
+"""Golden vectors for da4ml_amd.trace (to_pipeline / retime_pipeline / dead_statement_elimination) from the reference's
+OWN Python (src/da4ml/trace/pipeline.py, tracer.py, fixed_variable.py, types.py), imported in the build container with
+its native module supplied by oracle/_ref/libref.so (tests/golden/ref_py.py).  Run in the build container only:
+
+    python tests/golden/make_pipeline_golden.py
+"""
+import contextlib, gzip, io, json, sys
+from pathlib import Path
+
+HERE = Path(__file__).resolve().parent
+sys.path.insert(0, str(HERE.parent.parent))
+sys.path.insert(0, str(HERE.parent))
+sys.path.insert(0, str(HERE))
+
+import ref_py  # noqa: E402
+from pipeline_cases import CUTOFFS, SOLVES, handmade, solve_inputs  # noqa: E402
+
+
+def dump(p):
+    return json.loads(json.dumps(p, default=lambda o: o.to_dict()))
+
+
+def main():
+    m = ref_py.load()
+    R, rt, rp, rtr = m['oracle'], m['types'], m['pipeline'], m['tracer']
+    out = {'source': 'reference src/da4ml/trace/{pipeline,tracer,fixed_variable}.py + types.py run over oracle/_ref/libref.so', 'split': [], 'retime': [], 'dce': []}
+    for spec in SOLVES:
+        k, opts = solve_inputs(spec)
+        pipe = ref_py.to_ref_pipeline(rt, R.solve(k, **opts))
+        for si, comb in enumerate(pipe.solutions):
+            if not comb.ops:
+                continue
+            for cut in CUTOFFS:
+                try:
+                    res = dump(rp.to_pipeline(comb, cut, retiming=False))
+                except Exception as e:  # the reference's own failure mode is part of the contract
+                    res = {'raises': type(e).__name__}
+                out['split'].append({'solve': spec[0], 'stage': si, 'cutoff': cut, 'result': res})
+            for cut in CUTOFFS[1:5]:
+                buf = io.StringIO()
+                try:
+                    with contextlib.redirect_stdout(buf):
+                        res = dump(rp.to_pipeline(comb, cut, retiming=True))
+                except Exception as e:
+                    res = {'raises': type(e).__name__}
+                out['retime'].append({'solve': spec[0], 'stage': si, 'cutoff': cut, 'result': res, 'stdout': buf.getvalue()})
+            # dead statements: keep every other output only
+            half = rt.CombLogic(comb.shape, comb.inp_shifts, [i if j % 2 == 0 else -1 for j, i in enumerate(comb.out_idxs)], comb.out_shifts,
+                                comb.out_negs, comb.ops, comb.carry_size, comb.adder_size, None)  # fmt: skip
+            for keep in (False, True):
+                out['dce'].append({'solve': spec[0], 'stage': si, 'keep_dead_inputs': keep, 'result': dump(rtr.dead_statement_elimination(half, keep))})
+        # whole two-stage result through retime_pipeline directly
+        buf = io.StringIO()
+        try:
+            with contextlib.redirect_stdout(buf):
+                res = dump(rp.retime_pipeline(pipe))
+        except Exception as e:
+            res = {'raises': type(e).__name__}
+        out['retime'].append({'solve': spec[0], 'stage': 'pipeline', 'cutoff': None, 'result': res, 'stdout': buf.getvalue()})
+    hm = ref_py.to_ref_comb(rt, handmade())
+    for keep in (False, True):
+        out['dce'].append({'solve': 'handmade', 'stage': 0, 'keep_dead_inputs': keep, 'result': dump(rtr.dead_statement_elimination(hm, keep))})
+    for cut in (0.0, 1.0, 2.0):
+        out['split'].append({'solve': 'handmade', 'stage': 0, 'cutoff': cut, 'result': dump(rp.to_pipeline(hm, cut, retiming=False))})
+    path = HERE / 'pipeline_golden.json.gz'
+    with gzip.open(path, 'wt', compresslevel=9) as f:
+        json.dump(out, f, separators=(',', ':'))
+    print(path, path.stat().st_size, 'bytes;', {k: len(v) for k, v in out.items() if isinstance(v, list)})
+    print('raises:', [(c['solve'], c['stage'], c['cutoff'], c['result']['raises']) for sec in ('split', 'retime') for c in out[sec] if isinstance(c['result'], dict)])
+
+
+if __name__ == '__main__':
+    main()

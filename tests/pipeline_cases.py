@@ -1,0 +1,47 @@
+"""Seeded inputs of the pipelining / dead-statement tests, shared by tests/golden/make_pipeline_golden.py (which runs
+the reference's own Python on them) and tests/test_pipeline.py."""
+
+from cases import int_matrix, random_case
+
+from da4ml_amd.types import CombLogic, Op, QInterval
+
+# (name, kernel recipe, solve options): the solver output is what gets pipelined
+SOLVES = [
+    ('c1_16x16_int4_default', ('int_matrix', 0, 16, 16, -8, 8), {}),
+    ('c1_16x16_int4_tracer_cost', ('int_matrix', 1, 16, 16, -8, 8), dict(adder_size=1, carry_size=-1)),
+    ('16x16_int8_tracer_cost', ('int_matrix', 0, 16, 16, -128, 128), dict(adder_size=1, carry_size=-1)),
+    ('16x16_int8_carry8', ('int_matrix', 2, 16, 16, -128, 128), dict(adder_size=4, carry_size=8)),
+    ('12x20_int8_dc0', ('int_matrix', 3, 12, 20, -128, 128), dict(adder_size=1, carry_size=-1, decompose_dc=0, search_all_decompose_dc=False)),
+    ('32x32_int8_tracer_cost', ('int_matrix', 4, 32, 32, -128, 128), dict(adder_size=1, carry_size=-1, decompose_dc=-1, search_all_decompose_dc=False)),
+    ('random_case_3', ('random_case', 3), None),  # custom intervals + input latencies
+    ('random_case_9', ('random_case', 9), None),
+    ('random_case_14', ('random_case', 14), None),  # zero row
+    ('random_case_22', ('random_case', 22), None),  # zero column -> absent output
+]
+CUTOFFS = [0.0, 1.0, 2.0, 3.5, 5.0, 1000.0]
+
+
+def solve_inputs(spec):
+    name, recipe, opts = spec
+    if recipe[0] == 'random_case':
+        k, o, _ = random_case(recipe[1])
+        return k, o
+    return int_matrix(*recipe[1:]), opts
+
+
+def handmade() -> CombLogic:
+    """A graph with tracer-only statements (relu, msb-mux, constant) and dead code, for the passes that do not replay."""
+    q = QInterval(-8.0, 7.0, 1.0)
+    ops = [
+        Op(0, -1, -1, 0, q, 0.0, 0.0),  # 0: x0
+        Op(1, -1, -1, 0, q, 0.0, 0.0),  # 1: x1
+        Op(2, -1, -1, 0, q, 0.0, 0.0),  # 2: x2 (dead)
+        Op(0, 1, 0, 1, QInterval(-24.0, 21.0, 1.0), 1.0, 5.0),  # 3: x0 + 2 x1
+        Op(0, 1, 1, 0, QInterval(-15.0, 15.0, 1.0), 1.0, 5.0),  # 4: x0 - x1
+        Op(3, -1, 2, 0, QInterval(0.0, 21.0, 1.0), 1.0, 2.5),  # 5: relu(3)
+        Op(2, 0, 0, 0, QInterval(-16.0, 14.0, 1.0), 1.0, 5.0),  # 6: dead
+        Op(5, 4, 6, (1 << 32) | 4, QInterval(-30.0, 30.0, 1.0), 2.5, 3.0),  # 7: msb(4) ? 5 : 4 << 1
+        Op(7, 3, 0, 0, QInterval(-54.0, 51.0, 1.0), 4.0, 6.0),  # 8
+        Op(6, 6, 0, 0, QInterval(-32.0, 28.0, 1.0), 2.0, 5.0),  # 9: dead
+    ]
+    return CombLogic((3, 3), [0, 0, 0], [8, 5, -1], [0, 1, 0], [False, True, False], ops, -1, -1, None)

@@ -1,0 +1,89 @@
+"""da4ml_amd.trace against golden vectors produced by the reference's own Python
+(tests/golden/make_pipeline_golden.py): register-stage splitting, retiming, dead-statement elimination."""
+
+import contextlib
+import gzip
+import io
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from pipeline_cases import SOLVES, handmade, solve_inputs
+
+from da4ml_amd.trace import dead_statement_elimination, retime_pipeline, to_pipeline
+from da4ml_amd.types import CombLogic, Pipeline
+
+GOLDEN = json.load(gzip.open(Path(__file__).parent / 'golden' / 'pipeline_golden.json.gz', 'rt'))
+ERRORS = {'KeyError': KeyError, 'IndexError': IndexError, 'AssertionError': AssertionError, 'ValueError': ValueError}
+
+
+def dump(p):
+    return json.loads(json.dumps(p, default=lambda o: o.to_dict()))
+
+
+@pytest.fixture(scope='module')
+def solved(oracle):
+    """solver outputs of the shared cases (from the CPU oracle: these passes are host-side and need no GPU)"""
+    res = {}
+    for spec in SOLVES:
+        k, opts = solve_inputs(spec)
+        res[spec[0]] = oracle.solve(k, **opts)
+    res['handmade'] = Pipeline((handmade(),))
+    return res
+
+
+def _check(fn, item):
+    want = item['result']
+    if isinstance(want, dict) and 'raises' in want:
+        with pytest.raises(ERRORS[want['raises']]):
+            fn()
+        return 0
+    assert dump(fn()) == want, (item['solve'], item['stage'], item.get('cutoff'))
+    return 1
+
+
+def test_split_matches_reference(solved):
+    ok = sum(_check(lambda: to_pipeline(solved[it['solve']].solutions[it['stage']], it['cutoff'], retiming=False), it) for it in GOLDEN['split'])
+    assert ok >= 80
+
+
+def test_dead_statement_elimination_matches_reference(solved):
+    for it in GOLDEN['dce']:
+        comb = solved[it['solve']].solutions[it['stage']]
+        if it['solve'] != 'handmade':
+            comb = comb._replace(out_idxs=[i if j % 2 == 0 else -1 for j, i in enumerate(comb.out_idxs)])
+        assert dump(dead_statement_elimination(comb, it['keep_dead_inputs'])) == it['result'], (it['solve'], it['stage'])
+
+
+def test_retiming_matches_reference(solved):
+    ok = 0
+    for it in GOLDEN['retime']:
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            if it['stage'] == 'pipeline':
+                ok += _check(lambda: retime_pipeline(solved[it['solve']]), it)
+            else:
+                ok += _check(lambda: to_pipeline(solved[it['solve']].solutions[it['stage']], it['cutoff']), it)
+        if not isinstance(it['result'], dict):
+            assert buf.getvalue() == it['stdout']
+    assert ok >= 40
+
+
+def test_split_and_retime_keep_the_function(solved):
+    """size-independent property: every stage split / retiming implements the same matrix"""
+    comb = solved['32x32_int8_tracer_cost'].solutions[0]
+    for cut in (2.0, 5.0):
+        for retiming in (False, True):
+            p = to_pipeline(comb, cut, retiming=retiming, verbose=False)
+            assert np.array_equal(p.kernel, comb.kernel)
+            assert all(max(s.out_latency) <= (i + 1) * cut + 1e-6 for i, s in enumerate(p.solutions[:-1])) or retiming
+
+
+def test_unsupported_is_loud():
+    comb = handmade()
+    comb = comb._replace(ops=[op._replace(latency=op.latency * 10) for op in comb.ops])
+    assert len(to_pipeline(comb, 25.0, retiming=False).solutions) == 2
+    with pytest.raises(NotImplementedError):
+        to_pipeline(comb, 25.0)  # the bisection would have to replay relu / msb-mux statements: tracer territory
