@@ -6,9 +6,10 @@ Same names, arguments and results as the reference's ``src/da4ml/trace/pipeline.
 re-derives exactly what that round trip produces for the statements the CMVM solver emits -- input copies, add and
 subtract: intervals and power-of-two scale factors of every value (``fixed_variable.py:441-513,586-609``), the adder
 cost/latency model with the stage-boundary rule (``fixed_variable.py:341-379``), the tracer's statement order
-(``tracer.py:12-58``) and its dead-statement pass.  Anything else (other opcodes, constant or absent terms) raises
-``NotImplementedError`` instead of guessing.  Pinned to the reference's own Python (run in the build container over
-``oracle/_ref``) by ``tests/golden/pipeline_golden.json.gz``.
+(``tracer.py:12-58``) and its dead-statement pass, with the constant zero of absent terms.  Anything else (other
+opcodes, non-zero constants) raises
+``NotImplementedError`` instead of guessing.  Pinned to the reference's own Python (run in the build container, see
+``make_pipeline_golden.py`` next to the golden vectors) by ``pipeline_golden.json.gz``.
 """
 
 from __future__ import annotations
