@@ -28,7 +28,7 @@ _i32p = np.ctypeslib.ndpointer(np.int32, flags='C_CONTIGUOUS')
 EXPORTS = (
     'da_last_error da_version da_device_count da_set_device da_get_lsb_loc da_iceil_log2 da_cost_add da_int_arr_to_csd '
     'da_csd_decompose da_kernel_decompose da_solve da_solve_batch da_n_stages da_picked da_stage_info da_stage_copy '
-    'da_result_stats da_free da_timings da_dais_run da_dais_last_error'
+    'da_result_stats da_free da_timings da_dais_run da_dais_last_error da_dais_run_on'
 ).split()
 
 
@@ -322,12 +322,19 @@ def timings(reset: bool = False) -> dict:
     return dict(zip(names, t.tolist()))
 
 
-def dais_interp_run(bin_logic, data, n_threads: int = 1):
+_DAIS_EXECUTORS = {'host': 0, 'cpu': 0, 'device': 1, 'gpu': 1, 'host-scalar': 2}
+
+
+def dais_interp_run(bin_logic, data, n_threads: int = 1, executor: str = 'host'):
     """Integer-exact execution of a DAIS program (``CombLogic.to_binary()``; layout: reference ``docs/dais.md:70-95``) on a
     batch of samples: ``data`` float64 with ``n_samples * n_in`` elements -> float64 [n_samples, n_out].  Replaces
     ``dais_bin.run_interp`` (reference ``_binary/dais/bindings.cc:102-131``); the executor is ``da_dais_run`` in
     ``libda4ml_hip.so`` (``csrc/dais_interp.cc``, all opcodes, host threads over the samples).  Host utility for checking
-    solutions -- the reference's interpreter runs on the host too; not part of the solver path."""
+    solutions -- the reference's interpreter runs on the host too; not part of the solver path.
+
+    ``executor`` (no reference counterpart): ``'host'`` (default), ``'device'`` = the HIP kernel ``k_dais_run`` (one
+    thread per sample, ``csrc/dais_gpu.hip``; raises without a GPU), ``'host-scalar'`` = the device executor's per-thread
+    code run on the host (test aid).  All three give identical results."""
     prog = np.ascontiguousarray(np.ravel(bin_logic), dtype=np.int32)
     if prog.size < 4:
         raise RuntimeError('Invalid binary logic data')
@@ -337,9 +344,11 @@ def dais_interp_run(bin_logic, data, n_threads: int = 1):
     n_samples = x.size // n_in
     out = np.zeros((n_samples, max(n_out, 0)), dtype=np.float64)
     L = lib()
-    L.da_dais_run.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int]
+    L.da_dais_run_on.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int]
     L.da_dais_last_error.restype = C.c_char_p
-    if L.da_dais_run(prog.ctypes.data, prog.size, x.ctypes.data, n_samples, out.ctypes.data, int(n_threads)) != 0:
+    if executor not in _DAIS_EXECUTORS:
+        raise ValueError(f'unknown DAIS executor {executor!r} (one of {sorted(_DAIS_EXECUTORS)})')
+    if L.da_dais_run_on(prog.ctypes.data, prog.size, x.ctypes.data, n_samples, out.ctypes.data, int(n_threads), _DAIS_EXECUTORS[executor]) != 0:
         raise RuntimeError(L.da_dais_last_error().decode())
     return out
 

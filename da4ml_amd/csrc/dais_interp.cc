@@ -22,43 +22,13 @@
 
 #include "../../include/da4ml_hip.h"
 
+#include "dais_core.h"
+
+namespace dais {
 namespace {
-
-struct Fmt {  // fixed-point format (signed, integer bits, fractional bits)
-    int32_t sgn, ints, frac;
-    int width() const { return ints + frac + (sgn ? 1 : 0); }
-};
-
-enum Kind : int32_t { K_INPUT, K_ADDSUB, K_RELU, K_QUANT, K_CADD, K_CONST, K_MUX, K_MUL, K_LUT, K_BITU, K_BITB };
-
-struct Step {
-    int32_t kind;
-    int32_t a, b, c;       // operand registers (c: mux condition)
-    int32_t neg;           // operand negation flags (bit 0: a, bit 1: b)
-    int32_t sh_a, sh_b;    // left shifts applied to operand a / b
-    int32_t sh_out;        // right shift applied to the result (drop of fractional bits)
-    int32_t wrap_w;        // kinds that quantise: wrap the result into this many bits ...
-    int64_t wrap_lo;       // ... starting at this minimum
-    int64_t imm;           // constant / table offset / mask / msb threshold
-    int32_t aux;           // table index, bit operation, "condition is signed"
-    double scale;          // input scaling 2^(inp_shift + frac)
-};
-
-struct Program {
-    int64_t n_in = 0, n_out = 0, n_ops = 0;
-    std::vector<Step> steps;
-    std::vector<std::vector<int32_t>> tables;
-    std::vector<int32_t> out_idx, out_neg;
-    std::vector<double> out_scale;
-};
 
 [[noreturn]] void bad(const std::string &msg) { throw std::runtime_error(msg); }
 
-// two's-complement wrap of v into `w` bits whose smallest value is `lo` (reference DAISInterpreter.cc:139-152)
-inline int64_t wrap(int64_t v, int w, int64_t lo) {
-    const uint64_t mask = w >= 64 ? ~0ull : ((1ull << w) - 1);
-    return (int64_t)(((uint64_t)v - (uint64_t)lo) & mask) + lo;
-}
 inline int64_t fmt_min(const Fmt &f) { return f.sgn ? -((int64_t)1 << (f.width() - 1)) : 0; }
 
 void set_wrap(Step &s, const Fmt &to) {
@@ -68,6 +38,8 @@ void set_wrap(Step &s, const Fmt &to) {
     s.wrap_w = w;
     s.wrap_lo = w > 0 ? fmt_min(to) : 0;
 }
+
+}  // namespace
 
 Program decode(const int32_t *p, int64_t n_words) {
     if (n_words < 6) bad("Binary data too small to contain valid DAIS model file");
@@ -189,6 +161,8 @@ Program decode(const int32_t *p, int64_t n_words) {
     return g;
 }
 
+namespace {
+
 // A block of nb <= BLOCK samples: x[nb][n_in] -> y[nb][n_out].  Steps outermost, samples innermost, so that every step is
 // decoded once per block and its arithmetic is a short unit-stride loop over the block (vectorised by the compiler);
 // reg[n_ops][BLOCK] is the register file of the block.
@@ -283,19 +257,66 @@ void run_block(const Program &g, const double *x, double *y, int nb, int64_t *re
     }
 }
 
+// One sample at a time through dais::eval over the slot-compacted steps -- the exact per-thread code path of the device
+// executor (dais_gpu.hip: same eval, same slot assignment).  Slower than run_block; exists so that the shared arithmetic and
+// the slot logic are pinned against the golden vectors on hosts without a GPU.
+struct SlotProgram {
+    std::vector<Step> steps;
+    std::vector<int32_t> dst, slot_of;
+    int64_t n_slots = 0;
+};
+void run_scalar(const Program &g, const SlotProgram &sp, const double *x, double *y, int64_t *reg) {
+    for (int64_t i = 0; i < g.n_ops; ++i) {
+        const Step &s = sp.steps[i];
+        const int rd = reads(s.kind);
+        const int64_t a = (rd & 1) ? reg[s.a] : 0, b = (rd & 2) ? reg[s.b] : 0, c = (rd & 4) ? reg[s.c] : 0;
+        if (s.kind == K_LUT) {
+            const std::vector<int32_t> &t = g.tables[s.aux];
+            const int64_t idx = lut_index(s, a);
+            if (idx < 0 || idx >= (int64_t)t.size())
+                bad("Logic lookup index out of bounds: index=" + std::to_string(idx) + ", table_size=" + std::to_string(t.size()));
+            reg[sp.dst[i]] = t[(size_t)idx];
+        } else
+            reg[sp.dst[i]] = eval(s, a, b, c, s.kind == K_INPUT ? x[s.a] : 0.0);
+    }
+    for (int64_t j = 0; j < g.n_out; ++j) {
+        const int32_t o = g.out_idx[j];
+        const int64_t v = o < 0 ? 0 : reg[sp.slot_of[o]];
+        y[j] = o < 0 ? 0.0 : (double)(g.out_neg[j] ? -v : v) * g.out_scale[j];
+    }
+}
+
 thread_local std::string g_dais_err;
 
 }  // namespace
+}  // namespace dais
+
+using namespace dais;
+
+// device executor (dais_gpu.hip)
+int64_t dais_assign_slots(const dais::Program &g, std::vector<dais::Step> &steps, std::vector<int32_t> &dst, std::vector<int32_t> &slot_of);
+void dais_run_gpu(const dais::Program &g, const double *inputs, int64_t n_samples, double *outputs);
 
 extern "C" {
 
 const char *da_dais_last_error(void) { return g_dais_err.c_str(); }
 
 int da_dais_run(const int32_t *program, int64_t n_words, const double *inputs, int64_t n_samples, double *outputs, int n_threads) {
+    return da_dais_run_on(program, n_words, inputs, n_samples, outputs, n_threads, DA_DAIS_HOST);
+}
+
+int da_dais_run_on(const int32_t *program, int64_t n_words, const double *inputs, int64_t n_samples, double *outputs, int n_threads, int where) {
     try {
         if (!program || n_words < 4) bad("Invalid binary logic data");
         const Program g = decode(program, n_words);
         if (n_samples <= 0) return DA_OK;
+        if (where == DA_DAIS_DEVICE) {
+            dais_run_gpu(g, inputs, n_samples, outputs);
+            return DA_OK;
+        }
+        SlotProgram sp;
+        if (where == DA_DAIS_HOST_SCALAR) sp.n_slots = dais_assign_slots(g, sp.steps, sp.dst, sp.slot_of);
+        if (where != DA_DAIS_HOST && where != DA_DAIS_HOST_SCALAR) bad("da_dais_run_on: unknown executor " + std::to_string(where));
         // split like the reference (bindings.cc:57-66): at least 32 samples per thread
         int64_t hw = (int64_t)std::max(1u, std::thread::hardware_concurrency());
         int64_t want = n_threads <= 0 ? hw : std::min<int64_t>(n_threads, hw);
@@ -306,6 +327,11 @@ int da_dais_run(const int32_t *program, int64_t n_words, const double *inputs, i
         auto work = [&](int64_t lo, int64_t hi) {
             try {
                 std::vector<int64_t> reg((size_t)std::max<int64_t>(g.n_ops, 1) * BLOCK, 0);
+                if (where == DA_DAIS_HOST_SCALAR) {
+                    std::vector<int64_t> slots((size_t)sp.n_slots, 0);
+                    for (int64_t s = lo; s < hi; ++s) run_scalar(g, sp, inputs + s * g.n_in, outputs + s * g.n_out, slots.data());
+                    return;
+                }
                 for (int64_t s = lo; s < hi; s += BLOCK)
                     run_block(g, inputs + s * g.n_in, outputs + s * g.n_out, (int)std::min<int64_t>(BLOCK, hi - s), reg.data());
             } catch (...) {

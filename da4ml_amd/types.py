@@ -251,13 +251,14 @@ class CombLogic(NamedTuple):
     def save_binary(self, path: str | Path, version: int = 0):
         self.to_binary(version).tofile(str(path))
 
-    def predict(self, data, n_threads: int = 0):
-        """Integer-exact batch execution through the DAIS binary program, like the reference (``types.py:549-581``)."""
+    def predict(self, data, n_threads: int = 0, executor: str = 'host'):
+        """Integer-exact batch execution through the DAIS binary program, like the reference (``types.py:549-581``);
+        ``executor='device'`` runs the samples on the GPU (one thread per sample) instead of on host threads."""
         from ._binary import dais_interp_run
 
         if isinstance(data, (list, tuple)):
             data = np.concatenate([np.asarray(a).reshape(len(a), -1) for a in data], axis=-1)
-        return dais_interp_run(self.to_binary(), np.asarray(data, dtype=np.float64), n_threads)
+        return dais_interp_run(self.to_binary(), np.asarray(data, dtype=np.float64), n_threads, executor)
 
 
 class Pipeline(NamedTuple):

@@ -93,6 +93,18 @@ void da_free(da_result *r);
  * Returns DA_OK or DA_ERR_RUNTIME (message: da_dais_last_error, calling thread). */
 int da_dais_run(const int32_t *program, int64_t n_words, const double *inputs, int64_t n_samples, double *outputs, int n_threads);
 const char *da_dais_last_error(void);
+/* Same execution with the executor chosen by `where`:
+ *   DA_DAIS_HOST        the host block executor above;
+ *   DA_DAIS_DEVICE      HIP kernel k_dais_run on the current device: one thread per sample, register file
+ *                       [slot][sample] in HBM with liveness-compacted slots (csrc/dais_gpu.hip); fails without a GPU;
+ *   DA_DAIS_HOST_SCALAR the device executor's per-value code (csrc/dais_core.h) run sample by sample on the host --
+ *                       test aid that pins the shared arithmetic without a GPU.
+ * No reference counterpart (the reference's interpreter is host-only); results are identical for all three. */
+#define DA_DAIS_HOST 0
+#define DA_DAIS_DEVICE 1
+#define DA_DAIS_HOST_SCALAR 2
+int da_dais_run_on(const int32_t *program, int64_t n_words, const double *inputs, int64_t n_samples, double *outputs, int n_threads,
+                   int where);
 
 /* ---- instrumentation for the benchmark harness ------------------------------------------------------------- */
 /* t[31] = chains summed over the sampled launches; t[30] = capacity retries; t[18..29] = shader-clock cycles per kernel phase (7 of k_iter_select, 5 of k_iter_update);

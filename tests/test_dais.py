@@ -26,6 +26,8 @@ def test_golden_vectors_from_the_reference():
         want = np.asarray([float.fromhex(v) for v in case['outputs']]).reshape(case['n_samples'], -1)
         for threads in (1, 0):
             assert np.array_equal(dais_interp_run(prog, x, n_threads=threads), want), case['seed']
+        # the device executor's per-thread code (dais_core.h eval + slot-compacted registers), run on the host
+        assert np.array_equal(dais_interp_run(prog, x, executor='host-scalar'), want), case['seed']
         regen, _ = random_program(case['seed'], n_samples=8)
         assert np.array_equal(regen, prog), 'tests/dais_cases.py no longer reproduces the committed programs'
         n_in, n_out, n_ops = (int(v) for v in prog[2:5])
@@ -97,3 +99,25 @@ def test_solver_output_runs_through_the_executor(oracle):
         assert np.array_equal(stage.predict(x), stage(x))
     x = rng.integers(-128, 128, (50, 12)).astype(np.float64)
     assert np.array_equal(sol.solutions[0].predict(x) @ sol.solutions[1].kernel.astype(np.float64), x @ k)
+
+
+def test_device_code_path_on_the_host_equals_block_executor():
+    """csrc/dais_core.h + the liveness slot assignment of csrc/dais_gpu.hip (what every GPU thread runs) against the
+    block executor on many random programs; also a solver result, whose slot count must be far below its op count"""
+    from da4ml_amd._binary import dais_interp_run
+
+    for seed in range(2000, 2150):
+        prog, x = random_program(seed, n_ops=int(30 + seed % 120), n_samples=24)
+        assert np.array_equal(dais_interp_run(prog, x, executor='host-scalar'), dais_interp_run(prog, x)), seed
+
+
+def test_device_executor_needs_a_gpu():
+    from da4ml_amd import _binary as hip
+
+    if hip.device_count() > 0:
+        pytest.skip('a GPU is present')
+    prog, x = random_program(5)
+    with pytest.raises(RuntimeError, match='no HIP device'):
+        hip.dais_interp_run(prog, x, executor='device')
+    with pytest.raises(ValueError):
+        hip.dais_interp_run(prog, x, executor='tpu')
