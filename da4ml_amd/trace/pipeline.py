@@ -318,7 +318,9 @@ def _retimed(csol: Pipeline, cutoff: float, cost_add) -> Pipeline | None:
 
 def retime_pipeline(csol: Pipeline, verbose: bool = True) -> Pipeline:
     """Bisect the latency cutoff down to the smallest (to within 1) that keeps the number of stages, re-deriving every
-    latency under each trial cutoff (an adder that would cross a stage boundary starts at the boundary instead)."""
+    latency under each trial cutoff (an adder that would cross a stage boundary starts at the boundary instead).
+    One deliberate deviation: where the reference's bisection stops making progress and loops forever (integral lower
+    bound, upper bound less than 2 above it, midpoint infeasible) this returns the best pipeline found so far."""
     from .._binary import cost_add
 
     n_stages = len(csol.solutions)
@@ -329,6 +331,10 @@ def retime_pipeline(csol: Pipeline, verbose: bool = True) -> Pipeline:
         cutoff = (hi + lo) // 2
         trial = _retimed(csol, cutoff, cost_add)
         if trial is None or len(trial.solutions) > n_stages:
+            if cutoff == lo:
+                # (hi + lo) // 2 == lo (integral lo, 1 < hi - lo < 2) and still too fast: the state cannot change any
+                # more.  The reference's loop (pipeline.py:15-28) never terminates here; stop with the best found
+                break
             lo = cutoff
         else:
             hi, best = cutoff, trial
