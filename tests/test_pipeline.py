@@ -87,3 +87,17 @@ def test_unsupported_is_loud():
     assert len(to_pipeline(comb, 25.0, retiming=False).solutions) == 2
     with pytest.raises(NotImplementedError):
         to_pipeline(comb, 25.0)  # the bisection would have to replay relu / msb-mux statements: tracer territory
+
+
+def test_bisection_stall_terminates(oracle):
+    """random_case(92) stage 0 at cutoff 8.5 (and random_case(7) at 5.5): the reference's cutoff bisection reaches
+    (hi + lo) // 2 == lo with an infeasible midpoint and never returns; here the search stops with the best pipeline."""
+    from cases import random_case
+
+    for seed, cut in ((92, 8.5), (7, 5.5)):
+        k, opts, _ = random_case(seed)
+        comb = oracle.solve(k, **opts).solutions[0]
+        plain = to_pipeline(comb, cut, retiming=False)
+        p = to_pipeline(comb, cut, verbose=False)
+        assert len(p.solutions) == len(plain.solutions)
+        assert np.array_equal(p.kernel, comb.kernel)
