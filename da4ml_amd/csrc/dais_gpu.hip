@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -96,8 +97,8 @@ template <class T> struct DevBuf {
 // Slot assignment: value i gets a slot when it is produced and gives it back after its last reader; a step may write
 // the slot of an operand that dies in it (a thread reads its operands before it writes).  Outputs stay live to the end.
 // Returns the number of slots; rewrites the operand fields of `steps` from value numbers to slots, fills slot_of.
-// Also used by the host-side model of the device executor (da_dais_run_on, DA_DAIS_HOST_SCALAR keeps value numbers;
-// the slot logic itself is checked by dais_check_slots below, which the CPU tests call through the C ABI).
+// Also used by the host-side run of the device code path (da_dais_run_on with DA_DAIS_HOST_SCALAR, dais_interp.cc), which is
+// how the CPU tests check the slot logic against the golden vectors.
 int64_t dais_assign_slots(const dais::Program &g, std::vector<dais::Step> &steps, std::vector<int32_t> &dst, std::vector<int32_t> &slot_of) {
     const int64_t n = g.n_ops;
     std::vector<int64_t> last(n, -1);
@@ -168,6 +169,8 @@ void dais_run_gpu(const dais::Program &g, const double *inputs, int64_t n_sample
     DAIS_HIP(hipMemGetInfo(&free_b, &total_b));
     const int64_t per_sample = n_slots * 8 + (g.n_in + g.n_out) * 8;
     int64_t tile = std::min<int64_t>({n_samples, (int64_t)1 << 22, std::max<int64_t>((int64_t)(free_b / 4) / per_sample, TPB)});
+    if (const char *e = std::getenv("DA4ML_DAIS_TILE"))  // experiment knob: samples per launch (cache residency vs occupancy)
+        tile = std::max<int64_t>(1, std::min<int64_t>(tile, std::atoll(e)));
     tile = (tile + TPB - 1) / TPB * TPB;
 
     DevBuf<DevStep> d_steps(steps.size());
