@@ -3,8 +3,9 @@
 Field-for-field compatible with the reference's ``da4ml.types`` (reference
 ``src/da4ml/types.py:21-64`` for QInterval/Precision/Op, ``:176-215`` CombLogic fields,
 ``:584-633`` Pipeline) so that solver results can be swapped, JSON-dumped and diffed.
-The float replay (``CombLogic.__call__``) executes what the CMVM solver emits: opcodes -1 (input copy),
-0 (add) and 1 (subtract); the tracer-only opcodes raise there.  ``CombLogic.predict`` runs the integer-exact
+The float replay (``CombLogic.__call__``) executes what the CMVM solver emits -- opcodes -1 (input copy), 0 (add) and
+1 (subtract) -- and, for numeric inputs, the arithmetic statements of the tracer (relu, quantize, constant add/definition,
+msb-mux, multiply); lookup tables and bitwise operations raise there.  ``CombLogic.predict`` runs the integer-exact
 DAIS executor of the native library, which implements every opcode.
 
 Unlike the reference's per-sample Python replay (``types.py:217-370``) the numeric replay
@@ -81,6 +82,48 @@ def _is_numeric(a: np.ndarray) -> bool:
     return a.dtype != object
 
 
+# Numeric replay of the statements the reference's tracer adds around solver output (reference ``types.py:250-283`` with the
+# float branches of ``_relu`` / ``_quantize``, ``types.py:130-168``), vectorised over the batch: they appear in graphs that
+# pass through ``da4ml_amd.trace`` (a constant definition stands for an absent output after retiming) and in loaded files.
+# Lookup tables and the bitwise operations (opcodes 8-10) need the tracer's op library and stay unsupported here.
+def _op_relu(ops, op, buf):
+    v = buf[op.id0] if op.opcode == 2 else -buf[op.id0]
+    _, i, f = minimal_kif(op.qint)
+    v = np.floor(np.maximum(v, 0.0) * 2.0**f) / 2.0**f
+    return v % 2.0**i
+
+
+def _op_quantize(ops, op, buf):
+    v = buf[op.id0] if op.opcode == 3 else -buf[op.id0]
+    k, i, f = minimal_kif(op.qint)
+    bits, eps = k + i + f, 2.0**-f
+    bias = 2.0 ** (bits - 1) * k
+    return eps * ((np.floor(v / eps) + bias) % 2.0**bits - bias)
+
+
+def _op_mux(ops, op, buf):
+    cond_id = op.data & 0xFFFFFFFF
+    shift = (op.data >> 32) & 0xFFFFFFFF
+    shift = shift if shift < 0x80000000 else shift - 0x100000000
+    other = (buf[op.id1] if op.opcode == 6 else -buf[op.id1]) * 2.0**shift
+    q = ops[cond_id].qint
+    msb = buf[cond_id] < 0 if q.min < 0 else buf[cond_id] >= 2.0 ** (minimal_kif(q)[1] - 1)
+    return np.where(msb, buf[op.id0], other)
+
+
+_NUMERIC_OPS = {
+    2: _op_relu,
+    -2: _op_relu,
+    3: _op_quantize,
+    -3: _op_quantize,
+    4: lambda ops, op, buf: buf[op.id0] + op.data * op.qint.step,
+    5: lambda ops, op, buf: np.full(buf.shape[1], op.data * op.qint.step),
+    6: _op_mux,
+    -6: _op_mux,
+    7: lambda ops, op, buf: buf[op.id0] * buf[op.id1],
+}
+
+
 class CombLogic(NamedTuple):
     """One combinational adder graph: ``ops`` executed in order on a buffer, then ``out_idxs`` read out."""
 
@@ -113,6 +156,8 @@ class CombLogic(NamedTuple):
                 buf[i] = buf[op.id0] + buf[op.id1] * 2.0**op.data
             elif code == 1:
                 buf[i] = buf[op.id0] - buf[op.id1] * 2.0**op.data
+            elif numeric and code in _NUMERIC_OPS:
+                buf[i] = _NUMERIC_OPS[code](self.ops, op, buf)
             else:
                 raise NotImplementedError(f'opcode {code} is outside the CMVM path implemented by da4ml_amd ({op})')
         buf = buf.T

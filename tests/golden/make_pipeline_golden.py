@@ -13,7 +13,7 @@ sys.path.insert(0, str(HERE.parent))
 sys.path.insert(0, str(HERE))
 
 import ref_py  # noqa: E402
-from pipeline_cases import CUTOFFS, SOLVES, handmade, solve_inputs  # noqa: E402
+from pipeline_cases import CUTOFFS, REPLAY, SOLVES, handmade, replay_inputs, solve_inputs  # noqa: E402
 
 
 def dump(p):
@@ -23,7 +23,7 @@ def dump(p):
 def main():
     m = ref_py.load()
     R, rt, rp, rtr = m['oracle'], m['types'], m['pipeline'], m['tracer']
-    out = {'source': 'reference src/da4ml/trace/{pipeline,tracer,fixed_variable}.py + types.py run over oracle/_ref/libref.so', 'split': [], 'retime': [], 'dce': []}
+    out = {'source': 'reference src/da4ml/trace/{pipeline,tracer,fixed_variable}.py + types.py run over oracle/_ref/libref.so', 'split': [], 'retime': [], 'dce': [], 'replay': []}
     for spec in SOLVES:
         k, opts = solve_inputs(spec)
         pipe = ref_py.to_ref_pipeline(rt, R.solve(k, **opts))
@@ -62,6 +62,12 @@ def main():
         out['dce'].append({'solve': 'handmade', 'stage': 0, 'keep_dead_inputs': keep, 'result': dump(rtr.dead_statement_elimination(hm, keep))})
     for cut in (0.0, 1.0, 2.0):
         out['split'].append({'solve': 'handmade', 'stage': 0, 'cutoff': cut, 'result': dump(rp.to_pipeline(hm, cut, retiming=False))})
+    # numeric replay (reference types.py CombLogic.__call__, one sample at a time) of graphs with tracer statements
+    for spec in REPLAY:
+        comb, x = replay_inputs(spec)
+        rc = ref_py.to_ref_comb(rt, comb)
+        out['replay'].append({'graph': spec[0], 'outputs': [[float(v) for v in rc(list(row))] for row in x],
+                              'buffer0': [float(v) for v in rc(list(x[0]), dump=True)]})  # fmt: skip
     path = HERE / 'pipeline_golden.json.gz'
     with gzip.open(path, 'wt', compresslevel=9) as f:
         json.dump(out, f, separators=(',', ':'))

@@ -45,3 +45,33 @@ def handmade() -> CombLogic:
         Op(6, 6, 0, 0, QInterval(-32.0, 28.0, 1.0), 2.0, 5.0),  # 9: dead
     ]
     return CombLogic((3, 3), [0, 0, 0], [8, 5, -1], [0, 1, 0], [False, True, False], ops, -1, -1, None)
+
+
+def handmade2() -> CombLogic:
+    """quantize / constant add / constant / multiply / relu of a negated value / msb-mux on an unsigned condition"""
+    q = QInterval(-8.0, 7.75, 0.25)
+    ops = [
+        Op(0, -1, -1, 0, q, 0.0, 0.0),
+        Op(1, -1, -1, 0, q, 0.0, 0.0),
+        Op(0, 1, 0, -1, QInterval(-12.0, 11.625, 0.125), 1.0, 4.0),  # 2: x0 + x1/2
+        Op(2, -1, 3, 0, QInterval(-4.0, 3.5, 0.5), 1.0, 0.0),  # 3: quantize(2), wraps
+        Op(2, -1, -3, 0, QInterval(-16.0, 15.0, 1.0), 1.0, 0.0),  # 4: quantize(-2)
+        Op(3, -1, 4, 5, QInterval(-1.5, 6.0, 0.5), 1.0, 1.0),  # 5: (3) + 5 * 0.5
+        Op(-1, -1, 5, -3, QInterval(-0.75, -0.75, 0.25), 0.0, 0.0),  # 6: constant -0.75
+        Op(5, 6, 7, 0, QInterval(-4.5, 1.125, 0.125), 2.0, 9.0),  # 7: (5) * (6)
+        Op(1, -1, -2, 0, QInterval(0.0, 8.0, 0.25), 1.0, 1.0),  # 8: relu(-x1)
+        Op(8, 7, -6, (0xFFFFFFFF << 32) | 8, QInterval(-8.0, 8.0, 0.125), 3.0, 2.0),  # 9: msb(8) ? (8) : -(7) >> 1
+        Op(9, 4, 1, 1, QInterval(-40.0, 40.0, 0.125), 4.0, 5.0),  # 10: (9) - 2 (4)
+    ]
+    return CombLogic((2, 3), [0, 0], [10, 7, 3], [0, -1, 2], [False, True, False], ops, -1, -1, None)
+
+
+REPLAY = [('handmade', handmade, -8, 8, 1.0), ('handmade2', handmade2, -32, 32, 0.25)]
+
+
+def replay_inputs(spec):
+    import numpy as np
+
+    name, make, lo, hi, step = spec
+    comb = make()
+    return comb, np.random.default_rng(11).integers(lo, hi, (64, comb.shape[0])) * step

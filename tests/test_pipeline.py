@@ -10,7 +10,7 @@ from pathlib import Path
 import numpy as np
 import pytest
 
-from pipeline_cases import SOLVES, handmade, solve_inputs
+from pipeline_cases import REPLAY, SOLVES, handmade, replay_inputs, solve_inputs
 
 from da4ml_amd.trace import dead_statement_elimination, retime_pipeline, to_pipeline
 from da4ml_amd.types import CombLogic, Pipeline
@@ -101,3 +101,23 @@ def test_bisection_stall_terminates(oracle):
         p = to_pipeline(comb, cut, verbose=False)
         assert len(p.solutions) == len(plain.solutions)
         assert np.array_equal(p.kernel, comb.kernel)
+
+
+def test_numeric_replay_of_tracer_statements_matches_reference():
+    """CombLogic.__call__ on graphs with relu / quantize / constant / multiply / msb-mux statements against the
+    reference's own replay (golden 'replay' section)"""
+    gold = {g['graph']: g for g in GOLDEN['replay']}
+    for spec in REPLAY:
+        comb, x = replay_inputs(spec)
+        assert np.array_equal(comb(x), np.asarray(gold[spec[0]]['outputs'])), spec[0]
+        assert np.array_equal(comb(x[0], dump=True), np.asarray(gold[spec[0]]['buffer0'])), spec[0]
+
+
+def test_retimed_pipeline_with_absent_output_still_evaluates(solved):
+    """random_case(22) has a zero column: after retiming the absent output is a constant-zero statement (opcode 5)"""
+    pipe = solved['random_case_22']
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        rt = retime_pipeline(pipe)
+    assert any(op.opcode == 5 for s in rt.solutions for op in s.ops)
+    assert np.array_equal(rt.kernel, pipe.kernel)

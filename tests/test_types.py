@@ -42,10 +42,14 @@ def test_minimal_kif():
     assert minimal_kif(QInterval(0.0, 0.0, 1.0)) == (False, 0, 0)
 
 
-def test_non_cmvm_opcode_raises():
-    s = CombLogic((1, 1), [0], [1], [0], [False], [Op(0, -1, -1, 0, QInterval(-1, 1, 1), 0.0, 0.0), Op(0, -1, 2, 0, QInterval(0, 1, 1), 0.0, 0.0)], -1, -1)
+def test_unsupported_opcode_raises():
+    """relu & co. replay numerically (tests/test_pipeline.py); lookup tables and bitwise statements stay tracer territory"""
+    s = CombLogic((1, 1), [0], [1], [0], [False], [Op(0, -1, -1, 0, QInterval(-1, 1, 1), 0.0, 0.0), Op(0, -1, 9, 0, QInterval(0, 1, 1), 0.0, 0.0)], -1, -1)
     try:
         s([1.0])
     except NotImplementedError:
-        return
-    raise AssertionError('expected NotImplementedError')
+        pass
+    else:
+        raise AssertionError('expected NotImplementedError')
+    relu = s._replace(ops=[s.ops[0], Op(0, -1, 2, 0, QInterval(0, 1, 1), 0.0, 0.0)])
+    assert relu([1.0]).tolist() == [1.0] and relu([-1.0]).tolist() == [0.0]
