@@ -114,19 +114,83 @@ def gather_to_rank0(obj):
     return out
 
 
-def solve_many_sharded(kernels, **opts):
-    """Solve independent matrices over all ranks: rank r solves its shard on its own GPU; rank 0 returns all results."""
-    from . import _binary
+def estimate_chain_cost(kernel) -> float:
+    """Cheap host-side proxy for the greedy-loop work of one matrix: the number of initial digit pairs
+    ``sum_col C(d_col, 2)`` with ``d_col`` the non-zero CSD digits of a column (P_init; the number of
+    non-zero digits of the signed-digit recoding of ``n`` is ``popcount((3n ^ n) >> 1)``).  Only used to balance shards:
+    it never influences a result."""
+    import numpy as np
 
+    k = np.asarray(kernel, dtype=np.float64)
+    if k.size == 0:
+        return 0.0
+    nz = np.abs(k[k != 0])
+    if nz.size == 0:
+        return 1.0
+    # scale to integers by the finest power of two present (bounded: this is an estimate, not arithmetic)
+    frac = 0
+    while frac < 24 and np.any(nz * 2.0**frac != np.floor(nz * 2.0**frac)):
+        frac += 1
+    n = np.minimum(np.abs(k) * 2.0**frac, 2.0**40).astype(np.int64)
+    x = ((3 * n) ^ n) >> 1
+    digits = np.zeros(k.shape, dtype=np.int64)
+    while np.any(x):
+        digits += x & 1
+        x >>= 1
+    d_col = digits.sum(axis=0).astype(np.float64)
+    return float(np.sum(d_col * (d_col - 1.0) / 2.0)) + float(k.shape[0] + k.shape[1])
+
+
+def balanced_shards(costs, world: int) -> list[list[int]]:
+    """Deterministic longest-processing-time assignment of units to ranks: units by decreasing cost (ties: lower index
+    first), each to the currently least loaded rank (ties: lower rank).  Every rank computes the same table from the same
+    costs, so no exchange is needed; within a rank the units keep their original order."""
+    order = sorted(range(len(costs)), key=lambda i: (-float(costs[i]), i))
+    load = [0.0] * world
+    shards: list[list[int]] = [[] for _ in range(world)]
+    for i in order:
+        r = min(range(world), key=lambda j: (load[j], j))
+        shards[r].append(i)
+        load[r] += float(costs[i])
+    return [sorted(s) for s in shards]
+
+
+def solve_many_sharded(kernels, balance: str = 'cost', solver_many=None, **opts):
+    """Solve independent matrices over all ranks: rank r solves its shard on its own GPU; rank 0 returns all results in
+    the order of ``kernels`` (other ranks: None).  No data-path collective, one result gather.
+
+    ``balance='cost'`` (default) assigns matrices by estimated chain work (``estimate_chain_cost`` + ``balanced_shards``):
+    the layers of a model differ in size by orders of magnitude (BASELINE config C5), and a contiguous split by count
+    leaves most GPUs idle behind the one that drew the big layer.  ``balance='count'`` is the contiguous split (what
+    ``bench.py`` uses for its identical matrices).  ``solver_many`` defaults to the HIP path; the CPU tests inject a
+    stand-in."""
     rank, world, local, _ = init()
-    if _binary.device_count() > 0:
-        _binary.set_device(local % _binary.device_count())
-    lo, hi = shard_bounds(len(kernels), rank, world)
-    mine = _binary.solve_many(kernels[lo:hi], **opts) if hi > lo else []
-    parts = gather_to_rank0(mine)
+    if solver_many is None:
+        from . import _binary
+
+        if _binary.device_count() > 0:
+            _binary.set_device(local % _binary.device_count())
+        solver_many = _binary.solve_many
+    if balance == 'cost':
+        shards = balanced_shards([estimate_chain_cost(k) for k in kernels], world)
+    elif balance == 'count':
+        shards = [list(range(*shard_bounds(len(kernels), r, world))) for r in range(world)]
+    else:
+        raise ValueError(f"balance must be 'cost' or 'count', not {balance!r}")
+    mine = shards[rank]
+    per_kernel = {k: v for k, v in opts.items() if k in ('qintervals', 'latencies') and v is not None}
+    local_opts = {k: v for k, v in opts.items() if k not in per_kernel}
+    for k, v in per_kernel.items():  # one entry per matrix: follow the shard
+        local_opts[k] = [v[i] for i in mine]
+    solved = solver_many([kernels[i] for i in mine], **local_opts) if mine else []
+    parts = gather_to_rank0(list(zip(mine, solved)))
     if parts is None:
         return None
-    return [p for part in parts for p in part]
+    out = [None] * len(kernels)
+    for part in parts:
+        for i, p in part:
+            out[i] = p
+    return out
 
 
 def candidate_list(n_in: int, hard_dc: int = -1) -> tuple[list[int], int]:

@@ -106,3 +106,73 @@ def test_shard_bounds_cover():
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+
+
+def test_cost_estimate_and_balanced_shards():
+    import numpy as np
+    from cases import int_matrix
+
+    from da4ml_amd.multi_gpu import balanced_shards, estimate_chain_cost
+
+    # exact P_init of SURVEY.md section 8 for the C1 / C2 seed-0 matrices (+ n_in + n_out)
+    assert estimate_chain_cost(int_matrix(0, 16, 16, -8, 8)) == 4119 + 32
+    assert estimate_chain_cost(int_matrix(0, 64, 64, -128, 128)) == 1012155 + 128
+    assert estimate_chain_cost(int_matrix(0, 16, 16, -8, 8) * 0.25) == 4119 + 32  # power-of-two scaling does not matter
+    assert estimate_chain_cost(np.zeros((4, 4))) == 1.0 and estimate_chain_cost(np.zeros((0, 3))) == 0.0
+    # a model-like batch: one big layer, many small ones
+    costs = [900.0, 10.0, 10.0, 10.0, 300.0, 300.0, 300.0, 5.0]
+    for world in (1, 2, 3, 8, 16):
+        shards = balanced_shards(costs, world)
+        assert sorted(i for s in shards for i in s) == list(range(len(costs))) and len(shards) == world
+        assert all(s == sorted(s) for s in shards)
+        assert shards == balanced_shards(costs, world)  # deterministic: every rank derives the same table
+    two = balanced_shards(costs, 2)
+    loads = [sum(costs[i] for i in s) for s in two]
+    assert sorted(loads) == [915.0, 920.0]  # the contiguous split by count gives 930 / 905 here and 1210 / 625 for the rotated list
+    assert balanced_shards([1.0] * 4, 2) == [[0, 2], [1, 3]]
+
+
+MANY_WORKER = r'''
+import os, sys, json
+sys.path.insert(0, os.environ["DA_ROOT"]); sys.path.insert(0, os.path.join(os.environ["DA_ROOT"], "tests"))
+from da4ml_amd import multi_gpu as mg
+from oracle.oracle import Oracle   # stand-in solver: this host has no GPU
+from cases import int_matrix
+rank, world, local, device = mg.init("gloo")
+O = Oracle("port")
+def solve_many(kernels, qintervals=None, latencies=None, **kw):
+    return [O.solve(k, qintervals=None if qintervals is None else qintervals[i], latencies=None if latencies is None else latencies[i], **kw)
+            for i, k in enumerate(kernels)]
+shapes = [(12, 30), (3, 3), (4, 5), (20, 20), (2, 9), (6, 6), (16, 8)]
+ks = [int_matrix(40 + i, a, b, -64, 64) for i, (a, b) in enumerate(shapes)]
+lat = [[float(j % 3) for j in range(a)] for a, _ in shapes]
+res = {}
+for balance in ("cost", "count"):
+    got = mg.solve_many_sharded(ks, balance=balance, solver_many=solve_many, latencies=lat, adder_size=1, carry_size=-1)
+    if rank == 0:
+        res[balance] = [bool(g == O.solve(k, latencies=l, adder_size=1, carry_size=-1)) for g, k, l in zip(got, ks, lat)]
+    else:
+        assert got is None
+if rank == 0:
+    print(json.dumps(res), flush=True)
+mg.shutdown()
+'''
+
+
+def test_solve_many_sharded_gloo_world2():
+    """C5: a batch of different layer shapes sharded over two ranks (by estimated cost and by count) comes back on rank 0
+    in input order, every result equal to the single-process solve; per-matrix options follow their matrix."""
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE='2', LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), DA_ROOT=str(ROOT))
+        procs.append(subprocess.Popen([sys.executable, '-c', MANY_WORKER], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300) for p in procs]
+    import json
+
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0, e
+    r = json.loads(outs[0][0].strip().splitlines()[-1])
+    assert r == {'cost': [True] * 7, 'count': [True] * 7}, r
