@@ -20,4 +20,15 @@ for SET in "${SETS[@]}"; do
   python tools/summarise_pmc.py $OUT/pmc_$NAME > $OUT/pmc_$NAME.summary.txt 2>&1
   rm -rf $OUT/pmc_$NAME
 done
+# DAIS device executor (k_dais_run): throughput line + kernel stats + its HBM traffic (DAIS=0 skips)
+if [ "${DAIS:-1}" != "0" ]; then
+  timeout 300 python tools/dais_bench.py 64 1048576 > $OUT/dais_bench.txt 2>&1
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/dais_trace -o dais -- python tools/dais_bench.py 64 1048576 > $OUT/dais_trace.log 2>&1
+  cp $OUT/dais_trace/dais_kernel_stats.csv $OUT/dais_kernel_stats.csv 2>/dev/null; rm -rf $OUT/dais_trace
+  for SET in FETCH_SIZE WRITE_SIZE; do
+    timeout 300 rocprofv3 --pmc $SET --output-format csv -d $OUT/dais_pmc_$SET -o pmc -- python tools/dais_bench.py 64 262144 > $OUT/dais_pmc_$SET.log 2>&1
+    python tools/summarise_pmc.py $OUT/dais_pmc_$SET > $OUT/dais_pmc_$SET.summary.txt 2>&1
+    rm -rf $OUT/dais_pmc_$SET
+  done
+fi
 ls -la $OUT
