@@ -164,8 +164,14 @@ class CombLogic(NamedTuple):
         return buf[0] if single else buf
 
     def __call__(self, inp, quantize=False, debug=False, dump=False):
-        if quantize:
-            raise NotImplementedError('input quantisation belongs to the tracer, not to the CMVM path')
+        if quantize:  # truncate + wrap every input into the format of its input interval (reference types.py:247-249)
+            inp = np.asarray(inp)
+            if not _is_numeric(inp):
+                raise NotImplementedError('quantize=True needs numeric inputs (symbolic replay belongs to the tracer)')
+            k, i, f = (np.asarray(v, dtype=np.float64) for v in self.inp_kifs)
+            bits, eps = k + i + f, 2.0**-f
+            bias = 2.0 ** (bits - 1) * k
+            inp = eps * ((np.floor(inp / eps) + bias) % 2.0**bits - bias)
         buf = self._replay(inp)
         if debug:
             flat = np.asarray(buf)

@@ -68,6 +68,15 @@ def main():
         rc = ref_py.to_ref_comb(rt, comb)
         out['replay'].append({'graph': spec[0], 'outputs': [[float(v) for v in rc(list(row))] for row in x],
                               'buffer0': [float(v) for v in rc(list(x[0]), dump=True)]})  # fmt: skip
+    # quantize=True: inputs truncated + wrapped into the declared input formats first (types.py:247-249), every stage
+    import numpy as np
+
+    out['quantized'] = []
+    for spec in SOLVES[:7]:
+        k, opts = solve_inputs(spec)
+        pipe = ref_py.to_ref_pipeline(rt, R.solve(k, **opts))
+        x = np.random.default_rng(3).uniform(-300, 300, (16, k.shape[0]))
+        out['quantized'].append({'solve': spec[0], 'outputs': [[float(v) for v in pipe(list(row), quantize=True)] for row in x]})
     path = HERE / 'pipeline_golden.json.gz'
     with gzip.open(path, 'wt', compresslevel=9) as f:
         json.dump(out, f, separators=(',', ':'))

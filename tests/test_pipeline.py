@@ -121,3 +121,11 @@ def test_retimed_pipeline_with_absent_output_still_evaluates(solved):
         rt = retime_pipeline(pipe)
     assert any(op.opcode == 5 for s in rt.solutions for op in s.ops)
     assert np.array_equal(rt.kernel, pipe.kernel)
+
+
+def test_input_quantisation_matches_reference(solved):
+    """Pipeline.__call__(x, quantize=True) on off-grid, out-of-range inputs against the reference's replay"""
+    for item in GOLDEN['quantized']:
+        pipe = solved[item['solve']]
+        x = np.random.default_rng(3).uniform(-300, 300, (16, pipe.shape[0]))
+        assert np.array_equal(pipe(x, quantize=True), np.asarray(item['outputs'])), item['solve']
