@@ -23,7 +23,7 @@ from typing import NamedTuple
 
 import numpy as np
 
-__all__ = ['QInterval', 'Precision', 'Op', 'Pair', 'CombLogic', 'Pipeline', 'minimal_kif']
+__all__ = ['QInterval', 'Precision', 'Op', 'Pair', 'DAState', 'CombLogic', 'Pipeline', 'minimal_kif', 'JSONEncoder']
 
 
 class QInterval(NamedTuple):
@@ -61,6 +61,17 @@ class Pair(NamedTuple):
     shift: int
 
 
+class DAState(NamedTuple):
+    """Snapshot of the reference's host-side solver state (reference ``types.py:76-83``); kept for import compatibility --
+    the state of this implementation lives in HBM and is never materialised in this form."""
+
+    shifts: tuple
+    expr: list
+    ops: list
+    freq_stat: dict
+    kernel: np.ndarray
+
+
 def minimal_kif(qi: QInterval, symmetric: bool = False) -> Precision:
     """Smallest (sign, integer, fraction) fixed-point format holding ``qi`` (reference ``types.py:86-114``)."""
     if qi.min == qi.max == 0:
@@ -76,6 +87,9 @@ class _Encoder(json.JSONEncoder):
         if hasattr(o, 'to_dict'):
             return o.to_dict()
         return super().default(o)
+
+
+JSONEncoder = _Encoder  # the reference's public name (``types.py:169``)
 
 
 def _is_numeric(a: np.ndarray) -> bool:
