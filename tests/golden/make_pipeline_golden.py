@@ -13,7 +13,7 @@ sys.path.insert(0, str(HERE.parent))
 sys.path.insert(0, str(HERE))
 
 import ref_py  # noqa: E402
-from pipeline_cases import CUTOFFS, REPLAY, SOLVES, handmade, replay_inputs, solve_inputs  # noqa: E402
+from pipeline_cases import BIG, CUTOFFS, REPLAY, SOLVES, handmade, replay_inputs, solve_inputs  # noqa: E402
 
 
 def dump(p):
@@ -77,6 +77,34 @@ def main():
         pipe = ref_py.to_ref_pipeline(rt, R.solve(k, **opts))
         x = np.random.default_rng(3).uniform(-300, 300, (16, k.shape[0]))
         out['quantized'].append({'solve': spec[0], 'outputs': [[float(v) for v in pipe(list(row), quantize=True)] for row in x]})
+    # larger solver outputs by digest
+    import hashlib
+    import signal
+
+    class _Hang(Exception):
+        pass
+
+    def _alarm(*a):
+        raise _Hang()
+
+    signal.signal(signal.SIGALRM, _alarm)
+    out['big'] = []
+    for name, recipe, opts, cuts in BIG:
+        k, _ = solve_inputs((name, recipe, opts))
+        comb = ref_py.to_ref_pipeline(rt, R.solve(k, **opts)).solutions[0]
+        for cut in cuts:
+            for retiming in (False, True):
+                signal.alarm(60)  # the reference's retiming bisection does not always terminate
+                try:
+                    with contextlib.redirect_stdout(io.StringIO()):
+                        res = rp.to_pipeline(comb, cut, retiming=retiming)
+                except _Hang:
+                    out['big'].append({'solve': name, 'cutoff': cut, 'retiming': retiming, 'reference_hangs': True})
+                    continue
+                finally:
+                    signal.alarm(0)
+                out['big'].append({'solve': name, 'cutoff': cut, 'retiming': retiming, 'n_ops': [len(s.ops) for s in res[0]],
+                                   'sha256': hashlib.sha256(json.dumps(dump(res), separators=(',', ':')).encode()).hexdigest()})  # fmt: skip
     path = HERE / 'pipeline_golden.json.gz'
     with gzip.open(path, 'wt', compresslevel=9) as f:
         json.dump(out, f, separators=(',', ':'))

@@ -19,6 +19,12 @@ SOLVES = [
     ('random_case_22', ('random_case', 22), None),  # zero column -> absent output
 ]
 CUTOFFS = [0.0, 1.0, 2.0, 3.5, 5.0, 1000.0]
+# larger solver outputs, compared by digest: (name, kernel recipe, options, cutoffs)
+BIG = [
+    ('64x64_int8_tracer_cost', ('int_matrix', 0, 64, 64, -128, 128), dict(method0='wmc', method1='wmc', decompose_dc=-1, search_all_decompose_dc=False, adder_size=1, carry_size=-1), (2.0, 4.0, 7.0)),
+    ('64x64_int8_carry8', ('int_matrix', 1, 64, 64, -128, 128), dict(method0='wmc', method1='wmc', decompose_dc=-1, search_all_decompose_dc=False, adder_size=4, carry_size=8), (6.0, 15.0)),
+    ('48x40_int8_dc2', ('int_matrix', 2, 48, 40, -128, 128), dict(adder_size=2, carry_size=4, decompose_dc=2, search_all_decompose_dc=False), (5.0, 12.5)),
+]
 
 
 def solve_inputs(spec):

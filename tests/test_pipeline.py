@@ -10,7 +10,7 @@ from pathlib import Path
 import numpy as np
 import pytest
 
-from pipeline_cases import REPLAY, SOLVES, handmade, replay_inputs, solve_inputs
+from pipeline_cases import BIG, REPLAY, SOLVES, handmade, replay_inputs, solve_inputs
 
 from da4ml_amd.trace import dead_statement_elimination, retime_pipeline, to_pipeline
 from da4ml_amd.types import CombLogic, Pipeline
@@ -129,3 +129,25 @@ def test_input_quantisation_matches_reference(solved):
         pipe = solved[item['solve']]
         x = np.random.default_rng(3).uniform(-300, 300, (16, pipe.shape[0]))
         assert np.array_equal(pipe(x, quantize=True), np.asarray(item['outputs'])), item['solve']
+
+
+def test_larger_solver_outputs_by_digest(oracle):
+    import hashlib
+
+    want = {(g['solve'], g['cutoff'], g['retiming']): g for g in GOLDEN['big']}
+    seen = 0
+    for name, recipe, opts, cuts in BIG:
+        k, _ = solve_inputs((name, recipe, opts))
+        comb = oracle.solve(k, **opts).solutions[0]
+        for cut in cuts:
+            for retiming in (False, True):
+                p = to_pipeline(comb, cut, retiming=retiming, verbose=False)
+                g = want[(name, cut, retiming)]
+                if g.get('reference_hangs'):  # the reference's bisection never returns here; ours must, with the same function
+                    assert np.array_equal(p.kernel, comb.kernel)
+                    seen += 1
+                    continue
+                assert [len(s.ops) for s in p.solutions] == g['n_ops'], (name, cut, retiming)
+                assert hashlib.sha256(json.dumps(dump(p), separators=(',', ':')).encode()).hexdigest() == g['sha256'], (name, cut, retiming)
+                seen += 1
+    assert seen == len(GOLDEN['big']) == 14
