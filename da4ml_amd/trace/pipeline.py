@@ -6,9 +6,8 @@ Same names, arguments and results as the reference's ``src/da4ml/trace/pipeline.
 re-derives exactly what that round trip produces for the statements the CMVM solver emits -- input copies, add and
 subtract: intervals and power-of-two scale factors of every value (``fixed_variable.py:441-513,586-609``), the adder
 cost/latency model with the stage-boundary rule (``fixed_variable.py:341-379``), the tracer's statement order
-(``tracer.py:12-58``) and its dead-statement pass, with the constant zero of absent terms.  Anything else (other
-opcodes, non-zero constants) raises
-``NotImplementedError`` instead of guessing.  Pinned to the reference's own Python (run in the build container, see
+(``tracer.py:12-58``) and its dead-statement pass, with constant terms (zero-width input intervals become constant-add
+statements, absent outputs the constant zero).  Any other opcode raises ``NotImplementedError`` instead of guessing.  Pinned to the reference's own Python (run in the build container, see
 ``make_pipeline_golden.py`` next to the golden vectors) by ``pipeline_golden.json.gz``.
 """
 
@@ -163,6 +162,7 @@ class _Retimer:
         self.lat: list[float] = []
         self.cost: list[float] = []
         self.const: list[float | None] = []  # value of a constant node (zero-width interval), None otherwise
+        self.cadd: dict[int, float] = {}  # constant-add nodes: node -> constant in units of the source term (src[n] = (term,))
 
     # -- terms
     def new_input(self, qint: QInterval):
@@ -199,14 +199,32 @@ class _Retimer:
             return self.new_const(-self.const[n])
         return (n, -hi, -lo, st, -f)
 
+    def const_added(self, t, c: float):
+        """``t + c`` for a plain number ``c`` (reference ``_const_add``, fixed_variable.py:484-513): nothing for zero, a new
+        constant for a constant, a constant-add statement otherwise -- merged into ``t``'s own when ``t`` already is one."""
+        n, lo, hi, st, f = t
+        if c == 0:
+            return t
+        if self.const[n] is not None:
+            return self.new_const(self.const[n] + c)
+        if n in self.cadd:
+            parent = self.src[n][0]
+            sf = f / parent[4]
+            return self.scaled(self.const_added(parent, self.cadd[n] * parent[4] + c / sf), sf)
+        data = c / f
+        fb = _const_frac_bits(data)
+        self.src.append((t,))
+        self.lat.append(self.lat[n])
+        self.cost.append(float(ceil(log2(abs(data) + 2.0**-fb))) + fb)
+        self.const.append(None)
+        self.cadd[len(self.src) - 1] = data
+        return (len(self.src) - 1, lo + c, hi + c, min(st, 2.0 ** -_const_frac_bits(c)), f)
+
     def added(self, a, b):
-        # adding the constant zero returns the other term untouched (reference ``_const_add``, fixed_variable.py:488-495);
-        # any other constant would become a constant-add statement of the tracer, which retiming here does not cover
-        for const, other in ((b, a), (a, b)):
-            if self.const[const[0]] is not None:
-                if self.const[const[0]] != 0:
-                    raise NotImplementedError('non-zero constant terms (zero-width input intervals) are outside what retiming covers')
-                return other
+        if self.const[b[0]] is not None:
+            return self.const_added(a, self.const[b[0]])
+        if self.const[a[0]] is not None:
+            return self.const_added(b, self.const[a[0]])
         if a[4] < 0:
             if b[4] > 0:
                 return self.added(b, a)
@@ -266,9 +284,8 @@ class _Retimer:
                 stack.append((n, True))
                 if self.src[n] is None:  # a constant output
                     continue
-                a, b = self.src[n]
-                stack.append((b[0], False))
-                stack.append((a[0], False))
+                for t in reversed(self.src[n]):
+                    stack.append((t[0], False))
         total = len(order)
         ranked = sorted(range(total), key=lambda i: self.lat[order[i]] * total + i)
         order = [order[i] for i in ranked]
@@ -276,7 +293,7 @@ class _Retimer:
         used = {t[0] for t in outputs}
         for n in order:
             if self.src[n] is not None:
-                used.update((self.src[n][0][0], self.src[n][1][0]))
+                used.update(t[0] for t in self.src[n])
         input_no = {t[0]: j for j, t in enumerate(inputs)}
         order = [n for n in order if n in used or n in input_no]
         index = {n: i for i, n in enumerate(order)}
@@ -291,6 +308,14 @@ class _Retimer:
             if self.src[n] is None:
                 _, lo, hi, st, f = shape_of[n]
                 ops.append(Op(input_no[n], -1, -1, 0, QInterval(lo, hi, st), self.lat[n], 0.0))
+                continue
+            if n in self.cadd:  # constant add: data in units of the statement's own (unscaled) step
+                (a,) = self.src[n]
+                c = self.cadd[n] * a[4]
+                lo, hi = sorted(((a[1] + c) / a[4], (a[2] + c) / a[4]))
+                st = min(a[3], 2.0 ** -_const_frac_bits(c)) / abs(a[4])
+                assert index[a[0]] < i
+                ops.append(Op(index[a[0]], -1, 4, int(self.cadd[n] / st), QInterval(lo, hi, st), self.lat[n], self.cost[n]))
                 continue
             a, b = self.src[n]
             fa, fb = a[4], b[4]

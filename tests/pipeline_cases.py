@@ -17,7 +17,7 @@ SOLVES = [
     ('random_case_9', ('random_case', 9), None),
     ('random_case_14', ('random_case', 14), None),  # zero row
     ('random_case_22', ('random_case', 22), None),  # zero column -> absent output
-]
+] + [(f'const_inputs_{s}', ('const_input_case', s), None) for s in range(12)]
 CUTOFFS = [0.0, 1.0, 2.0, 3.5, 5.0, 1000.0]
 # larger solver outputs, compared by digest: (name, kernel recipe, options, cutoffs)
 BIG = [
@@ -27,8 +27,29 @@ BIG = [
 ]
 
 
+def const_input_case(seed):
+    """A small matrix whose inputs are partly constants (zero-width intervals): retiming turns them into constant adds."""
+    import numpy as np
+
+    rng = np.random.default_rng(seed)
+    n_in, n_out = int(rng.integers(3, 14)), int(rng.integers(2, 14))
+    k = int_matrix(seed, n_in, n_out, -64, 64)
+    q = []
+    for _ in range(n_in):
+        st = float(2.0 ** rng.integers(-2, 2))
+        if rng.random() < 0.35:
+            c = float(rng.integers(-9, 10)) * st
+            q.append((c, c, st))
+        else:
+            lo = float(rng.integers(-40, 1)) * st
+            q.append((lo, lo + float(rng.integers(1, 90)) * st, st))
+    return k, dict(qintervals=q, adder_size=int(rng.choice([-1, 1, 4])), carry_size=int(rng.choice([-1, 4, 8])))
+
+
 def solve_inputs(spec):
     name, recipe, opts = spec
+    if recipe[0] == 'const_input_case':
+        return const_input_case(recipe[1])
     if recipe[0] == 'random_case':
         k, o, _ = random_case(recipe[1])
         return k, o

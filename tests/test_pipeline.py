@@ -69,6 +69,8 @@ def test_retiming_matches_reference(solved):
         if not isinstance(it['result'], dict):
             assert buf.getvalue() == it['stdout']
     assert ok >= 40
+    # constant inputs (zero-width intervals) come back as constant-add statements
+    assert sum(any(op[2] == 4 for st in it['result'][0] for op in st[5]) for it in GOLDEN['retime'] if not isinstance(it['result'], dict)) >= 4
 
 
 def test_split_and_retime_keep_the_function(solved):
