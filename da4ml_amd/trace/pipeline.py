@@ -83,8 +83,6 @@ class _Splitter:
 
 def _split(comb: CombLogic, cutoff: float) -> Pipeline:
     assert len(comb.ops) > 0, 'No operations in the record'
-    if comb.lookup_tables is not None:
-        raise NotImplementedError('lookup tables are outside the CMVM path')
     values = list(comb.ops)
     # all outputs leave in the stage of the slowest one (an absent output, index -1, reads the last statement here, as in
     # the reference where ops[-1] is Python's last element)
@@ -100,6 +98,12 @@ def _split(comb: CombLogic, cutoff: float) -> Pipeline:
     for s in range(len(sp.stage_ops)):
         ops, outs = sp.stage_ops[s], sp.stage_outs[s]
         final = s == last
+        tables = None
+        if comb.lookup_tables is not None:  # every stage keeps only the tables it uses, renumbered in ascending order
+            used = sorted({op.data for op in ops if op.opcode == 8})
+            renumber = {t: j for j, t in enumerate(used)}
+            ops = [op._replace(data=renumber[op.data]) if op.opcode == 8 else op for op in ops]
+            tables = tuple(comb.lookup_tables[t] for t in used)
         stages.append(
             CombLogic(
                 shape=(n_in, len(outs)),
@@ -110,7 +114,7 @@ def _split(comb: CombLogic, cutoff: float) -> Pipeline:
                 ops=ops,
                 carry_size=comb.carry_size,
                 adder_size=comb.adder_size,
-                lookup_tables=None,
+                lookup_tables=tables,
             )
         )
         n_in = len(outs)

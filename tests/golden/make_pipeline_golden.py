@@ -13,7 +13,7 @@ sys.path.insert(0, str(HERE.parent))
 sys.path.insert(0, str(HERE))
 
 import ref_py  # noqa: E402
-from pipeline_cases import BIG, CUTOFFS, REPLAY, SOLVES, handmade, replay_inputs, solve_inputs  # noqa: E402
+from pipeline_cases import BIG, CUTOFFS, REPLAY, SOLVES, handmade, handmade_tables, replay_inputs, solve_inputs  # noqa: E402
 
 
 def dump(p):
@@ -62,6 +62,12 @@ def main():
         out['dce'].append({'solve': 'handmade', 'stage': 0, 'keep_dead_inputs': keep, 'result': dump(rtr.dead_statement_elimination(hm, keep))})
     for cut in (0.0, 1.0, 2.0):
         out['split'].append({'solve': 'handmade', 'stage': 0, 'cutoff': cut, 'result': dump(rp.to_pipeline(hm, cut, retiming=False))})
+    ht = handmade_tables()
+    ht_ref = ref_py.to_ref_comb(rt, ht)._replace(lookup_tables=ht.lookup_tables)  # table objects are opaque to these passes
+    for cut in (0.0, 1.0, 1.5, 3.0):
+        out['split'].append({'solve': 'handmade_tables', 'stage': 0, 'cutoff': cut, 'result': dump(rp.to_pipeline(ht_ref, cut, retiming=False))})
+    for keep in (False, True):
+        out['dce'].append({'solve': 'handmade_tables', 'stage': 0, 'keep_dead_inputs': keep, 'result': dump(rtr.dead_statement_elimination(ht_ref, keep))})
     # numeric replay (reference types.py CombLogic.__call__, one sample at a time) of graphs with tracer statements
     for spec in REPLAY:
         comb, x = replay_inputs(spec)

@@ -102,3 +102,19 @@ def replay_inputs(spec):
     name, make, lo, hi, step = spec
     comb = make()
     return comb, np.random.default_rng(11).integers(lo, hi, (64, comb.shape[0])) * step
+
+
+def handmade_tables() -> CombLogic:
+    """lookup statements (opcode 8) spread over stages: each stage keeps and renumbers only its own tables"""
+    q = QInterval(0.0, 7.0, 1.0)
+    ops = [
+        Op(0, -1, -1, 0, q, 0.0, 0.0),
+        Op(1, -1, -1, 0, q, 0.0, 0.0),
+        Op(0, -1, 8, 2, QInterval(0.0, 15.0, 1.0), 1.0, 4.0),  # 2: table 2
+        Op(1, -1, 8, 0, QInterval(0.0, 15.0, 1.0), 1.0, 4.0),  # 3: table 0
+        Op(2, 3, 0, 0, QInterval(0.0, 30.0, 1.0), 2.0, 5.0),  # 4
+        Op(4, -1, 8, 3, QInterval(0.0, 3.0, 1.0), 3.5, 4.0),  # 5: table 3
+        Op(2, -1, 8, 2, QInterval(0.0, 3.0, 1.0), 3.0, 4.0),  # 6: table 2 again, later stage
+        Op(5, 6, 0, 0, QInterval(0.0, 6.0, 1.0), 4.5, 3.0),  # 7
+    ]
+    return CombLogic((2, 2), [0, 0], [7, 4], [0, 0], [False, False], ops, -1, -1, ('t0', 't1', 't2', 't3'))
