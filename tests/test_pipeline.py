@@ -13,7 +13,7 @@ import pytest
 from pipeline_cases import BIG, REPLAY, SOLVES, handmade, handmade_tables, replay_inputs, solve_inputs
 
 from da4ml_amd.trace import dead_statement_elimination, retime_pipeline, to_pipeline
-from da4ml_amd.types import CombLogic, Pipeline
+from da4ml_amd.types import Pipeline
 
 GOLDEN = json.load(gzip.open(Path(__file__).parent / 'golden' / 'pipeline_golden.json.gz', 'rt'))
 ERRORS = {'KeyError': KeyError, 'IndexError': IndexError, 'AssertionError': AssertionError, 'ValueError': ValueError}
