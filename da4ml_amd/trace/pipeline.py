@@ -155,8 +155,8 @@ class _Retimer:
     """Re-derives a pipeline of add/subtract statements under a new latency cutoff.
 
     A *term* is ``(node, low, high, step, factor)``: a node of the new graph seen through a power-of-two (possibly
-    negative) scale, with the interval of the scaled value.  Nodes: ``src[n]`` is ``None`` for an input, else the two
-    terms that were added.  All numbers are dyadic rationals well inside double precision, so floats are exact where the
+    negative) scale, with the interval of the scaled value.  Nodes: ``src[n]`` is ``None`` for an input or a constant,
+    the one term a constant was added to (``cadd[n]``), else the two terms that were added.  All numbers are dyadic rationals well inside double precision, so floats are exact where the
     reference uses ``Decimal``."""
 
     def __init__(self, adder_size: int, carry_size: int, cutoff: float, cost_add):
