@@ -26,7 +26,7 @@ _i64p = np.ctypeslib.ndpointer(np.int64, flags='C_CONTIGUOUS')
 _i32p = np.ctypeslib.ndpointer(np.int32, flags='C_CONTIGUOUS')
 
 EXPORTS = (
-    'da_last_error da_version da_device_count da_set_device da_get_lsb_loc da_iceil_log2 da_cost_add da_int_arr_to_csd '
+    'da_last_error da_last_error_code da_version da_device_count da_set_device da_get_lsb_loc da_iceil_log2 da_cost_add da_int_arr_to_csd '
     'da_csd_decompose da_kernel_decompose da_solve da_solve_batch da_n_stages da_picked da_stage_info da_stage_copy '
     'da_result_stats da_free da_timings da_dais_run da_dais_last_error da_dais_run_on'
 ).split()
@@ -39,17 +39,33 @@ def lib():
         return _lib
     csrc = Path(__file__).resolve().parent.parent / 'csrc'
     sources = [p for p in csrc.glob('*') if p.suffix in ('.hip', '.cc', '.h')] + [_LIB_PATH.parent.parent / 'include' / 'da4ml_hip.h']
-    stale = not _os.environ.get('DA4ML_HIP_LIB') and (not _LIB_PATH.exists() or any(p.exists() and p.stat().st_mtime > _LIB_PATH.stat().st_mtime for p in sources))
-    if stale:  # build in-tree (hipcc cross-compiles for gfx950 without a GPU); never fall back to anything else
+    def _stale():
+        return not _LIB_PATH.exists() or any(p.exists() and p.stat().st_mtime > _LIB_PATH.stat().st_mtime for p in sources)
+
+    if not _os.environ.get('DA4ML_HIP_LIB') and _stale():
+        # build in-tree (hipcc cross-compiles for gfx950 without a GPU); never fall back to anything else.  Ranks of one
+        # job reach this point together: the build is serialised by a file lock, goes to a temporary file and is moved
+        # into place atomically, so that no process ever maps a half-written library; a failed rebuild is an error, not
+        # a silent load of the stale library (its ABI may no longer match the argtypes below).
+        import fcntl
         import shutil
         import subprocess
 
         if shutil.which('make') and (shutil.which('hipcc') or Path('/opt/rocm/bin/hipcc').exists()):
-            subprocess.run(['make', '-C', str(csrc)], check=False, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            with open(_LIB_PATH.parent / '.build.lock', 'w') as lock:
+                fcntl.flock(lock, fcntl.LOCK_EX)
+                if _stale():  # not rebuilt by another process while this one waited
+                    tmp = _LIB_PATH.with_suffix(f'.tmp{_os.getpid()}.so')
+                    r = subprocess.run(['make', '-C', str(csrc), 'variant', f'OUT={tmp}'], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+                    if r.returncode != 0 or not tmp.exists():
+                        tmp.unlink(missing_ok=True)
+                        raise ImportError(f'rebuilding {_LIB_PATH.name} failed (sources are newer than the library):\n{r.stdout[-2000:]}')
+                    _os.replace(tmp, _LIB_PATH)
     if not _LIB_PATH.exists():
         raise ImportError(f'{_LIB_PATH} is missing: build it with `python -c "import __graft_entry__ as g; g.build()"` or `make -C da4ml_amd/csrc`')
     L = C.CDLL(str(_LIB_PATH))
     L.da_last_error.restype = C.c_char_p
+    L.da_last_error_code.restype = C.c_int
     L.da_version.restype = C.c_char_p
     L.da_set_device.argtypes = [C.c_int]
     L.da_get_lsb_loc.argtypes = [C.c_float]
@@ -206,7 +222,7 @@ def solve(
                        None if q is None else q.ctypes.data, None if l is None else l.ctypes.data,
                        int(adder_size), int(carry_size), int(bool(search_all_decompose_dc)))  # fmt: skip
     if not h:
-        _raise(-2 if 'must' in lib().da_last_error().decode() else -1)
+        _raise(lib().da_last_error_code())
     return _collect(h, _stats)
 
 

@@ -15,6 +15,7 @@
 namespace {
 
 thread_local std::string g_err;
+thread_local int g_err_code = DA_OK;  // DA_ERR_* of the calling thread's last failure (da_last_error_code)
 std::mutex g_mutex;
 int g_device = 0;
 std::unique_ptr<da::gpu::HipBackend> g_backend;
@@ -31,9 +32,13 @@ da::gpu::HipBackend &backend() {
 
 int fail(const std::exception &e) {
     g_err = e.what();
-    if (dynamic_cast<const std::invalid_argument *>(&e)) return DA_ERR_VALUE;
-    if (g_err.rfind("no HIP device", 0) == 0) return DA_ERR_NO_DEVICE;
-    return DA_ERR_RUNTIME;
+    if (dynamic_cast<const std::invalid_argument *>(&e))
+        g_err_code = DA_ERR_VALUE;
+    else if (g_err.rfind("no HIP device", 0) == 0)
+        g_err_code = DA_ERR_NO_DEVICE;
+    else
+        g_err_code = DA_ERR_RUNTIME;
+    return g_err_code;
 }
 
 void check_dyadic_steps(const float *q, int64_t n_in) {
@@ -58,13 +63,14 @@ struct da_result {
 extern "C" {
 
 const char *da_last_error(void) { return g_err.c_str(); }
+int da_last_error_code(void) { return g_err_code; }
 const char *da_version(void) { return "da4ml_hip 0.1 (gfx950)"; }
 int da_device_count(void) { return da::gpu::device_count(); }
 int da_set_device(int device) {
     std::lock_guard<std::mutex> lk(g_mutex);
     if (device < 0 || device >= da::gpu::device_count()) {
         g_err = "invalid device index " + std::to_string(device);
-        return DA_ERR_NO_DEVICE;
+        return g_err_code = DA_ERR_NO_DEVICE;
     }
     g_device = device;
     return DA_OK;

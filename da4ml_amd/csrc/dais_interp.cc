@@ -116,9 +116,13 @@ Program decode(const int32_t *p, int64_t n_words) {
             s.sh_a = lshift(i, sh0), s.sh_b = lshift(i, sh1);
             const Fmt &fc = fmt[lo];
             s.aux = fc.sgn;
-            if (!fc.sgn) {  // the reference's unsigned msb test is `value > max(2^(width-2), 0)` (DAISInterpreter.cc:176-180)
-                if (fc.width() < 2) bad("msb_mux condition narrower than 2 bits");
-                s.imm = (int64_t)1 << (fc.width() - 2);
+            if (!fc.sgn) {
+                // the reference's unsigned msb test is `value > max(1LL << (width-2), 0LL)` (DAISInterpreter.cc:177-181).
+                // For a 1-bit condition -- what `np.where(cond.to_bool(), ..)` traces to -- the shift count is -1,
+                // which the x86 `shl` of the reference build takes modulo 64: 1 << 63 is negative, the max() gives 0 and
+                // the test is `value > 0`.  Reproduced here for every width < 2 (count & 63), not rejected.
+                const int64_t t = (int64_t)((uint64_t)1 << ((unsigned)(fc.width() - 2) & 63u));
+                s.imm = t > 0 ? t : 0;
             }
             set_wrap(s, to);
             break;

@@ -16,6 +16,7 @@ pass over the op list instead of ``n_in`` passes.
 from __future__ import annotations
 
 import json
+import os
 from functools import reduce
 from math import ceil, log2
 from pathlib import Path
@@ -138,6 +139,41 @@ _NUMERIC_OPS = {
 }
 
 
+def _s32(word: int) -> int:
+    word &= 0xFFFFFFFF
+    return word - (1 << 32) if word >= (1 << 31) else word
+
+
+def _describe(op) -> str:
+    """One-line description of a statement for ``CombLogic.__call__(debug=True)`` (every opcode of docs/dais.md)."""
+    code, a, b, d = op.opcode, op.id0, op.id1, int(op.data)
+    neg = '-' if code < 0 else ''
+    if code == -1:
+        return 'inp'
+    if code in (0, 1):
+        return f'buf[{a}] {"+-"[code]} buf[{b}]<<{d}'
+    if code in (2, -2):
+        return f'relu({neg}buf[{a}])'
+    if code in (3, -3):
+        return f'quantize({neg}buf[{a}])'
+    if code == 4:
+        return f'buf[{a}] + {d * op.qint.step}'
+    if code == 5:
+        return f'const {d * op.qint.step}'
+    if code in (6, -6):
+        return f'msb(buf[{d & 0xFFFFFFFF}]) ? buf[{a}] : {neg}buf[{b}] << {_s32(d >> 32)}'
+    if code == 7:
+        return f'buf[{a}] * buf[{b}]'
+    if code == 8:
+        return f'tables[{d & 0xFFFFFFFF}].lookup(buf[{a}])'
+    if code in (9, -9):
+        return f'{ {0: "~", 1: "any", 2: "all"}.get(d, "?")}({neg}buf[{a}])'
+    if code == 10:
+        sym = {0: '&', 1: '|', 2: '^'}.get((d >> 56) & 0xFF, '?')
+        return f'{"-" if (d >> 32) & 1 else ""}buf[{a}] {sym} {"-" if (d >> 33) & 1 else ""}buf[{b}] << {_s32(d)}'
+    return f'opcode {code}({a}, {b}, {d})'
+
+
 class CombLogic(NamedTuple):
     """One combinational adder graph: ``ops`` executed in order on a buffer, then ``out_idxs`` read out."""
 
@@ -191,8 +227,7 @@ class CombLogic(NamedTuple):
             flat = np.asarray(buf)
             flat = flat[0] if flat.ndim == 2 else flat
             for i, (op, v) in enumerate(zip(self.ops, flat)):
-                desc = 'inp' if op.opcode == -1 else f'buf[{op.id0}] {"+-"[op.opcode]} buf[{op.id1}]<<{op.data}'
-                print(f'{desc:<32} |-> buf[{i}] = {v}')
+                print(f'{_describe(op):<48} |-> buf[{i}] = {v}')
         if dump:
             return buf
         idx = np.asarray(self.out_idxs, dtype=np.int64)
@@ -273,6 +308,8 @@ class CombLogic(NamedTuple):
             for j in (op.id0, op.id1):
                 if j != -1:
                     cnt[j] += 1
+            if op.opcode in (6, -6):  # the msb-mux condition is a third operand (reference types.py:491-493)
+                cnt[op.data & 0xFFFFFFFF] += 1
         for i in self.out_idxs:
             if i >= 0:
                 cnt[i] += 1
@@ -301,17 +338,32 @@ class CombLogic(NamedTuple):
             return cls.deserialize(json.load(f))
 
     def to_binary(self, version: int = 0) -> np.ndarray:
-        """int32 DAIS program (layout: reference ``docs/dais.md:70-95``, ``types.py:500-541``)."""
+        """int32 DAIS program (layout: reference ``docs/dais.md:70-95``, ``types.py:500-541``): header, 8 words per
+        statement, then -- when the logic carries lookup tables -- the table sizes and the tables.  A table object must
+        offer what the reference's ``LookupTable`` does (``.table`` int32 entries, ``._get_pads(qint)``); anything else
+        raises instead of writing a program whose table statements could not be executed."""
         n_in, n_out = self.shape
+        tables = self.lookup_tables
+        if tables is not None and not all(hasattr(t, 'table') and hasattr(t, '_get_pads') for t in tables):
+            raise NotImplementedError('lookup tables without .table / ._get_pads cannot be serialised to a DAIS program')
         head = np.concatenate(
-            [[1, version, n_in, n_out, len(self.ops), 0], self.inp_shifts, self.out_idxs, self.out_shifts, self.out_negs]
+            [[1, version, n_in, n_out, len(self.ops), 0 if tables is None else len(tables)], self.inp_shifts, self.out_idxs, self.out_shifts, self.out_negs]
         ).astype(np.int32)
         code = np.zeros((len(self.ops), 8), dtype=np.int32)
         for i, op in enumerate(self.ops):
             code[i, 0:3] = (op.opcode, op.id0, op.id1)
-            code[i, 3:5].view(np.uint64)[0] = np.uint64(op.data & 0xFFFFFFFFFFFFFFFF)
+            data = int(op.data)
+            if op.opcode == 8:  # table statement: index in the low word, left padding of the table in the high word
+                if tables is None:
+                    raise NotImplementedError(f'statement {i} looks up table {data} but the logic has no lookup_tables')
+                data = (int(tables[data]._get_pads(self.ops[op.id0].qint)[0]) << 32) | data
+            code[i, 3:5].view(np.uint64)[0] = np.uint64(data & 0xFFFFFFFFFFFFFFFF)
             code[i, 5:8] = minimal_kif(op.qint)
-        return np.concatenate([head, code.ravel()])
+        words = [head, code.ravel()]
+        if tables is not None:
+            bodies = [np.asarray(t.table, dtype=np.int32).ravel() for t in tables]
+            words += [np.asarray([len(b) for b in bodies], dtype=np.int32), *bodies]
+        return np.concatenate(words)
 
     def save_binary(self, path: str | Path, version: int = 0):
         self.to_binary(version).tofile(str(path))
@@ -323,6 +375,8 @@ class CombLogic(NamedTuple):
 
         if isinstance(data, (list, tuple)):
             data = np.concatenate([np.asarray(a).reshape(len(a), -1) for a in data], axis=-1)
+        if n_threads <= 0:  # the reference's default thread count comes from the environment (types.py:577-578)
+            n_threads = int(os.environ.get('DA_DEFAULT_THREADS', 0))
         return dais_interp_run(self.to_binary(), np.asarray(data, dtype=np.float64), n_threads, executor)
 
 

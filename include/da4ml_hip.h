@@ -31,6 +31,10 @@ typedef struct da_result da_result; /* one solved Pipeline (two CombLogic stages
 
 /* ---- library / device ------------------------------------------------------------------------------------ */
 const char *da_last_error(void);
+/* DA_ERR_* class of the calling thread's last failure -- which Python exception the reference would have raised
+ * (std::invalid_argument -> ValueError, std::runtime_error -> RuntimeError; bindings.cc / state_opr.cc:70-72).  Needed
+ * by the handle-returning entry points (da_solve returns NULL without a code). */
+int da_last_error_code(void);
 const char *da_version(void);
 int da_device_count(void);     /* number of visible HIP devices (0 if none) */
 int da_set_device(int device); /* device used by subsequent calls of this process (default 0) */

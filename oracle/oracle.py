@@ -17,13 +17,32 @@ from pathlib import Path
 
 import numpy as np
 
-from da4ml_amd._marshal import pipeline_from_stages, stage_from_arrays
+from da4ml_amd.types import CombLogic, Op, Pipeline, QInterval  # the result data model only: the conversion below is the oracle's own
 
 HERE = Path(__file__).resolve().parent
 _f32p = np.ctypeslib.ndpointer(np.float32, flags='C_CONTIGUOUS')
 _i64p = np.ctypeslib.ndpointer(np.int64, flags='C_CONTIGUOUS')
 _i8p = np.ctypeslib.ndpointer(np.int8, flags='C_CONTIGUOUS')
 _i32p = np.ctypeslib.ndpointer(np.int32, flags='C_CONTIGUOUS')
+
+
+
+def stage_from_arrays(n_in, n_out, inp_shifts, out_idxs, out_shifts, out_negs, ops_i, ops_f, carry_size, adder_size):
+    """C arrays of one stage -> CombLogic.  Deliberately NOT the product's da4ml_amd._marshal (row-by-row here, array-wise
+    there): a conversion bug must not cancel between the checker and the thing checked."""
+    ops = []
+    for row in range(len(ops_i)):
+        id0, id1, opcode, data = (int(ops_i[row, c]) for c in range(4))
+        lo, hi, step, latency, cost = (float(ops_f[row, c]) for c in range(5))
+        ops.append(Op(id0, id1, opcode, data, QInterval(lo, hi, step), latency, cost))
+    as_ints = lambda a: [int(v) for v in a]  # noqa: E731
+    return CombLogic((int(n_in), int(n_out)), as_ints(inp_shifts), as_ints(out_idxs), as_ints(out_shifts), [int(v) != 0 for v in out_negs],
+                     ops, int(carry_size), int(adder_size))  # fmt: skip
+
+
+def pipeline_from_stages(stages):
+    return Pipeline(tuple(stages))
+
 
 STAT_NAMES = ('iterations', 'p_init', 'd0', 'f_first', 'f_sum', 'f_max', 'live_sum', 'match_sum', 'regen_pairs', 'tree_ops')
 

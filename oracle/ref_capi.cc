@@ -8,6 +8,8 @@
 #include "state_opr.hh"
 
 #include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
@@ -82,6 +84,12 @@ int ref_sample_chain(const float *kernel, int64_t n_in, int64_t n_out, const cha
         auto t1 = std::chrono::steady_clock::now();
         out[0] = std::chrono::duration<double>(t1 - t0).count();
         out[1] = out[2] = out[3] = 0;
+        // optional time marks "iteration seconds-since-start" (env REF_TRACE=<file>): the calibration curve of
+        // bench.py's cpu_baseline (tests/golden/make_cpu_calibration.py); instrumentation only
+        FILE *trace = nullptr;
+        if (const char *tp = std::getenv("REF_TRACE")) trace = std::fopen(tp, "w");
+        if (trace) std::fprintf(trace, "0 %.6f\n", out[0]);
+        long long next_mark = 1;
         while (true) {
             if (s.freq_stat.empty()) {
                 out[3] = 1;
@@ -95,7 +103,16 @@ int ref_sample_chain(const float *kernel, int64_t n_in, int64_t n_out, const cha
             update_state(s, pick, -1, -1);
             out[1] += 1;
             out[2] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
+            if (trace && (long long)out[1] >= next_mark) {
+                std::fprintf(trace, "%lld %.6f\n", (long long)out[1], out[0] + out[2]);
+                std::fflush(trace);
+                next_mark = next_mark < 64 ? next_mark * 2 : next_mark + (next_mark < 1024 ? 64 : 256);
+            }
             if (out[2] >= budget_s) break;
+        }
+        if (trace) {
+            std::fprintf(trace, "%lld %.6f\n", (long long)out[1], out[0] + out[2]);
+            std::fclose(trace);
         }
         return 0;
     } catch (const std::exception &e) {

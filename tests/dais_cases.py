@@ -60,7 +60,7 @@ def random_program(seed, n_in=4, n_ops=64, n_out=6, n_samples=24):
             lo, hi = _imm_words(v)
             push(5, -1, -1, lo, hi, (1, 10, int(rng.integers(0, 3))), 'const', abs(v) + 1)
         elif what == 'mux':
-            cands = [q for q in range(i) if fmt[q][0] == 1 or sum(fmt[q]) >= 2]
+            cands = list(range(i))  # incl. unsigned 1-bit conditions (reduce-or outputs, np.where's to_bool)
             c = int(rng.choice(cands))
             out_frac = fa[2]
             hi = (fb[2] - out_frac) + int(rng.integers(0, 3))
@@ -101,4 +101,14 @@ def random_program(seed, n_in=4, n_ops=64, n_out=6, n_samples=24):
     ).astype(np.int32)
     x = rng.uniform(-40.0, 40.0, (n_samples, n_in)) * rng.choice([1.0, 0.25, 0.03125], (1, n_in))
     x[0] = 0.0
+    return words, x
+
+
+def narrow_condition_program():
+    """msb_mux on UNSIGNED 1-BIT conditions (what np.where(cond.to_bool(), a, b) traces to): an input declared (0,1,0) and a
+    reduce-or result.  The reference tests `value > max(1LL << (width-2), 0)`, i.e. `value > 0` for width 1."""
+    ops = [[-1, 0, -1, 0, 0, 1, 4, 0], [-1, 1, -1, 0, 0, 0, 1, 0], [9, 0, -1, 1, 0, 0, 1, 0],
+           [-6, 0, 0, 1, 0, 1, 5, 0], [-6, 0, 0, 2, 0, 1, 5, 0], [6, 0, 1, 1, 0, 1, 5, 0]]  # fmt: skip
+    words = np.asarray([1, 0, 2, 3, len(ops), 0] + [0, 0] + [3, 4, 5] + [0, 0, 0] + [0, 0, 0] + [w for op in ops for w in op], dtype=np.int32)
+    x = np.asarray([[-3, 0], [-3, 1], [0, 0], [0, 1], [2, 0], [2, 1], [5, 1], [7, 0]], dtype=np.float64)
     return words, x

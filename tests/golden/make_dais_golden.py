@@ -7,14 +7,15 @@ from pathlib import Path
 HERE = Path(__file__).resolve().parent
 sys.path.insert(0, str(HERE.parent.parent)); sys.path.insert(0, str(HERE.parent))
 import numpy as np  # noqa: E402
-from dais_cases import random_program  # noqa: E402
+from dais_cases import narrow_condition_program, random_program  # noqa: E402
 
 R = C.CDLL(str(HERE.parent.parent / 'oracle' / '_ref' / 'libdais_ref.so'))
 R.dref_run.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]
 R.dref_last_error.restype = C.c_char_p
+
 cases = []
-for seed in range(48):
-    prog, x = random_program(seed, n_samples=8)
+for seed in range(49):
+    prog, x = narrow_condition_program() if seed == 48 else random_program(seed, n_samples=8)
     x = np.ascontiguousarray(x)
     out = np.zeros((x.shape[0], int(prog[3])))
     if R.dref_run(prog.ctypes.data, prog.size, x.ctypes.data, x.shape[0], out.ctypes.data) != 0:

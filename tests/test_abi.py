@@ -86,3 +86,22 @@ def test_product_never_imports_the_oracle():
         if path.suffix in ('.py', '.cc', '.h', '.hip') or path.name == 'Makefile':
             hit = bad.search(path.read_text())
             assert hit is None, f'{path}: {hit.group(0)!r}'
+
+
+def test_oracle_does_not_share_the_product_marshalling():
+    """the checker converts C arrays to Pipeline objects with its own code (oracle/oracle.py), not with da4ml_amd._marshal"""
+    src = (ROOT / 'oracle' / 'oracle.py').read_text()
+    assert '_marshal' not in src.replace('da4ml_amd._marshal (row-by-row', '')
+
+
+def test_error_class_comes_from_the_library_not_from_the_message():
+    """da_last_error_code() tells ValueError from RuntimeError (reference: std::invalid_argument vs std::runtime_error);
+    the Python shim must not sniff the message text"""
+    import da4ml_amd._binary as B
+
+    src = (ROOT / 'da4ml_amd' / '_binary' / '__init__.py').read_text()
+    assert "'must' in" not in src and 'da_last_error_code' in src
+    L = B.lib()
+    assert L.da_last_error_code() in (0, -1, -2, -3)
+    if B.device_count() == 0:  # no GPU here: set_device must fail with the NO_DEVICE class and say so
+        assert L.da_set_device(0) == -3 and L.da_last_error_code() == -3

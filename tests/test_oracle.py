@@ -76,6 +76,25 @@ def test_port_equals_reference_build(oracle):
             assert all(np.array_equal(a, b) for a, b in zip(oracle.kernel_decompose(k, dc), ref.kernel_decompose(k, dc)))
 
 
+def test_large_records_of_the_restatement_match_the_reference_build():
+    """tests/golden/large_*_golden.json: wherever a record of the reference's own build (key suffix _ref, made with
+    oracle/_ref/libref.so) exists beside the restatement's record of the same problem, the two digests are identical --
+    the restatement is pinned to the reference at 128x128 too, not only up to 64x64."""
+    import json
+    from pathlib import Path
+
+    pairs = 0
+    for name in ('large_chain_golden.json', 'large_default_golden.json'):
+        gold = json.loads((Path(__file__).parent / 'golden' / name).read_text())
+        for key, rec in gold.items():
+            if key.endswith('_ref'):
+                port = gold[key[:-4]]
+                assert (rec['sha256'], rec['cost'], rec['n_ops']) == (port['sha256'], port['cost'], port['n_ops']), key
+                assert rec['oracle'] == 'oracle/_ref/libref.so'
+                pairs += 1
+    assert pairs >= 1
+
+
 # ---- the reference's own tests (tests/test_cmvm.py), seeded, against the oracle --------------------------------------
 @pytest.mark.parametrize('n', [2, 4, 8])
 @pytest.mark.parametrize('bits', [2, 4, 8])

@@ -53,3 +53,70 @@ def test_unsupported_opcode_raises():
         raise AssertionError('expected NotImplementedError')
     relu = s._replace(ops=[s.ops[0], Op(0, -1, 2, 0, QInterval(0, 1, 1), 0.0, 0.0)])
     assert relu([1.0]).tolist() == [1.0] and relu([-1.0]).tolist() == [0.0]
+
+
+def _mux_logic():
+    q = QInterval(-8.0, 7.0, 1.0)
+    ops = [Op(0, -1, -1, 0, q, 0.0, 0.0), Op(1, -1, -1, 0, QInterval(0.0, 1.0, 1.0), 0.0, 0.0),
+           Op(0, 0, -6, 1 | (0 << 32), QInterval(-8.0, 8.0, 1.0), 0.0, 0.0)]  # fmt: skip
+    return CombLogic((2, 1), [0, 0], [2], [0], [False], ops, -1, -1)
+
+
+def test_ref_count_counts_the_mux_condition():
+    """reference types.py:491-493: the condition of an msb-mux statement is a reference to its statement"""
+    s = _mux_logic()
+    assert s.ref_count.tolist() == [2, 1, 1]
+
+
+def test_debug_print_covers_every_opcode(capsys):
+    s = _mux_logic()
+    s([3.0, 1.0], debug=True)
+    out = capsys.readouterr().out
+    assert 'msb(buf[1]) ? buf[0] : -buf[0] << 0' in out and out.count('|->') == 3
+    from da4ml_amd.types import _describe
+
+    q = QInterval(0.0, 1.0, 1.0)
+    for code in (-9, -6, -3, -2, -1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11):
+        assert isinstance(_describe(Op(0, 0, code, 0, q, 0.0, 0.0)), str)
+
+
+def test_binary_with_lookup_tables():
+    """table section + pad_left encoding of to_binary (reference types.py:504-541); objects that cannot provide them raise"""
+
+    class Table:  # the two members of the reference's LookupTable that serialisation uses
+        def __init__(self, entries, pad):
+            self.table, self.pad = np.asarray(entries, dtype=np.int32), pad
+
+        def _get_pads(self, qint):
+            return self.pad, 0
+
+    q = QInterval(0.0, 3.0, 1.0)
+    ops = [Op(0, -1, -1, 0, q, 0.0, 0.0), Op(0, -1, 8, 1, QInterval(-4.0, 3.0, 1.0), 0.0, 0.0)]
+    s = CombLogic((1, 1), [0], [1], [0], [False], ops, -1, -1, (Table([9, 9], 0), Table([1, -2, 3, -4, 0], 1)))
+    b = s.to_binary()
+    assert list(b[:6]) == [1, 0, 1, 1, 2, 2]
+    body = b[6 + 1 + 3 :]
+    assert list(body[8 + 3 : 8 + 5]) == [1, 1]  # low word = table index, high word = pad_left
+    assert list(body[16:]) == [2, 5, 9, 9, 1, -2, 3, -4, 0]
+    # executed by the product's interpreter: table[1][x - min(format) - pad_left]  (x = 1..3 -> entries 0..2)
+    assert s.predict(np.array([[1.0], [2.0], [3.0]])).ravel().tolist() == [1.0, -2.0, 3.0]
+    for bad in (s._replace(lookup_tables=None), s._replace(lookup_tables=(object(), object()))):
+        try:
+            bad.to_binary()
+        except NotImplementedError:
+            continue
+        raise AssertionError('expected NotImplementedError')
+
+
+def test_predict_default_threads_from_environment(monkeypatch, oracle):
+    import da4ml_amd._binary as B
+
+    s = oracle.solve(int_matrix(2, 5, 4, -8, 8)).solutions[0]
+    seen = []
+    real = B.dais_interp_run
+    monkeypatch.setattr(B, 'dais_interp_run', lambda prog, data, n_threads=1, executor='host': seen.append(n_threads) or real(prog, data, n_threads, executor))
+    monkeypatch.setenv('DA_DEFAULT_THREADS', '3')
+    x = np.zeros((4, 5))
+    s.predict(x)
+    s.predict(x, n_threads=2)
+    assert seen == [3, 2]
