@@ -11,13 +11,21 @@
 //   k_extract        digit gather of to_solution             cmvm_core.cc:103-113
 //   k_col_dist       stage-1 CSD Hamming distances           mat_decompose.cc:75-93
 //
-// Data layout in HBM, per chain (all arrays carved from one arena, see HipBackend::run_group):
-//   cells   [rcap][n_out]  Cell    digits of (row, column) as two position bitmasks (cmvm_core.h)
+// Data layout in HBM, per chain (all arrays carved from one arena, see HipBackend::run_chains):
+//   rlist   row lists: every row is a list of (column, cell) entries sorted by column.  The n_in input rows are DENSE
+//           (n_out entries, entry j = column j); every later row is SPARSE: it only ever holds the columns it was
+//           created with (digits only disappear from a row), so a typical row is one 128-byte line.  A cell holds the
+//           digits of (row, column) as two position bitmasks (cmvm_core.h).  Narrow layout (n_out <= 256, <= 12 digits):
+//           one u32 per entry = col:8 | minus:12 | plus:12; wide layout: 16 bytes = u64 cell + u32 col.
+//   rowoff  [rcap] {offset, length} of every row's list (bump-allocated in creation order)
 //   rows    [rcap]         RowInfo interval + latency of every row
-//   collist [n_out][lcap]  u32     ascending ids of rows that have (had) digits in a column
+//   collist [n_out][lcap]  u64     rows that have (had) digits in a column, ascending: row:24 | len:12 | off:28 -- the
+//                                  reference to the row's list travels with the id, so no consumer needs rowoff first
 //   table   C slots (power of two), open addressing on (id0,id1):
-//             hkey[C] u64, hrank[C] u32 (selection rank of the block's best key, 0 = none), hidx[C] u8,
-//             hstat[C] {n_overlap, |dlat|}, hcnt[C][Kpad] u16 exact occurrence counts of all keys
+//             hkey[C] u64 (16 keys = one 128-byte line = one probe bucket), hrank[C] u32 (selection rank of the block's
+//             best key, 0 = none; the array the selection re-reads), hblk[C] one PAYLOAD LINE per slot:
+//             {n_overlap, |dlat|, rank copy, index of the best key, K x u16 exact occurrence counts} -- a block update
+//             reads and writes ONE line instead of four arrays
 //   ub      [C / GS]       u64     upper bound of (rank << 32 | tie_word >> 23) over a group of GS consecutive slots
 //
 // The reference keeps a sorted table of all pairs with count >= 2, purges every entry touching the two
@@ -87,20 +95,24 @@ constexpr int MAX_GROUPS = 4096;   // 16 waves x 64 lanes x 4 register-resident 
 #define UPD_TIMER_FLUSH
 #endif
 
-struct HStat {
-    int ov;
-    float dl;
+// header of a pair block's payload line (16 bytes, followed by the K u16 counts)
+struct BlkHdr {
+    int ov;         // n_overlap of the two rows (indexers.cc:36-56)
+    float dl;       // |latency difference| of the two rows
+    uint32_t rank;  // copy of hrank[slot]
+    uint32_t idx;   // key index of the block's best key
 };
 
 // Pointers read from a chain descriptor are "generic" pointers to the compiler, which emits FLAT memory instructions
 // for them.  FLAT operations count in BOTH vmcnt and lgkmcnt, so every LDS wait (lgkmcnt(0)) would also wait for all
 // global loads in flight and serialise the software-pipelined loads of the greedy-loop kernels.  The hot kernels
-// therefore keep their table / cell / list pointers in the global address space (GLOBAL instructions, vmcnt only).
+// therefore keep their table / row / list pointers in the global address space (GLOBAL instructions, vmcnt only).
 #define DA_GLOBAL __attribute__((address_space(1)))
 template <class T> __device__ __forceinline__ T *gen(DA_GLOBAL T *p) { return (T *)p; }  // for the HIP atomic API
 typedef float da_f4 __attribute__((ext_vector_type(4)));
 typedef int da_i4 __attribute__((ext_vector_type(4)));
 typedef unsigned int da_u2 __attribute__((ext_vector_type(2)));
+typedef unsigned long long da_ul2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ RowInfo load_row(const DA_GLOBAL RowInfo *rows, size_t i) {
     const da_f4 v = *reinterpret_cast<const DA_GLOBAL da_f4 *>(rows + i);
     return RowInfo{v.x, v.y, v.z, v.w};
@@ -108,13 +120,31 @@ __device__ __forceinline__ RowInfo load_row(const DA_GLOBAL RowInfo *rows, size_
 __device__ __forceinline__ void store_row(DA_GLOBAL RowInfo *rows, size_t i, const RowInfo &r) {
     *reinterpret_cast<DA_GLOBAL da_f4 *>(rows + i) = da_f4{r.lo, r.hi, r.step, r.lat};
 }
-__device__ __forceinline__ HStat load_hstat(const DA_GLOBAL HStat *p, size_t i) {
-    const da_u2 v = *reinterpret_cast<const DA_GLOBAL da_u2 *>(p + i);
-    return HStat{(int)v.x, __uint_as_float(v.y)};
+
+// Row-list entry formats.  Narrow: u32 = col:8 | minus:12 | plus:12 (32 entries per 128-byte line); wide: 16 bytes.
+template <class Cell> struct RowFmt;
+template <> struct RowFmt<uint32_t> {
+    using Entry = uint32_t;
+    static __device__ __forceinline__ Entry pack(uint32_t col, uint32_t cell) { return (col << 24) | ((cell >> 16) << 12) | (cell & 0xFFFu); }
+    static __device__ __forceinline__ uint32_t col(Entry e) { return e >> 24; }
+    static __device__ __forceinline__ uint32_t cell(Entry e) { return (((e >> 12) & 0xFFFu) << 16) | (e & 0xFFFu); }
+    static __device__ __forceinline__ Entry none() { return 0u; }
+};
+template <> struct RowFmt<uint64_t> {
+    using Entry = da_ul2;  // x = cell, y = column
+    static __device__ __forceinline__ Entry pack(uint32_t col, uint64_t cell) { return Entry{(unsigned long long)cell, (unsigned long long)col}; }
+    static __device__ __forceinline__ uint32_t col(Entry e) { return (uint32_t)e.y; }
+    static __device__ __forceinline__ uint64_t cell(Entry e) { return (uint64_t)e.x; }
+    static __device__ __forceinline__ Entry none() { return Entry{0ull, 0ull}; }
+};
+// reference to a row as stored in the column lists and the partner list: row:24 | len:12 | off:28
+constexpr int REF_ROW_BITS = 24, REF_LEN_BITS = 12, REF_OFF_BITS = 28;
+__host__ __device__ __forceinline__ unsigned long long ref_pack(uint32_t row, uint32_t len, uint32_t off) {
+    return (unsigned long long)row | ((unsigned long long)len << REF_ROW_BITS) | ((unsigned long long)off << (REF_ROW_BITS + REF_LEN_BITS));
 }
-__device__ __forceinline__ void store_hstat(DA_GLOBAL HStat *p, size_t i, int ov, float dl) {
-    *reinterpret_cast<DA_GLOBAL da_u2 *>(p + i) = da_u2{(unsigned)ov, __float_as_uint(dl)};
-}
+__device__ __forceinline__ uint32_t ref_row(unsigned long long r) { return (uint32_t)r & ((1u << REF_ROW_BITS) - 1u); }
+__device__ __forceinline__ uint32_t ref_len(unsigned long long r) { return (uint32_t)(r >> REF_ROW_BITS) & ((1u << REF_LEN_BITS) - 1u); }
+__device__ __forceinline__ uint32_t ref_off(unsigned long long r) { return (uint32_t)(r >> (REF_ROW_BITS + REF_LEN_BITS)); }
 
 // Per-chain descriptor in device memory.  Pointers are raw device addresses into the arena.
 struct ChainDev {
@@ -129,23 +159,24 @@ struct ChainDev {
     int32_t *xint;  // centred integer matrix [n_in][n_out]
     int8_t *shift0, *shift1;
     // state
-    void *cells;
+    void *rlist;        // row-list entries (RowFmt<Cell>::Entry)
+    da_u2 *rowoff;      // [rcap] {offset, length} of every row's list
+    uint32_t rl_cap, rl_used;
     RowInfo *rows;
     uint32_t *stamp;
-    uint32_t *collist;
+    unsigned long long *collist;
     int *collen;
     unsigned long long *hkey;
     uint32_t *hrank;
-    uint8_t *hidx;
-    HStat *hstat;
-    uint16_t *hcnt;
+    unsigned char *hblk;  // [C] payload lines of (1 << pb_log2) bytes
+    int pb_log2;
     unsigned long long *ub;
     unsigned long long *gtie;  // [n_groups] full tie word of the group's best entry (valid while the group is clean)
     uint8_t *gdirty;           // [n_groups] a block's best (rank, key) changed since the group was last verified
     // per-iteration hand-off select -> update
     int *mcol;
     void *mA, *mB;
-    uint32_t *plist;
+    unsigned long long *plist;
     int m, n_partners;
     int claim_words;   // words of the LDS claim bitmap in k_iter_select (0: use the global stamp array)
     unsigned int work_ctr;
@@ -223,13 +254,11 @@ __device__ __forceinline__ unsigned long long bound_word(uint32_t rank, unsigned
 // Register-resident copy of the constant part of a chain descriptor (wave-uniform, lives in SGPRs); `g` is used
 // for the few mutable counters only.
 struct Ctx {
-    int n_out, n_bits, K, Kpad, method, gs_log2;
+    int n_out, n_bits, K, Kpad, method, gs_log2, pb_log2;
     uint32_t cmask, windows;
     DA_GLOBAL unsigned long long *hkey;
     DA_GLOBAL uint32_t *hrank;
-    DA_GLOBAL uint8_t *hidx;
-    DA_GLOBAL HStat *hstat;
-    DA_GLOBAL uint16_t *hcnt;
+    DA_GLOBAL unsigned char *hblk;
     DA_GLOBAL unsigned long long *ub;
     DA_GLOBAL uint8_t *gdirty;
     const DA_GLOBAL RowInfo *rows;
@@ -246,19 +275,32 @@ __device__ __forceinline__ Ctx make_ctx(ChainDev *g, int launch_id) {
     c.Kpad = g->Kpad;
     c.method = g->method;
     c.gs_log2 = g->gs_log2;
+    c.pb_log2 = g->pb_log2;
     c.cmask = g->cmask;
     c.windows = g->C / WAVE ? g->C / WAVE : 1;
     c.hkey = (DA_GLOBAL unsigned long long *)g->hkey;
     c.hrank = (DA_GLOBAL uint32_t *)g->hrank;
-    c.hidx = (DA_GLOBAL uint8_t *)g->hidx;
-    c.hstat = (DA_GLOBAL HStat *)g->hstat;
-    c.hcnt = (DA_GLOBAL uint16_t *)g->hcnt;
+    c.hblk = (DA_GLOBAL unsigned char *)g->hblk;
     c.ub = (DA_GLOBAL unsigned long long *)g->ub;
     c.gdirty = (DA_GLOBAL uint8_t *)g->gdirty;
     c.rows = (const DA_GLOBAL RowInfo *)g->rows;
     c.g = g;
     return c;
 }
+// payload line of a slot: 16-byte header, then the counts
+__device__ __forceinline__ DA_GLOBAL unsigned char *blk_ptr(const Ctx &c, int slot) { return c.hblk + ((size_t)(uint32_t)slot << c.pb_log2); }
+__device__ __forceinline__ BlkHdr load_hdr(const Ctx &c, int slot) {
+    const da_i4 v = *reinterpret_cast<const DA_GLOBAL da_i4 *>(blk_ptr(c, slot));
+    return BlkHdr{v.x, __int_as_float(v.y), (uint32_t)v.z, (uint32_t)v.w};
+}
+__device__ __forceinline__ void store_hdr(const Ctx &c, int slot, int ov, float dl, uint32_t rank, uint32_t idx) {
+    *reinterpret_cast<DA_GLOBAL da_i4 *>(blk_ptr(c, slot)) = da_i4{ov, __float_as_int(dl), (int)rank, (int)idx};
+}
+__device__ __forceinline__ void store_best(const Ctx &c, int slot, uint32_t rank, uint32_t idx) {  // rank copy + best key index
+    *reinterpret_cast<DA_GLOBAL da_u2 *>(blk_ptr(c, slot) + 8) = da_u2{rank, idx};
+}
+__device__ __forceinline__ uint32_t load_best_idx(const Ctx &c, uint32_t slot) { return *reinterpret_cast<const DA_GLOBAL uint32_t *>(blk_ptr(c, (int)slot) + 12); }
+__device__ __forceinline__ DA_GLOBAL uint16_t *blk_cnt(const Ctx &c, int slot) { return reinterpret_cast<DA_GLOBAL uint16_t *>(blk_ptr(c, slot) + 16); }
 
 // All table operations are executed by one full wavefront.  The table is probed in BUCKETS of 16 slots (one 128-byte
 // line of keys), starting at the bucket the hash points into and continuing with the following buckets.  A key is
@@ -317,22 +359,22 @@ __device__ bool table_insert(const Ctx &c, uint32_t lo, uint32_t hi, const RowIn
     int ov = n_overlap(ra, rb);
     float dl = fabsf(ra.lat - rb.lat);
     unsigned long long best = 0;
+    DA_GLOBAL uint16_t *cnt = blk_cnt(c, slot);
     for (int k = lane; k < c.Kpad; k += WAVE) {
         uint32_t n = k < c.K ? cnt_of(k) : 0u;
         if (n > 65535u) c.g->error = E_COUNT_OVERFLOW;
-        c.hcnt[(size_t)slot * c.Kpad + k] = (uint16_t)n;
+        cnt[k] = (uint16_t)n;
         uint32_t r = entry_rank(n, ov, dl, c.method);
         unsigned long long cand = r ? (((unsigned long long)r << 8) | (unsigned)k) : 0ull;
         best = cand > best ? cand : best;
     }
     best = wave_max_u64(best);
     if (lane == 0) {
-        uint32_t rank = (uint32_t)(best >> 8);
-        store_hstat(c.hstat, slot, ov, dl);
+        uint32_t rank = (uint32_t)(best >> 8), idx = (uint32_t)(best & 0xFF);
+        store_hdr(c, slot, ov, dl, rank, idx);
         c.hrank[slot] = rank;
-        c.hidx[slot] = (uint8_t)(best & 0xFF);
         if (rank) {
-            atomicMax(gen(&c.ub[slot >> c.gs_log2]), bound_word(rank, tie_word(lo, hi, (int)(best & 0xFF))));
+            atomicMax(gen(&c.ub[slot >> c.gs_log2]), bound_word(rank, tie_word(lo, hi, (int)idx)));
             c.gdirty[slot >> c.gs_log2] = 1;
         }
         atomicAdd(&c.g->n_live, 1u);  // no return value: fire-and-forget (the peak is sampled by k_iter_select)
@@ -340,58 +382,60 @@ __device__ bool table_insert(const Ctx &c, uint32_t lo, uint32_t hi, const RowIn
     return true;
 }
 
+// lane 0: publish the re-evaluated best key of a block (or delete the block when no count >= 2 is left)
+__device__ __forceinline__ void block_commit(const Ctx &c, int slot, unsigned long long key, const BlkHdr &h, unsigned long long best, int alive) {
+    if (!alive) {
+        c.hrank[slot] = 0;
+        c.hkey[slot] = c.tomb;
+        atomicSub(&c.g->n_live, 1u);
+        if (h.rank) c.gdirty[slot >> c.gs_log2] = 1;
+        return;
+    }
+    const uint32_t rank = (uint32_t)(best >> 8), idx = (uint32_t)(best & 0xFF);
+    if (rank != h.rank) c.hrank[slot] = rank;
+    if (rank != h.rank || idx != h.idx) store_best(c, slot, rank, idx);
+    if (rank > h.rank) atomicMax(gen(&c.ub[slot >> c.gs_log2]), bound_word(rank, tie_word((uint32_t)key, (uint32_t)(key >> 32), (int)idx)));
+    if (rank != h.rank || (rank && idx != h.idx)) c.gdirty[slot >> c.gs_log2] = 1;
+}
+
 // Re-evaluate a block after its counts changed (new_cnt(k, old) -> new count); deletes it when no count >= 2.
 template <class CntFn>
 __device__ void table_update(const Ctx &c, int slot, unsigned long long key, CntFn new_cnt) {
     int lane = lane_id();
-    HStat st = load_hstat(c.hstat, slot);
-    uint32_t prev = c.hrank[slot], prev_idx = c.hidx[slot];
+    const BlkHdr h = load_hdr(c, slot);
+    DA_GLOBAL uint16_t *cnt = blk_cnt(c, slot);
     unsigned long long best = 0;
     int alive = 0;
     for (int k = lane; k < c.K; k += WAVE) {
-        uint32_t old = c.hcnt[(size_t)slot * c.Kpad + k];
+        uint32_t old = cnt[k];
         uint32_t n = new_cnt(k, old);
-        if (n != old) c.hcnt[(size_t)slot * c.Kpad + k] = (uint16_t)n;
+        if (n != old) cnt[k] = (uint16_t)n;
         alive |= n >= 2;
-        uint32_t r = entry_rank(n, st.ov, st.dl, c.method);
+        uint32_t r = entry_rank(n, h.ov, h.dl, c.method);
         unsigned long long cand = r ? (((unsigned long long)r << 8) | (unsigned)k) : 0ull;
         best = cand > best ? cand : best;
     }
     best = wave_max_u64(best);
     alive = __any(alive);
-    if (lane == 0) {
-        if (!alive) {
-            c.hrank[slot] = 0;
-            c.hkey[slot] = c.tomb;
-            atomicSub(&c.g->n_live, 1u);
-            if (prev) c.gdirty[slot >> c.gs_log2] = 1;
-        } else {
-            uint32_t rank = (uint32_t)(best >> 8), idx = (uint32_t)(best & 0xFF);
-            if (rank != prev) c.hrank[slot] = rank;
-            if (idx != prev_idx) c.hidx[slot] = (uint8_t)idx;
-            if (rank > prev)
-                atomicMax(gen(&c.ub[slot >> c.gs_log2]), bound_word(rank, tie_word((uint32_t)key, (uint32_t)(key >> 32), (int)idx)));
-            if (rank != prev || (rank && idx != prev_idx)) c.gdirty[slot >> c.gs_log2] = 1;
-        }
-    }
+    if (lane == 0) block_commit(c, slot, key, h, best, alive);
 }
 
 // Two block updates with all their loads in flight together (a partner row touches its blocks with A and with B).
-// slot < 0 means "no such block".  delta arrays live in LDS.
+// slot < 0 means "no such block".  delta arrays live in LDS.  One payload line is read and written per block.
 __device__ __forceinline__ void table_update_pair(const Ctx &c, int slot0, unsigned long long key0, const uint32_t *d0, int slot1,
                                                   unsigned long long key1, const uint32_t *d1) {
     const int lane = lane_id();
     const bool h0 = slot0 >= 0, h1 = slot1 >= 0;
-    HStat st0 = h0 ? load_hstat(c.hstat, slot0) : HStat{0, 0.0f}, st1 = h1 ? load_hstat(c.hstat, slot1) : HStat{0, 0.0f};
-    uint32_t prev0 = h0 ? c.hrank[slot0] : 0u, prev1 = h1 ? c.hrank[slot1] : 0u;
-    uint32_t pidx0 = h0 ? c.hidx[slot0] : 0u, pidx1 = h1 ? c.hidx[slot1] : 0u;
+    const BlkHdr z{0, 0.0f, 0u, 0u};
+    const BlkHdr b0 = h0 ? load_hdr(c, slot0) : z, b1 = h1 ? load_hdr(c, slot1) : z;
+    DA_GLOBAL uint16_t *cnt0 = blk_cnt(c, h0 ? slot0 : 0), *cnt1 = blk_cnt(c, h1 ? slot1 : 0);
     uint32_t o0[2] = {0, 0}, o1[2] = {0, 0};
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         int k = lane + u * WAVE;
         if (k < c.K) {
-            if (h0) o0[u] = c.hcnt[(size_t)slot0 * c.Kpad + k];
-            if (h1) o1[u] = c.hcnt[(size_t)slot1 * c.Kpad + k];
+            if (h0) o0[u] = cnt0[k];
+            if (h1) o1[u] = cnt1[k];
         }
     }
     unsigned long long best0 = 0, best1 = 0;
@@ -402,17 +446,17 @@ __device__ __forceinline__ void table_update_pair(const Ctx &c, int slot0, unsig
         if (k < c.K) {
             if (h0) {
                 uint32_t n = o0[u] - d0[k];
-                if (n != o0[u]) c.hcnt[(size_t)slot0 * c.Kpad + k] = (uint16_t)n;
+                if (n != o0[u]) cnt0[k] = (uint16_t)n;
                 alive0 |= n >= 2;
-                uint32_t r = entry_rank(n, st0.ov, st0.dl, c.method);
+                uint32_t r = entry_rank(n, b0.ov, b0.dl, c.method);
                 unsigned long long cand = r ? (((unsigned long long)r << 8) | (unsigned)k) : 0ull;
                 best0 = cand > best0 ? cand : best0;
             }
             if (h1) {
                 uint32_t n = o1[u] - d1[k];
-                if (n != o1[u]) c.hcnt[(size_t)slot1 * c.Kpad + k] = (uint16_t)n;
+                if (n != o1[u]) cnt1[k] = (uint16_t)n;
                 alive1 |= n >= 2;
-                uint32_t r = entry_rank(n, st1.ov, st1.dl, c.method);
+                uint32_t r = entry_rank(n, b1.ov, b1.dl, c.method);
                 unsigned long long cand = r ? (((unsigned long long)r << 8) | (unsigned)k) : 0ull;
                 best1 = cand > best1 ? cand : best1;
             }
@@ -423,36 +467,8 @@ __device__ __forceinline__ void table_update_pair(const Ctx &c, int slot0, unsig
     alive0 = __any(alive0);
     alive1 = __any(alive1);
     if (lane == 0) {
-        if (h0) {
-            if (!alive0) {
-                c.hrank[slot0] = 0;
-                c.hkey[slot0] = c.tomb;
-                atomicSub(&c.g->n_live, 1u);
-                if (prev0) c.gdirty[slot0 >> c.gs_log2] = 1;
-            } else {
-                uint32_t rank = (uint32_t)(best0 >> 8), idx = (uint32_t)(best0 & 0xFF);
-                if (rank != prev0) c.hrank[slot0] = rank;
-                if (idx != pidx0) c.hidx[slot0] = (uint8_t)idx;
-                if (rank > prev0)
-                    atomicMax(gen(&c.ub[slot0 >> c.gs_log2]), bound_word(rank, tie_word((uint32_t)key0, (uint32_t)(key0 >> 32), (int)idx)));
-                if (rank != prev0 || (rank && idx != pidx0)) c.gdirty[slot0 >> c.gs_log2] = 1;
-            }
-        }
-        if (h1) {
-            if (!alive1) {
-                c.hrank[slot1] = 0;
-                c.hkey[slot1] = c.tomb;
-                atomicSub(&c.g->n_live, 1u);
-                if (prev1) c.gdirty[slot1 >> c.gs_log2] = 1;
-            } else {
-                uint32_t rank = (uint32_t)(best1 >> 8), idx = (uint32_t)(best1 & 0xFF);
-                if (rank != prev1) c.hrank[slot1] = rank;
-                if (idx != pidx1) c.hidx[slot1] = (uint8_t)idx;
-                if (rank > prev1)
-                    atomicMax(gen(&c.ub[slot1 >> c.gs_log2]), bound_word(rank, tie_word((uint32_t)key1, (uint32_t)(key1 >> 32), (int)idx)));
-                if (rank != prev1 || (rank && idx != pidx1)) c.gdirty[slot1 >> c.gs_log2] = 1;
-            }
-        }
+        if (h0) block_commit(c, slot0, key0, b0, best0, alive0);
+        if (h1) block_commit(c, slot1, key1, b1, best1, alive1);
     }
 }
 
@@ -520,13 +536,15 @@ __global__ void __launch_bounds__(256) k_prepare(ChainDev *chains) {
 }
 
 // ------------------------------------------------------------------------------------------------ k_init_cells
-// grid (ceil(n_out / 4), n_chains): one wave per column builds the cells of that column and its row list.
+// grid (ceil(n_out / 4), n_chains): one wave per column builds the entries of that column in the (dense) lists of the
+// input rows and the column's row list.
 template <class Cell> __global__ void __launch_bounds__(256) k_init_cells(ChainDev *chains) {
     using O = CellOps<Cell>;
+    using F = RowFmt<Cell>;
     ChainDev &ch = chains[blockIdx.y];
     int j = blockIdx.x * (blockDim.x / WAVE) + wave_id();
     if (j >= ch.n_out) return;
-    Cell *cells = reinterpret_cast<Cell *>(ch.cells);
+    auto *rl = reinterpret_cast<typename F::Entry *>(ch.rlist);
     int lane = lane_id(), len = 0;
     for (int base = 0; base < ch.n_in; base += WAVE) {
         int i = base + lane;
@@ -536,32 +554,36 @@ template <class Cell> __global__ void __launch_bounds__(256) k_init_cells(ChainD
             uint32_t p, m;
             naf_masks(ch.xint[(size_t)i * ch.n_out + j], p, m);
             c = dead ? (Cell)0 : O::make(p, m);
-            cells[(size_t)i * ch.n_out + j] = c;
+            rl[(size_t)i * ch.n_out + j] = F::pack((uint32_t)j, c);  // dense row: entry j is column j, empty cells included
         }
         unsigned long long nz = __ballot(c != 0);
-        if (c != 0) ch.collist[(size_t)j * ch.lcap + len + __popcll(nz & ((1ull << lane) - 1))] = (uint32_t)i;
+        if (c != 0)
+            ch.collist[(size_t)j * ch.lcap + len + __popcll(nz & ((1ull << lane) - 1))] = ref_pack((uint32_t)i, (uint32_t)ch.n_out, (uint32_t)i * (uint32_t)ch.n_out);
         len += __popcll(nz);
     }
     if (lane == 0) ch.collen[j] = len;
     if (j == 0)
-        for (int i = lane; i < ch.n_in; i += WAVE)
+        for (int i = lane; i < ch.n_in; i += WAVE) {
             ch.rows[i] = RowInfo{ch.qints[3 * i], ch.qints[3 * i + 1], ch.qints[3 * i + 2], ch.lats[i]};
+            ch.rowoff[i] = da_u2{(uint32_t)i * (uint32_t)ch.n_out, (uint32_t)ch.n_out};
+        }
 }
 
-// exact pair counts of one row pair over all columns into LDS counters (one wave)
+// exact pair counts of one pair of INPUT rows (dense lists) over all columns into LDS counters (one wave)
 template <class Cell>
-__device__ __forceinline__ void count_row_pair(const Ctx &c, const Cell *cells, uint32_t lo, uint32_t hi, uint32_t *cnt) {
+__device__ __forceinline__ void count_row_pair(const Ctx &c, const typename RowFmt<Cell>::Entry *rl, uint32_t lo, uint32_t hi, uint32_t *cnt) {
+    using F = RowFmt<Cell>;
     int lane = lane_id();
     for (int k = lane; k < c.Kpad; k += WAVE) cnt[k] = 0;
     lds_fence();
-    const Cell *rl = cells + (size_t)lo * c.n_out, *rh = cells + (size_t)hi * c.n_out;
+    const auto *el = rl + (size_t)lo * c.n_out, *eh = rl + (size_t)hi * c.n_out;
     for (int j = lane; j < c.n_out; j += WAVE) {
-        Cell a = rl[j];
+        Cell a = F::cell(el[j]);
         if (!a) continue;
         if (lo == hi)
             for_pairs_self<Cell>(a, c.n_bits, [&](int k) { atomicAdd(&cnt[k], 1u); });
         else {
-            Cell b = rh[j];
+            Cell b = F::cell(eh[j]);
             if (b) for_pairs_cross<Cell>(a, b, c.n_bits, [&](int k) { atomicAdd(&cnt[k], 1u); });
         }
     }
@@ -590,8 +612,8 @@ template <class Cell> __global__ void __launch_bounds__(256) k_init_pairs(ChainD
     while (i1 * (i1 + 1) / 2 > p) --i1;
     while ((i1 + 1) * (i1 + 2) / 2 <= p) ++i1;
     uint32_t hi = (uint32_t)i1, lo = (uint32_t)(p - i1 * (i1 + 1) / 2);
-    const auto *cells = reinterpret_cast<const Cell *>(g->cells);
-    count_row_pair<Cell>(c, cells, lo, hi, cnt);
+    const auto *rl = reinterpret_cast<const typename RowFmt<Cell>::Entry *>(g->rlist);
+    count_row_pair<Cell>(c, rl, lo, hi, cnt);
     if (!wave_any_ge2(cnt, c.K)) return;
     if (c.method < 0) {  // unknown method string with a non-empty table: the reference throws here
         if (lane_id() == 0) g->unknown_hit = 1;
@@ -602,27 +624,32 @@ template <class Cell> __global__ void __launch_bounds__(256) k_init_pairs(ChainD
 
 // ------------------------------------------------------------------------------------------------ k_iter_select
 // One block per chain: (1) arg-max of the pair table via lazily tightened group upper bounds, (2) substitution
-// of the chosen pair in every column, (3) exact recount of the pairs among the modified rows {A, B, new},
-// (4) the de-duplicated list of partner rows (rows sharing a substituted column) for k_iter_update.
+// of the chosen pair in the lists of rows A and B (the new row's list is their match set), (3) exact recount of the
+// pairs among the modified rows {A, B, new}, (4) the de-duplicated list of partner rows (rows sharing a substituted
+// column) for k_iter_update.
 template <class Cell> __global__ void __launch_bounds__(SEL_THREADS) k_iter_select(ChainDev *chains, unsigned int *n_done) {
     using O = CellOps<Cell>;
+    using F = RowFmt<Cell>;
+    using Entry = typename F::Entry;
     ChainDev *g = &chains[blockIdx.x];
     if (g->done) return;
     const Ctx c = make_ctx(g, 2 * g->iter);
     const int n_groups = g->n_groups, n_out = c.n_out, Kpad = c.Kpad, nb = c.n_bits, lcap = g->lcap;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // dynamic LDS carve: special-pair counters | per-matched-column scratch | claim bitmap
-    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(smem);                             // [6][Kpad]
+    // dynamic LDS carve: B's list | special-pair counters | per-matched-column scratch | column -> position in B | claim bitmap
+    Entry *s_bent = reinterpret_cast<Entry *>(smem);                                  // [n_out] entries of row B (updated in place)
+    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_bent + n_out);                  // [6][Kpad]
     int *s_len = reinterpret_cast<int *>(s_cnt + 6 * Kpad);                           // [n_out + 1] list lengths -> offsets
     int *s_col = s_len + n_out + 1;                                                   // [n_out] matched columns
-    uint32_t *s_bits = reinterpret_cast<uint32_t *>(s_col + n_out);                  // [claim_words] rows already claimed (if it fits)
+    int *s_bpos = s_col + n_out;                                                      // [n_out] 1 + position of a column in B's list, 0 = absent
+    uint32_t *s_bits = reinterpret_cast<uint32_t *>(s_bpos + n_out);                 // [claim_words] rows already claimed (if it fits)
     const int claim_words = g->claim_words;
     constexpr int NW = SEL_THREADS / WAVE;
     __shared__ unsigned long long s_red_tie[NW], s_floor0, s_floor;
     __shared__ uint32_t s_red_rank[NW];
     __shared__ uint32_t s_best_rank;
     __shared__ unsigned long long s_best_tie;
-    __shared__ int s_m, s_np, s_part[NW];
+    __shared__ int s_np, s_part[NW];
     __shared__ RowInfo s_new;
 
     const int tid = threadIdx.x, lane = lane_id(), wid = wave_id();
@@ -647,7 +674,6 @@ template <class Cell> __global__ void __launch_bounds__(SEL_THREADS) k_iter_sele
     if (tid == 0) {
         s_best_rank = 0;
         s_best_tie = 0;
-        s_m = 0;
         s_np = 0;
         s_floor0 = 0;
     }
@@ -688,12 +714,7 @@ template <class Cell> __global__ void __launch_bounds__(SEL_THREADS) k_iter_sele
                     top_u = u;
                 }
             const unsigned long long wtop = wave_max_u64(top);
-#ifdef DA_SELECT_FAST
-            // an LDS atomic load (ds_read_b64) instead of a volatile generic access, which is a FLAT load
-            if (wtop == 0 || wtop < __hip_atomic_load(&s_floor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
-#else
             if (wtop == 0 || wtop < *(volatile unsigned long long *)&s_floor) break;
-#endif
             const unsigned long long who = __ballot(top == wtop);
             const int owner = __ffsll((long long)who) - 1;
             const int own_u = __shfl(top_u, owner);
@@ -701,28 +722,12 @@ template <class Cell> __global__ void __launch_bounds__(SEL_THREADS) k_iter_sele
             const uint32_t base = grp * gs;
             uint32_t rk[8];
             uint32_t grank = 0;
-#ifdef DA_SELECT_FAST
-            // EXPERIMENT (not yet measured): keys and key indices are loaded together with the ranks (one memory round
-            // trip per verified group instead of two; 13 instead of 4 bytes per slot)
-            unsigned long long kq[8];
-            uint32_t ix[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                int o = lane + u * WAVE;
-                rk[u] = o < gs ? c.hrank[base + o] : 0u;
-                kq[u] = o < gs ? c.hkey[base + o] : 0ull;
-                ix[u] = o < gs ? (uint32_t)c.hidx[base + o] : 0u;
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) grank = max(grank, rk[u]);
-#else
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 int o = lane + u * WAVE;
                 rk[u] = o < gs ? c.hrank[base + o] : 0u;
                 grank = max(grank, rk[u]);
             }
-#endif
             for (int o = lane + 8 * WAVE; o < gs; o += WAVE) grank = max(grank, c.hrank[base + o]);
             grank = wave_max_u32(grank);
             unsigned long long gt = 0;
@@ -731,20 +736,15 @@ template <class Cell> __global__ void __launch_bounds__(SEL_THREADS) k_iter_sele
                 for (int u = 0; u < 8; ++u) {
                     int o = lane + u * WAVE;
                     if (o < gs && rk[u] == grank) {
-#ifdef DA_SELECT_FAST
-                        unsigned long long kk = kq[u];
-                        unsigned long long tw = tie_word((uint32_t)kk, (uint32_t)(kk >> 32), (int)ix[u]);
-#else
                         unsigned long long kk = c.hkey[base + o];
-                        unsigned long long tw = tie_word((uint32_t)kk, (uint32_t)(kk >> 32), c.hidx[base + o]);
-#endif
+                        unsigned long long tw = tie_word((uint32_t)kk, (uint32_t)(kk >> 32), (int)load_best_idx(c, base + o));
                         gt = tw > gt ? tw : gt;
                     }
                 }
                 for (int o = lane + 8 * WAVE; o < gs; o += WAVE)
                     if (c.hrank[base + o] == grank) {
                         unsigned long long kk = c.hkey[base + o];
-                        unsigned long long tw = tie_word((uint32_t)kk, (uint32_t)(kk >> 32), c.hidx[base + o]);
+                        unsigned long long tw = tie_word((uint32_t)kk, (uint32_t)(kk >> 32), (int)load_best_idx(c, base + o));
                         gt = tw > gt ? tw : gt;
                     }
                 gt = wave_max_u64(gt);
@@ -828,19 +828,11 @@ template <class Cell> __global__ void __launch_bounds__(SEL_THREADS) k_iter_sele
     const bool same = A == B;
     const int iter = g->iter;
 
-    // ---------------- (2) new row record + substitution
-#ifdef DA_SELECT_FAST
-    // EXPERIMENT (not yet measured): the first-pass cell / list-length loads are issued before the barrier, in flight
-    // while thread 0 fetches the two row records and builds the new one (columns are private to their thread)
-    Cell pre_a = 0, pre_b = 0;
-    int pre_len = 0;
-    if (tid < n_out) {
-        const DA_GLOBAL Cell *cf = (const DA_GLOBAL Cell *)g->cells;
-        pre_a = cf[(size_t)A * n_out + tid];
-        pre_b = same ? pre_a : cf[(size_t)B * n_out + tid];
-        pre_len = ((const DA_GLOBAL int *)g->collen)[tid];
-    }
-#endif
+    // ---------------- (2) new row record + substitution.  Every thread fetches the list references of A and B (two
+    // broadcast loads) while thread 0 fetches the two row records and builds the new one.
+    DA_GLOBAL da_u2 *rowoff = (DA_GLOBAL da_u2 *)g->rowoff;
+    const da_u2 refA = rowoff[A], refB = rowoff[B];
+    const uint32_t offN = g->rl_used;
     if (tid == 0) {
         RowInfo ra = load_row(c.rows, A), rb = load_row(c.rows, B), rn;
         int derr = 0;
@@ -854,60 +846,115 @@ template <class Cell> __global__ void __launch_bounds__(SEL_THREADS) k_iter_sele
         if (g->n_live > g->live_peak) g->live_peak = g->n_live;
     }
     for (int k = tid; k < 6 * Kpad; k += SEL_THREADS) s_cnt[k] = 0;
+    const int lenA = (int)refA.y, lenB = (int)refB.y;
+    if (offN + (uint32_t)lenA > g->rl_cap) {  // the new row has at most lenA entries (cannot happen with the exact bound; guarded)
+        if (tid == 0) {
+            g->error = E_LIST_CAPACITY;
+            g->done = 1;
+            g->n_partners = 0;
+            atomicAdd(n_done, 1u);
+        }
+        return;
+    }
+    DA_GLOBAL Entry *rl = (DA_GLOBAL Entry *)g->rlist;
+    DA_GLOBAL Entry *rlA = rl + refA.x, *rlB = rl + refB.x, *rlN = rl + offN;
+    if (!same) {  // B's list into LDS, addressable by column
+        for (int j = tid; j < n_out; j += SEL_THREADS) s_bpos[j] = 0;
+        __syncthreads();
+        for (int t = tid; t < lenB; t += SEL_THREADS) {
+            const Entry e = rlB[t];
+            s_bent[t] = e;
+            s_bpos[F::col(e)] = t + 1;
+        }
+    }
     __syncthreads();
     tp[3] = clock64();
-    DA_GLOBAL Cell *cells = (DA_GLOBAL Cell *)g->cells;
-    DA_GLOBAL Cell *rowA = cells + (size_t)A * n_out, *rowB = cells + (size_t)B * n_out, *rowN = cells + (size_t)Nw * n_out;
     DA_GLOBAL Cell *mA = (DA_GLOBAL Cell *)g->mA, *mB = (DA_GLOBAL Cell *)g->mB;
     DA_GLOBAL int *mcol = (DA_GLOBAL int *)g->mcol, *collen = (DA_GLOBAL int *)g->collen;
-    DA_GLOBAL uint32_t *collist = (DA_GLOBAL uint32_t *)g->collist;
+    DA_GLOBAL unsigned long long *collist = (DA_GLOBAL unsigned long long *)g->collist;
     uint32_t *cAA = s_cnt, *cAB = s_cnt + Kpad, *cBB = s_cnt + 2 * Kpad, *cAN = s_cnt + 3 * Kpad, *cBN = s_cnt + 4 * Kpad,
              *cNN = s_cnt + 5 * Kpad;
     unsigned int my_matches = 0;
-    for (int j = tid; j < n_out; j += SEL_THREADS) {
-#ifdef DA_SELECT_FAST
-        Cell a = j == tid ? pre_a : rowA[j], b = same ? a : (j == tid ? pre_b : rowB[j]), ma = 0, mb = 0;
-#else
-        Cell a = rowA[j], b = same ? a : rowB[j], ma = 0, mb = 0;
-#endif
-        if (a && b) substitute_column<Cell>(a, b, same, shift, sub, ma, mb);
-        Cell na = same ? (Cell)(a & ~ma & ~mb) : (Cell)(a & ~ma), nbv = b & ~mb;
-        if (ma) {
-            rowA[j] = na;
-            if (!same) rowB[j] = nbv;
-            int at = atomicAdd(&s_m, 1);
-            mcol[at] = j;
+    int m = 0;  // matched columns so far (block-uniform)
+    // pass 1: one thread per entry of A (ascending columns); the matched columns are compacted in column order, which
+    // is the order of the new row's list
+    for (int t0 = 0; t0 < lenA; t0 += SEL_THREADS) {
+        const int t = t0 + tid;
+        Cell a = 0, b = 0, ma = 0, mb = 0, na = 0, nbv = 0;
+        uint32_t colA = 0;
+        int pos = 0;
+        if (t < lenA) {
+            const Entry e = rlA[t];
+            colA = F::col(e);
+            a = F::cell(e);
+            if (same)
+                b = a;
+            else {
+                pos = s_bpos[colA];
+                b = pos ? F::cell(s_bent[pos - 1]) : (Cell)0;
+            }
+            if (a && b) substitute_column<Cell>(a, b, same, shift, sub, ma, mb);
+            na = same ? (Cell)(a & ~ma & ~mb) : (Cell)(a & ~ma);
+            nbv = b & ~mb;
+        }
+        const bool hit = ma != 0;
+        const unsigned long long bal = __ballot(hit);
+        if (lane == 0) s_part[wid] = __popcll(bal);
+        __syncthreads();
+        int wbase = 0, chunk = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            const int v = s_part[w];
+            wbase += w < wid ? v : 0;
+            chunk += v;
+        }
+        if (hit) {
+            const int at = m + wbase + __popcll(bal & ((1ull << lane) - 1));
+            rlA[t] = F::pack(colA, na);
+            if (!same) s_bent[pos - 1] = F::pack(colA, nbv);
+            rlN[at] = F::pack(colA, ma);
+            mcol[at] = (int)colA;
             mA[at] = ma;
             mB[at] = mb;
-#ifdef DA_SELECT_FAST
-            int len = j == tid ? pre_len : collen[j];
-#else
-            int len = collen[j];
-#endif
-            s_len[at] = len;  // the pre-append length: the new row itself is not a partner
-            s_col[at] = j;
-            if (len < lcap) {
-                collist[(size_t)j * lcap + len] = Nw;
-                collen[j] = len + 1;
-            } else
-                g->error = E_LIST_CAPACITY;
+            s_len[at] = collen[colA];  // the pre-append length: the new row itself is not a partner
+            s_col[at] = (int)colA;
             my_matches += popc32(O::plus(ma) | O::minus(ma));
         }
-        rowN[j] = ma;
-        // ---------------- (3) exact recount of the pairs among {A, B, new} (their old blocks are replaced)
+        // ---------------- (3) exact recount of the pairs among {A, B, new} (their old blocks are replaced); the
+        // self pairs of B are counted in pass 2 (B may have columns A does not have)
         if (na) for_pairs_self<Cell>(na, nb, [&](int k) { atomicAdd(&cAA[k], 1u); });
         if (!same) {
             if (na && nbv) for_pairs_cross<Cell>(na, nbv, nb, [&](int k) { atomicAdd(&cAB[k], 1u); });
-            if (nbv) for_pairs_self<Cell>(nbv, nb, [&](int k) { atomicAdd(&cBB[k], 1u); });
             if (nbv && ma) for_pairs_cross<Cell>(nbv, ma, nb, [&](int k) { atomicAdd(&cBN[k], 1u); });
         }
         if (na && ma) for_pairs_cross<Cell>(na, ma, nb, [&](int k) { atomicAdd(&cAN[k], 1u); });
         if (ma) for_pairs_self<Cell>(ma, nb, [&](int k) { atomicAdd(&cNN[k], 1u); });
+        m += chunk;
+        __syncthreads();  // s_part is reused by the next chunk; s_bent updates visible to pass 2
     }
     if (my_matches) atomicAdd(&g->st_matches, (unsigned long long)my_matches);
+    // pass 2: B's list back to memory, self pairs of what is left of B
+    if (!same)
+        for (int t = tid; t < lenB; t += SEL_THREADS) {
+            const Entry e = s_bent[t];
+            rlB[t] = e;
+            const Cell nbv = F::cell(e);
+            if (nbv) for_pairs_self<Cell>(nbv, nb, [&](int k) { atomicAdd(&cBB[k], 1u); });
+        }
+    // the new row joins the lists of its columns
+    {
+        const unsigned long long refN = ref_pack(Nw, (uint32_t)m, offN);
+        for (int k = tid; k < m; k += SEL_THREADS) {
+            const int j = s_col[k], len = s_len[k];
+            if (len < lcap) {
+                collist[(size_t)j * lcap + len] = refN;
+                collen[j] = len + 1;
+            } else
+                g->error = E_LIST_CAPACITY;
+        }
+    }
     __syncthreads();
     tp[4] = clock64();
-    const int m = s_m;
     // exclusive prefix sum of the list lengths of the matched columns (m <= n_out)
     for (int k = tid; k < claim_words; k += SEL_THREADS) s_bits[k] = 0;
     if (m <= WAVE) {  // the common case: one wave, shuffle scan
@@ -950,15 +997,12 @@ template <class Cell> __global__ void __launch_bounds__(SEL_THREADS) k_iter_sele
     // partner list -- by the first NW-6 waves; the last six waves store the six special pairs meanwhile.
     constexpr int CLAIM_WAVES = NW - 6, CLAIM_THREADS = CLAIM_WAVES * WAVE;
     if (wid < CLAIM_WAVES) {
-        DA_GLOBAL uint32_t *stamp = (DA_GLOBAL uint32_t *)g->stamp, *plist = (DA_GLOBAL uint32_t *)g->plist;
+        DA_GLOBAL uint32_t *stamp = (DA_GLOBAL uint32_t *)g->stamp;
+        DA_GLOBAL unsigned long long *plist = (DA_GLOBAL unsigned long long *)g->plist;
         const uint32_t tag = (uint32_t)iter + 1u;
-#ifdef DA_SELECT_FAST
-        constexpr int CLAIM_ILP = 8;  // EXPERIMENT: at C3 sizes (about 5.6 list entries per thread) one pass, one round trip
-#else
         constexpr int CLAIM_ILP = 4;
-#endif
         for (int f0 = tid; f0 < total; f0 += CLAIM_ILP * CLAIM_THREADS) {
-            uint32_t r[CLAIM_ILP];
+            unsigned long long r[CLAIM_ILP];
             bool ok[CLAIM_ILP];
 #pragma unroll
             for (int u = 0; u < CLAIM_ILP; ++u) {  // CLAIM_ILP independent list reads in flight
@@ -979,15 +1023,16 @@ template <class Cell> __global__ void __launch_bounds__(SEL_THREADS) k_iter_sele
             }
 #pragma unroll
             for (int u = 0; u < CLAIM_ILP; ++u) {
-                if (!ok[u] || r[u] == A || r[u] == B) {
+                const uint32_t row = ref_row(r[u]);
+                if (!ok[u] || row == A || row == B) {
                     ok[u] = false;
                     continue;
                 }
                 if (claim_words) {  // de-duplicate in the LDS bitmap: no global round trip
-                    const uint32_t bit = 1u << (r[u] & 31);
-                    ok[u] = (atomicOr(&s_bits[r[u] >> 5], bit) & bit) == 0;
+                    const uint32_t bit = 1u << (row & 31);
+                    ok[u] = (atomicOr(&s_bits[row >> 5], bit) & bit) == 0;
                 } else
-                    ok[u] = atomicExch(gen(&stamp[r[u]]), tag) != tag;
+                    ok[u] = atomicExch(gen(&stamp[row]), tag) != tag;
             }
 #pragma unroll
             for (int u = 0; u < CLAIM_ILP; ++u)
@@ -1023,6 +1068,8 @@ template <class Cell> __global__ void __launch_bounds__(SEL_THREADS) k_iter_sele
     tp[7] = clock64();
     if (tid == 0) {
         for (int q = 0; q < 7; ++q) g->st_phase[q] += (unsigned long long)(tp[q + 1] - tp[q]);
+        rowoff[Nw] = da_u2{offN, (uint32_t)m};
+        g->rl_used = offN + (uint32_t)m;
         g->m = m;
         g->n_partners = s_np;
         g->work_ctr = 0;
@@ -1036,12 +1083,13 @@ template <class Cell> __global__ void __launch_bounds__(SEL_THREADS) k_iter_sele
 
 // ------------------------------------------------------------------------------------------------ k_iter_update
 // grid (U, n_chains).  Every partner row (a row other than A, B, new that shares a substituted column) is handled
-// by ONE wavefront, fetched from the chain's work list with an atomic counter: it subtracts the pair occurrences
-// lost with A's / B's consumed digits from the blocks (A,r), (B,r) and creates the block (r,new).
-template <class Cell>
+// by ONE wavefront (static striding over the chain's partner list): it subtracts the pair occurrences lost with
+// A's / B's consumed digits from the blocks (A,r), (B,r) and creates the block (r,new).  The partner's list is read
+// with one coalesced load (lane = entry); lanes whose entry lies in a substituted column enumerate digit pairs.
 #ifndef DA_UPD_OCC
-#define DA_UPD_OCC 8  // blocks of 256 threads per CU the register budget is capped for (EXPERIMENT: 7 or 6 trade wave slots
-                      // for registers: at 8 the kernel spills, and every spill reload is a vmcnt(0) wait inside the partner loop)
+#define DA_UPD_OCC 6  // blocks of 256 threads per CU the register budget is capped for.  Measured on MI355X (C3, batch 64):
+                      // 8 -> 41.6, 7 -> 45.3, 6 -> 46.1 solves/s: at 8 the kernel spills and every spill reload is a
+                      // vmcnt(0) wait inside the partner loop
 #endif
 #if DA_UPD_OCC >= 8
 #define DA_UPD_SGPRS 80  // 800 SGPRs per SIMD: more than 80 per wave would cap the residency below 8 waves per SIMD
@@ -1050,7 +1098,10 @@ template <class Cell>
 #else
 #define DA_UPD_SGPRS 102
 #endif
+template <class Cell>
 __global__ void __launch_bounds__(UPD_THREADS, DA_UPD_OCC) __attribute__((amdgpu_num_sgpr(DA_UPD_SGPRS))) k_iter_update(ChainDev *chains) {
+    using F = RowFmt<Cell>;
+    using Entry = typename F::Entry;
     ChainDev *g = &chains[blockIdx.y];
     if (g->done) return;
     const int n_partners = g->n_partners;
@@ -1058,17 +1109,20 @@ __global__ void __launch_bounds__(UPD_THREADS, DA_UPD_OCC) __attribute__((amdgpu
     const Ctx c = make_ctx(g, 2 * g->iter - 1);
     const int m = g->m, nb = c.n_bits, Kpad = c.Kpad, n_out = c.n_out;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // LDS: per-wave counters [UPD_WAVES][3][Kpad] | matched columns [m] | consumed digits of A [m] and B [m]
-    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(smem);
-    int *s_col = reinterpret_cast<int *>(s_cnt + UPD_WAVES * 3 * Kpad);
-    Cell *s_mA = reinterpret_cast<Cell *>(s_col + ((n_out + 1) & ~1));
+    // LDS: consumed digits of A [n_out] and B [n_out] | per-wave counters [UPD_WAVES][3][Kpad] | column -> 1 + index of the
+    // substituted column, 0 = not substituted [n_out]
+    Cell *s_mA = reinterpret_cast<Cell *>(smem);
     Cell *s_mB = s_mA + n_out;
+    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_mB + n_out);
+    uint16_t *s_cmap = reinterpret_cast<uint16_t *>(s_cnt + UPD_WAVES * 3 * Kpad);
     const int tid = threadIdx.x, lane = lane_id(), wid = wave_id();
+    for (int j = tid; j < n_out; j += UPD_THREADS) s_cmap[j] = 0;
+    __syncthreads();
     {
         const DA_GLOBAL int *mcol = (const DA_GLOBAL int *)g->mcol;
         const DA_GLOBAL Cell *mA = (const DA_GLOBAL Cell *)g->mA, *mB = (const DA_GLOBAL Cell *)g->mB;
         for (int j = tid; j < m; j += UPD_THREADS) {
-            s_col[j] = mcol[j];
+            s_cmap[mcol[j]] = (uint16_t)(j + 1);
             s_mA[j] = mA[j];
             s_mB[j] = mB[j];
         }
@@ -1076,69 +1130,48 @@ __global__ void __launch_bounds__(UPD_THREADS, DA_UPD_OCC) __attribute__((amdgpu
     __syncthreads();
     const uint32_t A = g->A, B = g->B, Nw = g->Nw;
     const bool same = A == B;
-    const DA_GLOBAL Cell *cells = (const DA_GLOBAL Cell *)g->cells;
-    const DA_GLOBAL uint32_t *plist = (const DA_GLOBAL uint32_t *)g->plist;
+    const DA_GLOBAL Entry *rl = (const DA_GLOBAL Entry *)g->rlist;
+    const DA_GLOBAL unsigned long long *plist = (const DA_GLOBAL unsigned long long *)g->plist;
     const RowInfo rnew = load_row(c.rows, Nw);
     uint32_t *dA = s_cnt + (size_t)wid * 3 * Kpad, *dB = dA + Kpad, *cN = dB + Kpad;
     unsigned int partners = 0, found = 0, inserts = 0;
     UPD_TIMER_DECL
     // static striding over the partner list (no work counter: partners cost about the same).  Software pipeline: the
-    // cell and probe loads of the NEXT partner are issued before the current partner's blocks are read, so the two
+    // list and probe loads of the NEXT partner are issued before the current partner's blocks are read, so the two
     // dependent memory round-trips of consecutive partners overlap.
     const int total_waves = (int)gridDim.x * UPD_WAVES;
     const int first = (int)blockIdx.x * UPD_WAVES + wid;
     const bool second = lane >= (int)BUCKET;
     const bool probing = lane < (int)BUCKET || (!same && lane < 2 * (int)BUCKET);
-#ifdef DA_UNCOND_PREFETCH
-    const int my_col = s_col[min(lane, m - 1)];  // this lane's substituted column, read from LDS once (not per partner)
-#endif
-    auto issue = [&](uint32_t row, Cell &x0, unsigned long long &kk) {
-#ifdef DA_UNCOND_PREFETCH
-        // EXPERIMENT (not yet measured): every lane loads, with clamped indices and no branch around the loads.  The
-        // loads of the NEXT partner then no longer sit behind exec-masked branches, and the first enumeration pass
-        // (below) uses the prefetched cell without any load, so nothing forces a vmcnt(0) wait on the loads issued
-        // just before for the next partner.
-        const uint32_t other = second ? B : A;
-        const uint32_t h = hash_pair(min(other, row), max(other, row));
-        x0 = cells[(size_t)row * n_out + my_col];  // lanes >= m: a valid but unused cell
-        kk = c.hkey[((h & ~(BUCKET - 1)) & c.cmask) + (lane & (BUCKET - 1))];
-#else
-        x0 = lane < m ? cells[(size_t)row * n_out + s_col[lane]] : (Cell)0;
+    auto issue = [&](unsigned long long ref, Entry &e0, unsigned long long &kk) {
+        const uint32_t row = ref_row(ref);
+        e0 = lane < (int)ref_len(ref) ? rl[(size_t)ref_off(ref) + lane] : F::none();
         const uint32_t other = second ? B : A;
         const uint32_t h = hash_pair(min(other, row), max(other, row));
         kk = probing ? c.hkey[((h & ~(BUCKET - 1)) & c.cmask) + (lane & (BUCKET - 1))] : KEY_TOMB;
-#endif
     };
-    uint32_t pr = 0, pr_next = 0;
-    Cell x0 = 0;
+    unsigned long long pref = 0, pref_next = 0;
+    Entry e0 = F::none();
     unsigned long long kk = KEY_TOMB;
     if (first < n_partners) {
-        pr = plist[first];
-        issue(pr, x0, kk);
-#ifdef DA_UNCOND_PREFETCH
-        pr_next = plist[min(first + total_waves, n_partners - 1)];
-#else
-        if (first + total_waves < n_partners) pr_next = plist[first + total_waves];
-#endif
+        pref = plist[first];
+        issue(pref, e0, kk);
+        if (first + total_waves < n_partners) pref_next = plist[first + total_waves];
     }
     for (int q = first; q < n_partners; q += total_waves) {
         // next partner: loads in flight during this partner's processing
         const bool has_next = q + total_waves < n_partners;
-        const uint32_t prn = pr_next;
-        Cell x0n = 0;
+        const unsigned long long prefn = pref_next;
+        Entry e0n = F::none();
         unsigned long long kkn = KEY_TOMB;
-#ifdef DA_UNCOND_PREFETCH
-        pr_next = plist[min(q + 2 * total_waves, n_partners - 1)];  // past the end: re-reads the last entry, unused
-        issue(prn, x0n, kkn);
-        (void)has_next;
-#else
         if (has_next) {
-            if (q + 2 * total_waves < n_partners) pr_next = plist[q + 2 * total_waves];
-            issue(prn, x0n, kkn);
+            if (q + 2 * total_waves < n_partners) pref_next = plist[q + 2 * total_waves];
+            issue(prefn, e0n, kkn);
         }
-#endif
         ++partners;
-        const DA_GLOBAL Cell *rowR = cells + (size_t)pr * n_out;
+        const uint32_t pr = ref_row(pref);
+        const int plen = (int)ref_len(pref);
+        const DA_GLOBAL Entry *rowR = rl + (size_t)ref_off(pref);
         const uint32_t lA = min(A, pr), hA = max(A, pr), lB = min(B, pr), hB = max(B, pr);
         const unsigned long long keyA = pack_pair(lA, hA), keyB = pack_pair(lB, hB);
         // resolve the two first-bucket probes (lanes 0-15: block with A, lanes 16-31: block with B)
@@ -1163,46 +1196,22 @@ __global__ void __launch_bounds__(UPD_THREADS, DA_UPD_OCC) __attribute__((amdgpu
         for (int k = lane; k < 3 * Kpad; k += WAVE) dA[k] = 0;
         lds_fence();
         int got_new = 0;
-#ifdef DA_UNCOND_PREFETCH
-        auto enumerate = [&](int j, Cell x) {
-            if (!x) return;
-            Cell ma = s_mA[j], mb = s_mB[j];
-            if (slotA >= 0) {
-                for_pairs_part<Cell>(ma, x, A < pr, nb, [&](int k) { atomicAdd(&dA[k], 1u); });
-                if (same) for_pairs_part<Cell>(mb, x, A < pr, nb, [&](int k) { atomicAdd(&dA[k], 1u); });
-            }
-            if (!same && slotB >= 0) for_pairs_part<Cell>(mb, x, B < pr, nb, [&](int k) { atomicAdd(&dB[k], 1u); });
-#ifdef DA_NORTN_ATOMICS
-            for_pairs_cross<Cell>(x, ma, nb, [&](int k) { atomicAdd(&cN[k], 1u); });  // no return value: not waited for
-#else
-            for_pairs_cross<Cell>(x, ma, nb, [&](int k) { got_new |= atomicAdd(&cN[k], 1u) >= 1u; });
-#endif
-        };
-        if (lane < m) enumerate(lane, x0);  // the prefetched cell: no load, no wait on the younger loads
-        for (int j = lane + WAVE; j < m; j += WAVE) enumerate(j, rowR[s_col[j]]);  // m > 64 only
-#else
-        for (int j = lane; j < m; j += WAVE) {
-            Cell x = j == lane ? x0 : rowR[s_col[j]];
+        for (int j = lane; j < plen; j += WAVE) {
+            const Entry e = j == lane ? e0 : rowR[j];
+            const Cell x = F::cell(e);
             if (!x) continue;
-            Cell ma = s_mA[j], mb = s_mB[j];
+            const int at = (int)s_cmap[F::col(e)];
+            if (!at) continue;  // this column was not substituted
+            Cell ma = s_mA[at - 1], mb = s_mB[at - 1];
             if (slotA >= 0) {
                 for_pairs_part<Cell>(ma, x, A < pr, nb, [&](int k) { atomicAdd(&dA[k], 1u); });
                 if (same) for_pairs_part<Cell>(mb, x, A < pr, nb, [&](int k) { atomicAdd(&dA[k], 1u); });
             }
             if (!same && slotB >= 0) for_pairs_part<Cell>(mb, x, B < pr, nb, [&](int k) { atomicAdd(&dB[k], 1u); });
-#ifdef DA_NORTN_ATOMICS
-            for_pairs_cross<Cell>(x, ma, nb, [&](int k) { atomicAdd(&cN[k], 1u); });
-#else
             for_pairs_cross<Cell>(x, ma, nb, [&](int k) { got_new |= atomicAdd(&cN[k], 1u) >= 1u; });
-#endif
         }
-#endif
         lds_fence();
-#ifdef DA_NORTN_ATOMICS
-        // EXPERIMENT (not yet measured): fire-and-forget LDS adds above, one scan of the new block's counters here
-        for (int k = lane; k < c.K; k += WAVE) got_new |= cN[k] >= 2u;
-#endif
-        UPD_TIMER_MARK(2)  // cells + pair enumeration
+        UPD_TIMER_MARK(2)  // list + pair enumeration
         if (slotA >= 0 || slotB >= 0) table_update_pair(c, slotA, keyA, dA, slotB, keyB, dB);
         found += (slotA >= 0) + (slotB >= 0);
         UPD_TIMER_MARK(3)  // block updates
@@ -1211,8 +1220,8 @@ __global__ void __launch_bounds__(UPD_THREADS, DA_UPD_OCC) __attribute__((amdgpu
             ++inserts;
         }
         UPD_TIMER_MARK(4)  // block creation
-        pr = prn;
-        x0 = x0n;
+        pref = prefn;
+        e0 = e0n;
         kk = kkn;
     }
     UPD_TIMER_FLUSH
@@ -1228,18 +1237,34 @@ __global__ void __launch_bounds__(UPD_THREADS, DA_UPD_OCC) __attribute__((amdgpu
 // grid (ceil(n_out / 4), n_chains): one wave per column compacts the surviving (row, cell) entries in row order.
 template <class Cell> __global__ void __launch_bounds__(256) k_extract(ChainDev *chains) {
     using O = CellOps<Cell>;
+    using F = RowFmt<Cell>;
     ChainDev &ch = chains[blockIdx.y];
     int j = blockIdx.x * (blockDim.x / WAVE) + wave_id();
     if (j >= ch.n_out) return;
-    const Cell *cells = reinterpret_cast<const Cell *>(ch.cells);
+    const auto *rl = reinterpret_cast<const typename F::Entry *>(ch.rlist);
     int lane = lane_id(), len = ch.collen[j], out = 0;
     for (int base = 0; base < len; base += WAVE) {
         int e = base + lane;
         Cell c = 0;
         uint32_t r = 0;
         if (e < len) {
-            r = ch.collist[(size_t)j * ch.lcap + e];
-            c = cells[(size_t)r * ch.n_out + j];
+            const unsigned long long ref = ch.collist[(size_t)j * ch.lcap + e];
+            r = ref_row(ref);
+            const auto *row = rl + ref_off(ref);
+            if ((int)r < ch.n_in)
+                c = F::cell(row[j]);  // dense input row
+            else {  // sparse row, sorted by column: binary search for column j (listed here, so it is present)
+                int lo = 0, hi = (int)ref_len(ref) - 1;
+                while (lo < hi) {
+                    int mid = (lo + hi) >> 1;
+                    if (F::col(row[mid]) < (uint32_t)j)
+                        lo = mid + 1;
+                    else
+                        hi = mid;
+                }
+                const auto en = row[lo];
+                c = F::col(en) == (uint32_t)j ? F::cell(en) : (Cell)0;
+            }
         }
         unsigned long long nz = __ballot(c != 0);
         if (c != 0) {
@@ -1457,33 +1482,32 @@ void *HipBackend::stream() const { return impl_->stream; }
 namespace {
 
 struct Geometry {
-    bool wide;  // 64-bit cells
-    int n_bits, K, Kpad, rcap, lcap, gs_log2, n_groups, pk_cap;
-    uint32_t C;
+    bool wide;  // 64-bit cells and 16-byte list entries (more than 12 digits or more than 256 columns)
+    int n_bits, K, Kpad, rcap, lcap, gs_log2, n_groups, pk_cap, pb_log2;
+    uint32_t C, rl_cap;
 };
 
 // carve one chain's arrays; with base == nullptr only the size is computed
 size_t carve_chain(unsigned char *base, const ChainJob &job, const Geometry &g, ChainDev &d) {
     Carver c(base);
-    size_t cell = g.wide ? 8 : 4;
-    size_t n_in = job.n_in, n_out = job.n_out;
-    d.cells = c.take<unsigned char>((size_t)g.rcap * n_out * cell);
+    size_t cell = g.wide ? 8 : 4, entry = g.wide ? 16 : 4;
+    size_t n_out = job.n_out;
+    d.rlist = c.take<unsigned char>((size_t)g.rl_cap * entry);
+    d.rowoff = c.take<da_u2>(g.rcap);
     d.rows = c.take<RowInfo>(g.rcap);
     d.stamp = c.take<uint32_t>(g.rcap);
-    d.collist = c.take<uint32_t>(n_out * (size_t)g.lcap);
+    d.collist = c.take<unsigned long long>(n_out * (size_t)g.lcap);
     d.collen = c.take<int>(n_out);
     d.hkey = c.take<unsigned long long>(g.C);
     d.hrank = c.take<uint32_t>(g.C);
-    d.hidx = c.take<uint8_t>(g.C);
-    d.hstat = c.take<HStat>(g.C);
-    d.hcnt = c.take<uint16_t>((size_t)g.C * g.Kpad);
+    d.hblk = c.take<unsigned char>((size_t)g.C << g.pb_log2);
     d.ub = c.take<unsigned long long>(g.n_groups);
     d.gtie = c.take<unsigned long long>(g.n_groups);
     d.gdirty = c.take<uint8_t>(g.n_groups);
     d.mcol = c.take<int>(n_out);
     d.mA = c.take<unsigned char>(n_out * cell);
     d.mB = c.take<unsigned char>(n_out * cell);
-    d.plist = c.take<uint32_t>(g.rcap);
+    d.plist = c.take<unsigned long long>(g.rcap);
     d.picks = c.take<int4>(g.rcap);
     d.fin_row = c.take<uint32_t>(n_out * (size_t)g.lcap);
     d.fin_cell = c.take<unsigned long long>(n_out * (size_t)g.lcap);
@@ -1493,7 +1517,6 @@ size_t carve_chain(unsigned char *base, const ChainJob &job, const Geometry &g, 
     d.pk_row = c.take<uint32_t>((size_t)g.pk_cap);
     d.pk_cell = c.take<unsigned long long>((size_t)g.pk_cap);
     d.pk_lat = c.take<float>(g.rcap);
-    (void)n_in;
     return align_up(c.off, 256);
 }
 
@@ -1573,9 +1596,11 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
         Geometry &g = geo[i];
         g.n_bits = d.prep_nbits;
         if (g.n_bits > 30) throw std::runtime_error("kernel needs more than 30 CSD digits per entry (the reference overflows int32 there); unsupported");
-        g.wide = g.n_bits > 16;
+        g.wide = g.n_bits > 12 || jobs[i].n_out > 256;  // the narrow list entry is col:8 | minus:12 | plus:12
         g.K = key_count(g.n_bits);
         g.Kpad = (g.K + 3) & ~3;
+        g.pb_log2 = 5;  // payload line of a pair block: 16-byte header + Kpad u16 counts, padded to a power of two
+        while ((1 << g.pb_log2) < 16 + 2 * g.Kpad) ++g.pb_log2;
         long long D0 = d.prep_digits;
         // every greedy step removes at least one digit; typical chains need ~D0/8 steps
         long long steps = jobs[i].method == M_DUMMY || jobs[i].method < 0 ? 0 : std::max<long long>(16, (long long)(D0 * row_scale_ / 4));
@@ -1583,6 +1608,12 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
         g.rcap = jobs[i].n_in + (int)steps + 1;
         g.lcap = jobs[i].n_in + d.prep_maxdcol + 1;
         g.pk_cap = (int)std::min<long long>(D0 + 1, (long long)1 << 30);  // digits only ever disappear
+        // row lists: the dense lists of the input rows + one entry per (new row, column), each holding at least one of
+        // the digits that the substitutions move into new rows (at most D0 over a chain)
+        const long long rl_want = (long long)jobs[i].n_in * jobs[i].n_out + D0 + jobs[i].n_out + 64;
+        if (rl_want >= (1ll << REF_OFF_BITS) || g.rcap >= (1 << REF_ROW_BITS) || jobs[i].n_out >= (1 << REF_LEN_BITS))
+            throw std::runtime_error("problem too large for the row-reference format (rows < 2^24, columns < 4096, list entries < 2^28)");
+        g.rl_cap = (uint32_t)rl_want;
         // table capacity: blocks peak well above the initial pair count when rows are dense
         long long pairs0 = std::min<long long>((long long)jobs[i].n_in * (jobs[i].n_in + 1) / 2, std::max<long long>(d.prep_pairs, 1));
         double growth = std::max(4.0, jobs[i].n_in / 5.0);
@@ -1626,6 +1657,9 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
         d.n_groups = g.n_groups;
         d.C = g.C;
         d.cmask = g.C - 1;
+        d.pb_log2 = g.pb_log2;
+        d.rl_cap = g.rl_cap;
+        d.rl_used = (uint32_t)jobs[i].n_in * (uint32_t)jobs[i].n_out;
         d.n_rows = jobs[i].n_in;
         d.claim_words = (g.rcap + 31) / 32 * 4 <= 64 * 1024 ? (g.rcap + 31) / 32 : 0;
         d.iter = 0;
@@ -1636,7 +1670,6 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
         HIP_CHECK(hipMemsetAsync(d.hrank, 0, sizeof(uint32_t) * (size_t)g.C, st));
         HIP_CHECK(hipMemsetAsync(d.ub, 0, sizeof(unsigned long long) * (size_t)g.n_groups, st));
         HIP_CHECK(hipMemsetAsync(d.gdirty, 1, (size_t)g.n_groups, st));
-        // rows beyond n_in start with empty cells: new rows are fully written by k_iter_select
     }
     HIP_CHECK(hipMemcpyAsync(d_desc, desc.data(), sizeof(ChainDev) * (size_t)n, hipMemcpyHostToDevice, st));
     HIP_CHECK(hipMemsetAsync(im.d_done, 0, sizeof(unsigned int), st));
@@ -1669,10 +1702,11 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
         int w = geo[i].wide;
         size_t claim_bytes = ((size_t)geo[i].rcap + 31) / 32 * 4;
         if (claim_bytes > 64 * 1024) claim_bytes = 0;
-        size_t s = 6 * (size_t)geo[i].Kpad * 4 + (2 * (size_t)jobs[i].n_out + 1) * 4 + claim_bytes;
+        const size_t no = (size_t)jobs[i].n_out, cellb = geo[i].wide ? 8 : 4, entb = geo[i].wide ? 16 : 4;
+        size_t s = no * entb + 6 * (size_t)geo[i].Kpad * 4 + (3 * no + 1) * 4 + claim_bytes;
         s = align_up(s, 16);
         sel_lds[w] = std::max(sel_lds[w], s);
-        upd_lds[w] = std::max(upd_lds[w], align_up((size_t)UPD_WAVES * 3 * geo[i].Kpad * 4 + (((size_t)jobs[i].n_out + 1) & ~(size_t)1) * 4 + 2 * (size_t)jobs[i].n_out * (geo[i].wide ? 8 : 4), 16));
+        upd_lds[w] = std::max(upd_lds[w], align_up(2 * no * cellb + (size_t)UPD_WAVES * 3 * geo[i].Kpad * 4 + no * 2, 16));
         pair_lds[w] = std::max(pair_lds[w], (size_t)4 * geo[i].Kpad * 4);
         max_pairs[w] = std::max(max_pairs[w], (long long)jobs[i].n_in * (jobs[i].n_in + 1) / 2);
     }
@@ -2007,7 +2041,7 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
         im.timings.iterations += d.iter;
         im.timings.rescans += (long long)d.st_rescans;
         im.timings.partners += (long long)d.st_partners;
-        im.timings.table_bytes += (double)d.C * (8 + 4 + 1 + 8 + 2.0 * d.Kpad);
+        im.timings.table_bytes += (double)d.C * (8.0 + 4.0 + (double)(1 << d.pb_log2));
     }
     lap("extract + download + unpack");
     im.timings.loop_ms += loop_ms;
