@@ -208,20 +208,45 @@ __constant__ Log2Table c_log2;
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE - 1); }
 __device__ __forceinline__ int wave_id() { return threadIdx.x / WAVE; }
 
+// Wave-wide reductions on the DPP path (row shifts inside the 16-lane rows, then the two row broadcasts of gfx9): six
+// VALU operations per 32-bit word and no LDS round trip.  (The __shfl_xor butterflies they replace go through
+// ds_bpermute -- about 900 cycles per 64-bit reduction, which dominated the arg-max loop of k_iter_select.)
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ uint32_t dpp_u32(uint32_t identity, uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)identity, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
+constexpr int DPP_ROW_SHR1 = 0x111, DPP_ROW_SHR2 = 0x112, DPP_ROW_SHR4 = 0x114, DPP_ROW_SHR8 = 0x118, DPP_ROW_BCAST15 = 0x142, DPP_ROW_BCAST31 = 0x143;
+#define DA_DPP_REDUCE32(v, ident, OP)                                   \
+    v = OP(v, dpp_u32<DPP_ROW_SHR1, 0xF>(ident, v));                    \
+    v = OP(v, dpp_u32<DPP_ROW_SHR2, 0xF>(ident, v));                    \
+    v = OP(v, dpp_u32<DPP_ROW_SHR4, 0xF>(ident, v));                    \
+    v = OP(v, dpp_u32<DPP_ROW_SHR8, 0xF>(ident, v));                    \
+    v = OP(v, dpp_u32<DPP_ROW_BCAST15, 0xA>(ident, v));                 \
+    v = OP(v, dpp_u32<DPP_ROW_BCAST31, 0xC>(ident, v));
+__device__ __forceinline__ uint32_t umax32(uint32_t a, uint32_t b) { return a > b ? a : b; }
+__device__ __forceinline__ uint32_t smin32(uint32_t a, uint32_t b) { return (int)a < (int)b ? a : b; }
 __device__ __forceinline__ int wave_min_i32(int v) {
-    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
-    return v;
+    uint32_t x = (uint32_t)v;
+    DA_DPP_REDUCE32(x, 0x7FFFFFFFu, smin32)
+    return __builtin_amdgcn_readlane((int)x, 63);
 }
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
-    for (int o = 32; o > 0; o >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, o));
-    return v;
+    DA_DPP_REDUCE32(v, 0u, umax32)
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ unsigned long long dpp_max_u64(unsigned long long v) {
+    const uint32_t lo = dpp_u32<CTRL, ROW_MASK>(0u, (uint32_t)v), hi = dpp_u32<CTRL, ROW_MASK>(0u, (uint32_t)(v >> 32));
+    const unsigned long long t = ((unsigned long long)hi << 32) | lo;
+    return t > v ? t : v;
 }
 __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
-    for (int o = 32; o > 0; o >>= 1) {
-        unsigned long long t = __shfl_xor(v, o);
-        v = t > v ? t : v;
-    }
-    return v;
+    v = dpp_max_u64<DPP_ROW_SHR1, 0xF>(v);
+    v = dpp_max_u64<DPP_ROW_SHR2, 0xF>(v);
+    v = dpp_max_u64<DPP_ROW_SHR4, 0xF>(v);
+    v = dpp_max_u64<DPP_ROW_SHR8, 0xF>(v);
+    v = dpp_max_u64<DPP_ROW_BCAST15, 0xA>(v);
+    v = dpp_max_u64<DPP_ROW_BCAST31, 0xC>(v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, 63), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), 63);
+    return ((unsigned long long)hi << 32) | lo;
 }
 // Make this wave's LDS traffic visible to its own lanes: wait for outstanding LDS operations only (lgkmcnt(0));
 // global loads stay in flight.  LDS operations of one wave complete in order, so no wider fence is needed for the
@@ -418,58 +443,6 @@ __device__ void table_update(const Ctx &c, int slot, unsigned long long key, Cnt
     best = wave_max_u64(best);
     alive = __any(alive);
     if (lane == 0) block_commit(c, slot, key, h, best, alive);
-}
-
-// Two block updates with all their loads in flight together (a partner row touches its blocks with A and with B).
-// slot < 0 means "no such block".  delta arrays live in LDS.  One payload line is read and written per block.
-__device__ __forceinline__ void table_update_pair(const Ctx &c, int slot0, unsigned long long key0, const uint32_t *d0, int slot1,
-                                                  unsigned long long key1, const uint32_t *d1) {
-    const int lane = lane_id();
-    const bool h0 = slot0 >= 0, h1 = slot1 >= 0;
-    const BlkHdr z{0, 0.0f, 0u, 0u};
-    const BlkHdr b0 = h0 ? load_hdr(c, slot0) : z, b1 = h1 ? load_hdr(c, slot1) : z;
-    DA_GLOBAL uint16_t *cnt0 = blk_cnt(c, h0 ? slot0 : 0), *cnt1 = blk_cnt(c, h1 ? slot1 : 0);
-    uint32_t o0[2] = {0, 0}, o1[2] = {0, 0};
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        int k = lane + u * WAVE;
-        if (k < c.K) {
-            if (h0) o0[u] = cnt0[k];
-            if (h1) o1[u] = cnt1[k];
-        }
-    }
-    unsigned long long best0 = 0, best1 = 0;
-    int alive0 = 0, alive1 = 0;
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        int k = lane + u * WAVE;
-        if (k < c.K) {
-            if (h0) {
-                uint32_t n = o0[u] - d0[k];
-                if (n != o0[u]) cnt0[k] = (uint16_t)n;
-                alive0 |= n >= 2;
-                uint32_t r = entry_rank(n, b0.ov, b0.dl, c.method);
-                unsigned long long cand = r ? (((unsigned long long)r << 8) | (unsigned)k) : 0ull;
-                best0 = cand > best0 ? cand : best0;
-            }
-            if (h1) {
-                uint32_t n = o1[u] - d1[k];
-                if (n != o1[u]) cnt1[k] = (uint16_t)n;
-                alive1 |= n >= 2;
-                uint32_t r = entry_rank(n, b1.ov, b1.dl, c.method);
-                unsigned long long cand = r ? (((unsigned long long)r << 8) | (unsigned)k) : 0ull;
-                best1 = cand > best1 ? cand : best1;
-            }
-        }
-    }
-    best0 = wave_max_u64(best0);
-    best1 = wave_max_u64(best1);
-    alive0 = __any(alive0);
-    alive1 = __any(alive1);
-    if (lane == 0) {
-        if (h0) block_commit(c, slot0, key0, b0, best0, alive0);
-        if (h1) block_commit(c, slot1, key1, b1, best1, alive1);
-    }
 }
 
 // ------------------------------------------------------------------------------------------------ k_prepare
@@ -714,7 +687,7 @@ template <class Cell> __global__ void __launch_bounds__(SEL_THREADS) k_iter_sele
                     top_u = u;
                 }
             const unsigned long long wtop = wave_max_u64(top);
-            if (wtop == 0 || wtop < *(volatile unsigned long long *)&s_floor) break;
+            if (wtop == 0 || wtop < __hip_atomic_load(&s_floor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;  // ds_read_b64, not a FLAT load
             const unsigned long long who = __ballot(top == wtop);
             const int owner = __ffsll((long long)who) - 1;
             const int own_u = __shfl(top_u, owner);
@@ -858,6 +831,10 @@ template <class Cell> __global__ void __launch_bounds__(SEL_THREADS) k_iter_sele
     }
     DA_GLOBAL Entry *rl = (DA_GLOBAL Entry *)g->rlist;
     DA_GLOBAL Entry *rlA = rl + refA.x, *rlB = rl + refB.x, *rlN = rl + offN;
+    DA_GLOBAL int *collen = (DA_GLOBAL int *)g->collen;
+    // this thread's entry of A (first chunk) and the list length of its column are fetched now, in flight together with B's
+    // list: pass 1 below then starts without a dependent load
+    const Entry eA0 = tid < lenA ? rlA[tid] : F::none();
     if (!same) {  // B's list into LDS, addressable by column
         for (int j = tid; j < n_out; j += SEL_THREADS) s_bpos[j] = 0;
         __syncthreads();
@@ -867,10 +844,11 @@ template <class Cell> __global__ void __launch_bounds__(SEL_THREADS) k_iter_sele
             s_bpos[F::col(e)] = t + 1;
         }
     }
+    const int clen0 = tid < lenA ? collen[F::col(eA0)] : 0;  // pre-append list length of this thread's column (used if it matches)
     __syncthreads();
     tp[3] = clock64();
     DA_GLOBAL Cell *mA = (DA_GLOBAL Cell *)g->mA, *mB = (DA_GLOBAL Cell *)g->mB;
-    DA_GLOBAL int *mcol = (DA_GLOBAL int *)g->mcol, *collen = (DA_GLOBAL int *)g->collen;
+    DA_GLOBAL int *mcol = (DA_GLOBAL int *)g->mcol;
     DA_GLOBAL unsigned long long *collist = (DA_GLOBAL unsigned long long *)g->collist;
     uint32_t *cAA = s_cnt, *cAB = s_cnt + Kpad, *cBB = s_cnt + 2 * Kpad, *cAN = s_cnt + 3 * Kpad, *cBN = s_cnt + 4 * Kpad,
              *cNN = s_cnt + 5 * Kpad;
@@ -884,7 +862,7 @@ template <class Cell> __global__ void __launch_bounds__(SEL_THREADS) k_iter_sele
         uint32_t colA = 0;
         int pos = 0;
         if (t < lenA) {
-            const Entry e = rlA[t];
+            const Entry e = t0 == 0 ? eA0 : rlA[t];
             colA = F::col(e);
             a = F::cell(e);
             if (same)
@@ -916,7 +894,7 @@ template <class Cell> __global__ void __launch_bounds__(SEL_THREADS) k_iter_sele
             mcol[at] = (int)colA;
             mA[at] = ma;
             mB[at] = mb;
-            s_len[at] = collen[colA];  // the pre-append length: the new row itself is not a partner
+            s_len[at] = t0 == 0 ? clen0 : collen[colA];  // the pre-append length: the new row itself is not a partner
             s_col[at] = (int)colA;
             my_matches += popc32(O::plus(ma) | O::minus(ma));
         }
@@ -1000,13 +978,13 @@ template <class Cell> __global__ void __launch_bounds__(SEL_THREADS) k_iter_sele
         DA_GLOBAL uint32_t *stamp = (DA_GLOBAL uint32_t *)g->stamp;
         DA_GLOBAL unsigned long long *plist = (DA_GLOBAL unsigned long long *)g->plist;
         const uint32_t tag = (uint32_t)iter + 1u;
-        constexpr int CLAIM_ILP = 4;
-        for (int f0 = tid; f0 < total; f0 += CLAIM_ILP * CLAIM_THREADS) {
+        constexpr int CLAIM_ILP = 8;  // independent list reads in flight per thread: one pass covers 5120 list entries
+        for (int fb = wid * WAVE; fb < total; fb += CLAIM_ILP * CLAIM_THREADS) {  // wave-uniform trip count: all lanes stay active
             unsigned long long r[CLAIM_ILP];
             bool ok[CLAIM_ILP];
 #pragma unroll
             for (int u = 0; u < CLAIM_ILP; ++u) {  // CLAIM_ILP independent list reads in flight
-                const int f = f0 + u * CLAIM_THREADS;
+                const int f = fb + lane + u * CLAIM_THREADS;
                 ok[u] = f < total;
                 r[u] = 0;
                 if (ok[u]) {
@@ -1035,8 +1013,14 @@ template <class Cell> __global__ void __launch_bounds__(SEL_THREADS) k_iter_sele
                     ok[u] = atomicExch(gen(&stamp[row]), tag) != tag;
             }
 #pragma unroll
-            for (int u = 0; u < CLAIM_ILP; ++u)
-                if (ok[u]) plist[atomicAdd(&s_np, 1)] = r[u];
+            for (int u = 0; u < CLAIM_ILP; ++u) {  // one LDS atomic per wave (not per row: same-address atomics serialise)
+                const unsigned long long okm = __ballot(ok[u]);
+                if (!okm) continue;
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&s_np, (int)__popcll(okm));
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (ok[u]) plist[base + __popcll(okm & ((1ull << lane) - 1))] = r[u];
+            }
         }
     } else {
         const int sp = wid - CLAIM_WAVES;
@@ -1083,13 +1067,17 @@ template <class Cell> __global__ void __launch_bounds__(SEL_THREADS) k_iter_sele
 
 // ------------------------------------------------------------------------------------------------ k_iter_update
 // grid (U, n_chains).  Every partner row (a row other than A, B, new that shares a substituted column) is handled
-// by ONE wavefront (static striding over the chain's partner list): it subtracts the pair occurrences lost with
-// A's / B's consumed digits from the blocks (A,r), (B,r) and creates the block (r,new).  The partner's list is read
-// with one coalesced load (lane = entry); lanes whose entry lies in a substituted column enumerate digit pairs.
+// by ONE wavefront: it subtracts the pair occurrences lost with A's / B's consumed digits from the blocks (A,r),
+// (B,r) and creates the block (r,new).
+//
+// The kernel is bound by dependent memory round trips (list reference -> list + two key buckets -> two payload lines),
+// not by bytes, so a wave takes a contiguous chunk of the partner list and works on UPD_BATCH partners at once: all
+// their lists and key buckets are loaded together, then all their payload lines (ONE 32-bit word per lane covers a
+// whole line: header in lanes 0-3, two u16 counts per lane after them), the digit pairs are enumerated into per-partner
+// LDS counters while the payload lines are in flight, and only then the blocks are re-evaluated.  Three round trips per
+// batch instead of per partner.  Rare cases (key not in its first bucket, block creation) run after the batch from LDS.
 #ifndef DA_UPD_OCC
-#define DA_UPD_OCC 6  // blocks of 256 threads per CU the register budget is capped for.  Measured on MI355X (C3, batch 64):
-                      // 8 -> 41.6, 7 -> 45.3, 6 -> 46.1 solves/s: at 8 the kernel spills and every spill reload is a
-                      // vmcnt(0) wait inside the partner loop
+#define DA_UPD_OCC 6  // blocks of 256 threads per CU the register budget is capped for
 #endif
 #if DA_UPD_OCC >= 8
 #define DA_UPD_SGPRS 80  // 800 SGPRs per SIMD: more than 80 per wave would cap the residency below 8 waves per SIMD
@@ -1098,10 +1086,72 @@ template <class Cell> __global__ void __launch_bounds__(SEL_THREADS) k_iter_sele
 #else
 #define DA_UPD_SGPRS 102
 #endif
+#ifndef DA_UPD_BATCH
+#define DA_UPD_BATCH 6
+#endif
+constexpr int UPD_BATCH = DA_UPD_BATCH;
+
+__device__ __forceinline__ unsigned long long bcast64(unsigned long long v, int src_lane) {  // wave-uniform copy of lane src_lane's value
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src_lane);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), src_lane);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+// Which 32-bit word of a block's payload line a lane prefetches.  DIRECT (narrow layout, K <= 46): lane k < K the word that
+// holds count k (lanes 2j and 2j+1 share a word), lanes 60-63 the four header words -- no cross-lane traffic afterwards.
+// Otherwise (K up to 118): lane L word L, the counts are redistributed with a wave shuffle.
+template <bool DIRECT> __device__ __forceinline__ int payload_word(int lane, int K, int nwords, bool &active) {
+    if (DIRECT) {
+        active = lane < K || lane >= 60;
+        return lane < K ? 4 + (lane >> 1) : lane - 60;
+    }
+    active = lane < nwords;
+    return lane;
+}
+// Re-evaluate one block from its prefetched payload word `w` (see payload_word) and the deltas `d` (LDS): new counts
+// stored, best key / rank / group state published by lane 0.
+template <bool DIRECT> __device__ __forceinline__ void apply_block(const Ctx &c, int slot, unsigned long long key, uint32_t w, const uint32_t *d) {
+    const int lane = lane_id();
+    constexpr int H = DIRECT ? 60 : 0;
+    BlkHdr h;
+    h.ov = __builtin_amdgcn_readlane((int)w, H);
+    h.dl = __int_as_float(__builtin_amdgcn_readlane((int)w, H + 1));
+    h.rank = (uint32_t)__builtin_amdgcn_readlane((int)w, H + 2);
+    h.idx = (uint32_t)__builtin_amdgcn_readlane((int)w, H + 3);
+    DA_GLOBAL uint16_t *cnt = blk_cnt(c, slot);
+    unsigned long long best = 0;
+    int alive = 0;
+    for (int k0 = 0; k0 < c.K; k0 += WAVE) {  // at most two rounds (K <= 118); one when DIRECT
+        const int k = k0 + lane;
+        const uint32_t v = DIRECT ? w : (uint32_t)__shfl((int)w, 4 + (k >> 1));
+        if (k < c.K) {
+            const uint32_t old = (k & 1) ? (v >> 16) : (v & 0xFFFFu);
+            const uint32_t n = old - d[k];
+            if (n != old) cnt[k] = (uint16_t)n;
+            alive |= n >= 2;
+            const uint32_t r = entry_rank(n, h.ov, h.dl, c.method);
+            const unsigned long long cand = r ? (((unsigned long long)r << 8) | (unsigned)k) : 0ull;
+            best = cand > best ? cand : best;
+        }
+    }
+    best = wave_max_u64(best);
+    alive = __any(alive);
+    if (lane == 0) block_commit(c, slot, key, h, best, alive);
+}
+
+__device__ __forceinline__ unsigned long long uniform64(unsigned long long v) {  // a value all lanes agree on, made wave-uniform for the compiler
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+constexpr int SLOT_NONE = -1, SLOT_SLOW = -2;  // no such block / to be searched beyond its first bucket
+
 template <class Cell>
 __global__ void __launch_bounds__(UPD_THREADS, DA_UPD_OCC) __attribute__((amdgpu_num_sgpr(DA_UPD_SGPRS))) k_iter_update(ChainDev *chains) {
     using F = RowFmt<Cell>;
     using Entry = typename F::Entry;
+    constexpr int PB = UPD_BATCH;
+    constexpr bool DIRECT = sizeof(Cell) == 4;  // narrow layout: K <= 46 counts, one payload word per lane without a shuffle
     ChainDev *g = &chains[blockIdx.y];
     if (g->done) return;
     const int n_partners = g->n_partners;
@@ -1109,12 +1159,16 @@ __global__ void __launch_bounds__(UPD_THREADS, DA_UPD_OCC) __attribute__((amdgpu
     const Ctx c = make_ctx(g, 2 * g->iter - 1);
     const int m = g->m, nb = c.n_bits, Kpad = c.Kpad, n_out = c.n_out;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // LDS: consumed digits of A [n_out] and B [n_out] | per-wave counters [UPD_WAVES][3][Kpad] | column -> 1 + index of the
-    // substituted column, 0 = not substituted [n_out]
+    // LDS: consumed digits of A [n_out] and B [n_out] | per-wave references
+    // [UPD_WAVES][PB] | per-wave, per-partner counters [UPD_WAVES][PB][3][Kpad] | per-wave slots [UPD_WAVES][2 PB] |
+    // column -> 1 + index of the substituted column, 0 = not substituted [n_out]
     Cell *s_mA = reinterpret_cast<Cell *>(smem);
     Cell *s_mB = s_mA + n_out;
-    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_mB + n_out);
-    uint16_t *s_cmap = reinterpret_cast<uint16_t *>(s_cnt + UPD_WAVES * 3 * Kpad);
+    unsigned long long *s_ref = reinterpret_cast<unsigned long long *>(s_mB + n_out);
+    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_ref + UPD_WAVES * PB);
+    int *s_slot = reinterpret_cast<int *>(s_cnt + (size_t)UPD_WAVES * PB * 3 * Kpad);
+    int *s_col = s_slot + UPD_WAVES * 2 * PB;  // [n_out] the substituted columns (their order is the order of mA / mB)
+    uint16_t *s_cmap = reinterpret_cast<uint16_t *>(s_col + n_out);
     const int tid = threadIdx.x, lane = lane_id(), wid = wave_id();
     for (int j = tid; j < n_out; j += UPD_THREADS) s_cmap[j] = 0;
     __syncthreads();
@@ -1122,7 +1176,9 @@ __global__ void __launch_bounds__(UPD_THREADS, DA_UPD_OCC) __attribute__((amdgpu
         const DA_GLOBAL int *mcol = (const DA_GLOBAL int *)g->mcol;
         const DA_GLOBAL Cell *mA = (const DA_GLOBAL Cell *)g->mA, *mB = (const DA_GLOBAL Cell *)g->mB;
         for (int j = tid; j < m; j += UPD_THREADS) {
-            s_cmap[mcol[j]] = (uint16_t)(j + 1);
+            const int col = mcol[j];
+            s_col[j] = col;
+            s_cmap[col] = (uint16_t)(j + 1);
             s_mA[j] = mA[j];
             s_mB[j] = mB[j];
         }
@@ -1133,96 +1189,191 @@ __global__ void __launch_bounds__(UPD_THREADS, DA_UPD_OCC) __attribute__((amdgpu
     const DA_GLOBAL Entry *rl = (const DA_GLOBAL Entry *)g->rlist;
     const DA_GLOBAL unsigned long long *plist = (const DA_GLOBAL unsigned long long *)g->plist;
     const RowInfo rnew = load_row(c.rows, Nw);
-    uint32_t *dA = s_cnt + (size_t)wid * 3 * Kpad, *dB = dA + Kpad, *cN = dB + Kpad;
+    uint32_t *wcnt = s_cnt + (size_t)wid * PB * 3 * Kpad;
+    unsigned long long *wref = s_ref + wid * PB;
+    int *wslot = s_slot + wid * 2 * PB;
+    const int nwords = 4 + Kpad / 2;  // 32-bit words of a payload line in use (<= 64)
     unsigned int partners = 0, found = 0, inserts = 0;
     UPD_TIMER_DECL
-    // static striding over the partner list (no work counter: partners cost about the same).  Software pipeline: the
-    // list and probe loads of the NEXT partner are issued before the current partner's blocks are read, so the two
-    // dependent memory round-trips of consecutive partners overlap.
-    const int total_waves = (int)gridDim.x * UPD_WAVES;
-    const int first = (int)blockIdx.x * UPD_WAVES + wid;
+    // Partner q of the list goes to wave q mod total_waves: the expensive partners (the dense input rows at the head of
+    // the list) spread over all waves.  A wave's partners are processed in batches of PB.
+    const int total_waves = (int)gridDim.x * UPD_WAVES, gw = (int)blockIdx.x * UPD_WAVES + wid;
+    const int mine = gw < n_partners ? (n_partners - 1 - gw) / total_waves + 1 : 0;
+    const int n_in = g->n_in;
     const bool second = lane >= (int)BUCKET;
     const bool probing = lane < (int)BUCKET || (!same && lane < 2 * (int)BUCKET);
-    auto issue = [&](unsigned long long ref, Entry &e0, unsigned long long &kk) {
-        const uint32_t row = ref_row(ref);
-        e0 = lane < (int)ref_len(ref) ? rl[(size_t)ref_off(ref) + lane] : F::none();
-        const uint32_t other = second ? B : A;
-        const uint32_t h = hash_pair(min(other, row), max(other, row));
-        kk = probing ? c.hkey[((h & ~(BUCKET - 1)) & c.cmask) + (lane & (BUCKET - 1))] : KEY_TOMB;
-    };
-    unsigned long long pref = 0, pref_next = 0;
-    Entry e0 = F::none();
-    unsigned long long kk = KEY_TOMB;
-    if (first < n_partners) {
-        pref = plist[first];
-        issue(pref, e0, kk);
-        if (first + total_waves < n_partners) pref_next = plist[first + total_waves];
-    }
-    for (int q = first; q < n_partners; q += total_waves) {
-        // next partner: loads in flight during this partner's processing
-        const bool has_next = q + total_waves < n_partners;
-        const unsigned long long prefn = pref_next;
-        Entry e0n = F::none();
-        unsigned long long kkn = KEY_TOMB;
-        if (has_next) {
-            if (q + 2 * total_waves < n_partners) pref_next = plist[q + 2 * total_waves];
-            issue(prefn, e0n, kkn);
-        }
-        ++partners;
-        const uint32_t pr = ref_row(pref);
-        const int plen = (int)ref_len(pref);
-        const DA_GLOBAL Entry *rowR = rl + (size_t)ref_off(pref);
-        const uint32_t lA = min(A, pr), hA = max(A, pr), lB = min(B, pr), hB = max(B, pr);
-        const unsigned long long keyA = pack_pair(lA, hA), keyB = pack_pair(lB, hB);
-        // resolve the two first-bucket probes (lanes 0-15: block with A, lanes 16-31: block with B)
-        int slotA = -1, slotB = -1;
-        {
-            const unsigned long long want = second ? keyB : keyA;
-            const unsigned long long hit = __ballot(probing && kk == want), emp = __ballot(probing && kk == KEY_EMPTY);
-            const unsigned long long m0 = 0xFFFFull, m1 = 0xFFFF0000ull;
-            const uint32_t hhA = hash_pair(lA, hA), hhB = hash_pair(lB, hB);
-            if (hit & m0)
-                slotA = (int)(((hhA & ~(BUCKET - 1)) & c.cmask) + (__ffsll((long long)(hit & m0)) - 1));
-            else if (!(emp & m0))
-                slotA = table_find_from(c, keyA, hhA, 1);
-            if (!same) {
-                if (hit & m1)
-                    slotB = (int)(((hhB & ~(BUCKET - 1)) & c.cmask) + (__ffsll((long long)(hit & m1)) - 1 - (int)BUCKET));
-                else if (!(emp & m1))
-                    slotB = table_find_from(c, keyB, hhB, 1);
+    for (int b0 = 0; b0 < mine; b0 += PB) {
+        const int nbat = min(PB, mine - b0);
+        partners += (unsigned)nbat;
+        // ---- round trip 1: the references of the batch
+        const unsigned long long myref = lane < nbat ? plist[gw + (size_t)(b0 + lane) * total_waves] : 0ull;
+        if (lane < PB) wref[lane] = myref;
+        // ---- round trip 2: every partner's list head (lane = entry) and its two key buckets (lanes 0-15: block with A,
+        // lanes 16-31: block with B), all in flight together
+        unsigned long long kk[PB];
+        uint32_t hb[PB];  // first slot of the key bucket this lane's half probes (lanes 0-15: block with A, 16-31: with B)
+        Entry e[PB];
+#pragma unroll
+        for (int p = 0; p < PB; ++p) {
+            const unsigned long long ref = bcast64(myref, p);
+            e[p] = F::none();
+            kk[p] = KEY_TOMB;
+            hb[p] = 0;
+            if (p < nbat) {
+                const uint32_t row = ref_row(ref);
+                if ((int)row < n_in) {  // dense input row: entry j is column j -- fetch the substituted columns only
+                    if (lane < m) e[p] = rl[(size_t)ref_off(ref) + s_col[lane]];
+                } else if (lane < (int)ref_len(ref))
+                    e[p] = rl[(size_t)ref_off(ref) + lane];
+                const uint32_t other = second ? B : A;
+                hb[p] = (hash_pair(min(other, row), max(other, row)) & ~(BUCKET - 1)) & c.cmask;
+                if (probing) kk[p] = c.hkey[hb[p] + (lane & (BUCKET - 1))];
             }
         }
-        UPD_TIMER_MARK(1)  // list entry + two table probes
-        for (int k = lane; k < 3 * Kpad; k += WAVE) dA[k] = 0;
-        lds_fence();
-        int got_new = 0;
-        for (int j = lane; j < plen; j += WAVE) {
-            const Entry e = j == lane ? e0 : rowR[j];
-            const Cell x = F::cell(e);
-            if (!x) continue;
-            const int at = (int)s_cmap[F::col(e)];
-            if (!at) continue;  // this column was not substituted
-            Cell ma = s_mA[at - 1], mb = s_mB[at - 1];
-            if (slotA >= 0) {
+        for (int k = lane; k < PB * 3 * Kpad; k += WAVE) wcnt[k] = 0;  // while the loads are in flight
+        // ---- resolve the first-bucket probes; round trip 3: the payload lines of the blocks that exist
+        uint32_t wA[PB], wB[PB];
+        bool pw_active;
+        const int pw = payload_word<DIRECT>(lane, c.K, nwords, pw_active);
+#pragma unroll
+        for (int p = 0; p < PB; ++p) {
+            int sA = SLOT_NONE, sB = SLOT_NONE;
+            if (p < nbat) {
+                const uint32_t pr = ref_row(bcast64(myref, p));
+                const uint32_t lA = min(A, pr), hA = max(A, pr), lB = min(B, pr), hB = max(B, pr);
+                const unsigned long long want = second ? pack_pair(lB, hB) : pack_pair(lA, hA);
+                const unsigned long long hit = __ballot(probing && kk[p] == want), emp = __ballot(probing && kk[p] == KEY_EMPTY);
+                const unsigned long long m0 = 0xFFFFull, m1 = 0xFFFF0000ull;
+                if (hit & m0)
+                    sA = __builtin_amdgcn_readlane((int)hb[p], 0) + (__ffsll((long long)(hit & m0)) - 1);
+                else if (!(emp & m0))
+                    sA = SLOT_SLOW;
+                if (!same) {
+                    if (hit & m1)
+                        sB = __builtin_amdgcn_readlane((int)hb[p], BUCKET) + (__ffsll((long long)(hit & m1)) - 1 - (int)BUCKET);
+                    else if (!(emp & m1))
+                        sB = SLOT_SLOW;
+                }
+            }
+            wA[p] = (sA >= 0 && pw_active) ? reinterpret_cast<const DA_GLOBAL uint32_t *>(blk_ptr(c, sA))[pw] : 0u;
+            wB[p] = (sB >= 0 && pw_active) ? reinterpret_cast<const DA_GLOBAL uint32_t *>(blk_ptr(c, sB))[pw] : 0u;
+            if (lane == 0) {
+                wslot[2 * p] = sA;
+                wslot[2 * p + 1] = sB;
+            }
+        }
+        UPD_TIMER_MARK(1)  // references + lists + table probes
+        lds_fence();  // counters zero, references and slots readable
+        // ---- digit pairs lost with A's / B's consumed digits and gained with the new row, into the per-partner LDS counters.
+        // All partners of the batch at once: a lane holds (at most) one entry of every partner; it walks the entries of
+        // its own that lie in a substituted column (a bit mask), so the loop runs max-over-lanes(matched entries) times --
+        // two or three -- instead of once per partner with a handful of lanes active.
+        auto pairs_of = [&](int p, Cell x, int at) {  // per-lane p: everything about the partner comes from LDS
+            const Cell ma = s_mA[at - 1], mb = s_mB[at - 1];
+            const uint32_t pr = ref_row(wref[p]);
+            const int sA = wslot[2 * p], sB = wslot[2 * p + 1];
+            uint32_t *dA = wcnt + (size_t)p * 3 * Kpad, *dB = dA + Kpad, *cN = dB + Kpad;
+            if (sA != SLOT_NONE) {
                 for_pairs_part<Cell>(ma, x, A < pr, nb, [&](int k) { atomicAdd(&dA[k], 1u); });
                 if (same) for_pairs_part<Cell>(mb, x, A < pr, nb, [&](int k) { atomicAdd(&dA[k], 1u); });
             }
-            if (!same && slotB >= 0) for_pairs_part<Cell>(mb, x, B < pr, nb, [&](int k) { atomicAdd(&dB[k], 1u); });
-            for_pairs_cross<Cell>(x, ma, nb, [&](int k) { got_new |= atomicAdd(&cN[k], 1u) >= 1u; });
+            if (!same && sB != SLOT_NONE) for_pairs_part<Cell>(mb, x, B < pr, nb, [&](int k) { atomicAdd(&dB[k], 1u); });
+            for_pairs_cross<Cell>(x, ma, nb, [&](int k) { atomicAdd(&cN[k], 1u); });  // no return value: nothing waits for it
+        };
+        unsigned mine_mask = 0;  // bit p: this lane's entry of partner p lies in a substituted column
+#pragma unroll
+        for (int p = 0; p < PB; ++p)
+            if (F::cell(e[p]) && s_cmap[F::col(e[p])]) mine_mask |= 1u << p;
+        while (__any(mine_mask != 0)) {
+            if (mine_mask) {
+                const int p = __ffs((int)mine_mask) - 1;
+                mine_mask &= mine_mask - 1;
+                Entry en = e[0];
+#pragma unroll
+                for (int q = 1; q < PB; ++q) en = p == q ? e[q] : en;
+                pairs_of(p, F::cell(en), (int)s_cmap[F::col(en)]);
+            }
+        }
+        // rows with more than 64 entries (created by the early, wide substitutions) / more than 64 substituted columns
+        // of a dense input row: the rest of the list, one partner at a time
+        unsigned gotnew = 0, slow = 0;
+        for (int p = 0; p < nbat; ++p) {
+            const unsigned long long ref = uniform64(wref[p]);
+            const bool dense = (int)ref_row(ref) < n_in;
+            const int cnt = dense ? m : (int)ref_len(ref);
+            const int sA = __builtin_amdgcn_readfirstlane(wslot[2 * p]), sB = __builtin_amdgcn_readfirstlane(wslot[2 * p + 1]);
+            if (sA == SLOT_SLOW || sB == SLOT_SLOW) slow |= 1u << p;
+            if (cnt <= WAVE) continue;
+            const DA_GLOBAL Entry *rowR = rl + (size_t)ref_off(ref);
+            for (int j = WAVE + lane; j < cnt; j += WAVE) {
+                const Entry en = rowR[dense ? s_col[j] : j];
+                const Cell x = F::cell(en);
+                if (!x) continue;
+                const int at = (int)s_cmap[F::col(en)];
+                if (at) pairs_of(p, x, at);
+            }
         }
         lds_fence();
-        UPD_TIMER_MARK(2)  // list + pair enumeration
-        if (slotA >= 0 || slotB >= 0) table_update_pair(c, slotA, keyA, dA, slotB, keyB, dB);
-        found += (slotA >= 0) + (slotB >= 0);
-        UPD_TIMER_MARK(3)  // block updates
-        if (__any(got_new)) {
-            table_insert(c, pr, Nw, load_row(c.rows, pr), rnew, [&](int k) { return cN[k]; });
-            ++inserts;
+        // a block (partner, new row) is created when one of its counts reached 2: one scan of the counters per partner
+#pragma unroll
+        for (int p = 0; p < PB; ++p) {
+            if (p < nbat) {
+                const uint32_t *cN = wcnt + ((size_t)p * 3 + 2) * Kpad;
+                int f = 0;
+                for (int k = lane; k < c.K; k += WAVE) f |= cN[k] >= 2u;
+                if (__any(f)) gotnew |= 1u << p;
+            }
         }
-        UPD_TIMER_MARK(4)  // block creation
-        pref = prefn;
-        e0 = e0n;
-        kk = kkn;
+        UPD_TIMER_MARK(2)  // pair enumeration
+        // ---- re-evaluate the blocks from their prefetched payload lines.  A plain loop (the body is emitted once: the
+        // unrolled form was 12 k instructions); the partner's payload words are picked from the register arrays by
+        // a select chain on the (uniform) loop index.
+        for (int p = 0; p < nbat; ++p) {
+            const int sA = __builtin_amdgcn_readfirstlane(wslot[2 * p]), sB = __builtin_amdgcn_readfirstlane(wslot[2 * p + 1]);
+            if (sA < 0 && sB < 0) continue;
+            uint32_t pa = wA[0], pb = wB[0];
+#pragma unroll
+            for (int q = 1; q < PB; ++q) {
+                pa = p == q ? wA[q] : pa;
+                pb = p == q ? wB[q] : pb;
+            }
+            const uint32_t pr = ref_row(uniform64(wref[p]));
+            const uint32_t *dA = wcnt + (size_t)p * 3 * Kpad, *dB = dA + Kpad;
+            if (sA >= 0) apply_block<DIRECT>(c, sA, pack_pair(min(A, pr), max(A, pr)), pa, dA);
+            if (sB >= 0) apply_block<DIRECT>(c, sB, pack_pair(min(B, pr), max(B, pr)), pb, dB);
+            found += (sA >= 0) + (sB >= 0);
+        }
+        UPD_TIMER_MARK(3)  // block updates
+        // ---- rare: blocks beyond their first bucket, block creation (one partner at a time, state from LDS)
+        if (slow | gotnew) {
+            for (int p = 0; p < nbat; ++p) {
+                if (!(((slow | gotnew) >> p) & 1u)) continue;
+                const uint32_t pr = ref_row(uniform64(wref[p]));
+                const uint32_t *dA = wcnt + (size_t)p * 3 * Kpad, *dB = dA + Kpad, *cN = dB + Kpad;
+                if (__builtin_amdgcn_readfirstlane(wslot[2 * p]) == SLOT_SLOW) {
+                    const uint32_t lo = min(A, pr), hi = max(A, pr);
+                    const int slot = table_find_from(c, pack_pair(lo, hi), hash_pair(lo, hi), 1);
+                    if (slot >= 0) {
+                        table_update(c, slot, pack_pair(lo, hi), [&](int k, uint32_t old) { return old - dA[k]; });
+                        ++found;
+                    }
+                }
+                if (__builtin_amdgcn_readfirstlane(wslot[2 * p + 1]) == SLOT_SLOW) {
+                    const uint32_t lo = min(B, pr), hi = max(B, pr);
+                    const int slot = table_find_from(c, pack_pair(lo, hi), hash_pair(lo, hi), 1);
+                    if (slot >= 0) {
+                        table_update(c, slot, pack_pair(lo, hi), [&](int k, uint32_t old) { return old - dB[k]; });
+                        ++found;
+                    }
+                }
+                if ((gotnew >> p) & 1u) {
+                    table_insert(c, pr, Nw, load_row(c.rows, pr), rnew, [&](int k) { return cN[k]; });
+                    ++inserts;
+                }
+            }
+        }
+        UPD_TIMER_MARK(4)  // slow path + block creation
+        lds_fence();  // the next batch overwrites the per-wave LDS state
     }
     UPD_TIMER_FLUSH
     if (lane == 0 && partners) {
@@ -1438,7 +1589,8 @@ struct HipBackend::Impl {
     hipStream_t lanes[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // greedy-loop streams of the chain groups
     int n_lanes = 3;  // + the poll stream = 4 hardware queues
     bool use_graph = false;
-    int upd_total_blocks = 2048;  // k_iter_update blocks over all chains of a batch (4 waves each)
+    int upd_total_blocks = 4096;  // k_iter_update blocks over all chains of a batch (4 waves each): 64 per chain at batch 64, i.e. a
+                                  // wave's share of <= 2048 partner rows fits one batch of UPD_BATCH
     bool mt_launch = false;
     DeviceBuffer arena, desc_buf, io_buf;
     unsigned int *d_done = nullptr;
@@ -1706,14 +1858,14 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
         size_t s = no * entb + 6 * (size_t)geo[i].Kpad * 4 + (3 * no + 1) * 4 + claim_bytes;
         s = align_up(s, 16);
         sel_lds[w] = std::max(sel_lds[w], s);
-        upd_lds[w] = std::max(upd_lds[w], align_up(2 * no * cellb + (size_t)UPD_WAVES * 3 * geo[i].Kpad * 4 + no * 2, 16));
+        upd_lds[w] = std::max(upd_lds[w], align_up((size_t)UPD_WAVES * UPD_BATCH * (8 + 3 * (size_t)geo[i].Kpad * 4 + 8) + 2 * no * cellb + no * 6, 16));
         pair_lds[w] = std::max(pair_lds[w], (size_t)4 * geo[i].Kpad * 4);
         max_pairs[w] = std::max(max_pairs[w], (long long)jobs[i].n_in * (jobs[i].n_in + 1) / 2);
     }
     for (int w = 0; w < 2; ++w) {
         int cnt = ranges[w].count;
         if (cnt == 0) continue;
-        // keep the whole chip busy: ~4 blocks per CU in total, at least 2 and at most 32 per chain
+        // at least 2 and at most 64 blocks per chain
         upd_blocks[w] = std::max(2, std::min(64, (im.upd_total_blocks + cnt - 1) / std::max(cnt, 1)));
     }
     for (int w = 0; w < 2; ++w) {

@@ -1,0 +1,91 @@
+// cmvm_shard.cc -- orchestration of a column-sharded greedy chain (see cmvm_shard.h).  Engine-agnostic: the HIP engine
+// (cmvm_shard_gpu.hip) in the product, the sequential engine model in the CPU tests.
+
+#include "cmvm_shard.h"
+
+#include <algorithm>
+#include <numeric>
+
+namespace da {
+
+void ShardedBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
+    for (int i = 0; i < n; ++i) {
+        const ChainJob &j = jobs[i];
+        const bool shardable = comm_.world > 1 && j.n_out >= comm_.world && j.method >= 0 && j.method != M_DUMMY;
+        if (shardable)
+            run_one(j, outs[i]);
+        else
+            inner_.run_chains(&j, &outs[i], 1);  // replicated: every rank computes the same small chain
+    }
+}
+
+void ShardedBackend::run_one(const ChainJob &job, ChainOut &out) {
+    int c0, c1;
+    shard_columns(job.n_out, comm_.rank, comm_.world, c0, c1);
+    std::unique_ptr<ShardEngine> eng = make_(job, c0, c1, ctx_);
+    const bool dev = eng->on_device();
+    ++sharded_chains;
+
+    // initial pair counts: partial over the own columns, summed over the ranks
+    int64_t count = 0;
+    int32_t *buf = eng->init_counts(count);
+    comm_.sum(buf, count, dev);
+    eng->init_table();
+
+    // greedy loop: two exchanges per step
+    while (true) {
+        int32_t *flags = nullptr;
+        int64_t fcount = 0;
+        if (!eng->select(flags, fcount)) break;  // identical decision on every rank: the table is replicated
+        comm_.sum(flags, fcount, dev);
+        int64_t scount = 0;
+        int32_t *slab = eng->partial(scount);
+        comm_.sum(slab, scount, dev);
+        eng->apply();
+        ++sharded_steps;
+    }
+
+    // merge: everything row-related is already global; the surviving digits of the other ranks' columns come in by
+    // all-reduce(sum) of buffers in which every rank fills its own segment
+    ChainOut own;
+    eng->finish(own);
+    out = ChainOut{};
+    out.error = own.error;
+    out.unknown_method_hit = own.unknown_method_hit;
+    out.n_bits = own.n_bits;
+    out.shift0 = own.shift0;
+    out.shift1 = own.shift1;
+    out.picks = own.picks;
+    out.row_lat = own.row_lat;
+    out.stats = own.stats;
+    const int n_out = job.n_out;
+    std::vector<int32_t> cnt((size_t)n_out + 1, 0);
+    for (int j = c0; j < c1; ++j) cnt[j] = (int32_t)(own.col_start[j - c0 + 1] - own.col_start[j - c0]);
+    cnt[n_out] = own.error;  // any rank's capacity error fails the chain everywhere
+    comm_.sum(cnt.data(), (int64_t)cnt.size(), false);
+    if (cnt[n_out] != 0 && out.error == E_OK) out.error = own.error ? own.error : E_TABLE_CAPACITY;
+    out.col_start.assign((size_t)n_out + 1, 0);
+    for (int j = 0; j < n_out; ++j) out.col_start[j + 1] = out.col_start[j] + (uint32_t)cnt[j];
+    const size_t total = out.col_start[n_out];
+    std::vector<int32_t> dig(3 * total, 0);  // row | low half of the cell | high half
+    const size_t first = out.col_start[c0];
+    for (size_t k = 0; k < own.dig_row.size(); ++k) {
+        dig[first + k] = (int32_t)own.dig_row[k];
+        dig[total + first + k] = (int32_t)(uint32_t)own.dig_cell[k];
+        dig[2 * total + first + k] = (int32_t)(uint32_t)(own.dig_cell[k] >> 32);
+    }
+    comm_.sum(dig.data(), (int64_t)dig.size(), false);
+    out.dig_row.resize(total);
+    out.dig_cell.resize(total);
+    for (size_t k = 0; k < total; ++k) {
+        out.dig_row[k] = (uint32_t)dig[k];
+        out.dig_cell[k] = (uint64_t)(uint32_t)dig[total + k] | ((uint64_t)(uint32_t)dig[2 * total + k] << 32);
+    }
+    // statistics that are per-column sums
+    int32_t st[2] = {(int32_t)std::min<int64_t>(own.stats.matches, INT32_MAX), (int32_t)std::min<int64_t>(own.stats.digits0, INT32_MAX)};
+    comm_.sum(st, 2, false);
+    out.stats.matches = st[0];
+    out.stats.digits0 = st[1];
+}
+
+}  // namespace da

@@ -259,3 +259,78 @@ def solve_candidates_sharded(kernel, method0: str = 'wmc', method1: str = 'auto'
     box = [mine.get(best)]
     dist.broadcast_object_list(box, src=best % world)
     return box[0]
+
+
+# ------------------------------------------------------------------------------------------------ column-sharded chains
+class _DeviceView:
+    """int32 view of ``count`` words of device memory owned by the HIP library, for ``torch.as_tensor`` (zero copy)."""
+
+    def __init__(self, ptr: int, count: int):
+        self.__cuda_array_interface__ = {'shape': (int(count),), 'typestr': '<i4', 'data': (int(ptr), False), 'version': 2}
+
+
+def make_allreduce_callback(device):
+    """C callback ``void(ctx, buf, count, on_device)`` = in-place all-reduce(sum) of int32 over the process group: the one
+    collective a column-sharded chain uses (``csrc/cmvm_shard.h``).  RCCL (backend ``nccl``) works on device memory
+    directly; with ``gloo`` (CPU tests, or several ranks sharing one GPU) device buffers are staged through the host.
+    Returns (callback object -- keep it alive during the solve --, list collecting exceptions raised inside it)."""
+    import ctypes as C
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_int64, C.c_int)
+    nccl = dist.is_initialized() and dist.get_backend() == 'nccl'
+    errors: list[BaseException] = []
+
+    def allreduce(ctx, buf, count, on_device):
+        try:
+            if on_device:
+                t = torch.as_tensor(_DeviceView(buf, count), device=device)
+                if nccl:
+                    dist.all_reduce(t)
+                else:
+                    h = t.cpu()
+                    dist.all_reduce(h)
+                    t.copy_(h)
+                torch.cuda.synchronize(device)
+            else:
+                t = torch.from_numpy(np.ctypeslib.as_array((C.c_int32 * count).from_address(buf)))
+                if nccl:
+                    d = t.to(device)
+                    dist.all_reduce(d)
+                    t.copy_(d.cpu())
+                else:
+                    dist.all_reduce(t)
+        except BaseException as e:  # an exception must not unwind through the C caller
+            errors.append(e)
+
+    return FN(allreduce), errors
+
+
+def solve_column_sharded(kernel, method0: str = 'wmc', method1: str = 'auto', hard_dc: int = -1, decompose_dc: int = -2, qintervals=None,
+                         latencies=None, adder_size: int = -1, carry_size: int = -1, search_all_decompose_dc: bool = True, sharded_solver=None,
+                         return_stats: bool = False):  # fmt: skip
+    """One ``solve`` whose greedy chains are sharded over the output COLUMNS of their matrices (BASELINE config C4,
+    SURVEY.md section 8e(2); ``csrc/cmvm_shard.h``): rank g holds the digits of columns [g n_out / W, (g+1) n_out / W), the
+    pair table is replicated, every greedy step exchanges two all-reduce(sum) slabs (RCCL over xGMI on GPUs).  Every rank
+    calls this with the same arguments and gets the same Pipeline, identical to the single-process ``solve``.
+
+    Bound by the latency of ~2 collectives per greedy step (4 10^4 per 256x256 chain): it does not scale; the layout that
+    does is ``solve_many_sharded``.  ``sharded_solver`` defaults to the HIP engine (``_binary.solve_sharded``); the CPU
+    tests inject the sequential engine model."""
+    rank, world, local, device = init()
+    if sharded_solver is None:
+        from . import _binary
+
+        if _binary.device_count() > 0:
+            _binary.set_device(local % _binary.device_count())
+        sharded_solver = _binary.solve_sharded
+    cb, errors = make_allreduce_callback(device)
+    pipe, stats = sharded_solver(kernel, method0=method0, method1=method1, hard_dc=hard_dc, decompose_dc=decompose_dc, qintervals=qintervals,
+                                 latencies=latencies, adder_size=adder_size, carry_size=carry_size, search_all_decompose_dc=search_all_decompose_dc,
+                                 rank=rank, world=world, allreduce=cb)  # fmt: skip
+    if errors:
+        raise errors[0]
+    return (pipe, stats) if return_stats else pipe

@@ -57,6 +57,15 @@ def solve_worker(job):
     return dt, p.cost, [len(s.ops) for s in p.solutions]
 
 
+def problem_worker(job):
+    """one complete solve of an explicit problem: (kind, kernel, opts incl. qintervals / latencies) -> (seconds, cost)"""
+    kind, kernel, opts = job
+    o = _oracle(kind)
+    t = time.perf_counter()
+    p = o.solve(kernel, **opts)
+    return time.perf_counter() - t, p.cost
+
+
 def run_pool(fn, jobs, workers):
     """map ``fn`` over ``jobs`` on ``workers`` spawned processes; returns (results in job order, wall seconds of the map)"""
     import multiprocessing as mp

@@ -188,6 +188,25 @@ class Oracle:
             raise RuntimeError(self.g('last_error')().decode())
         return [self._collect(res[i]) for i in range(n)]
 
+    def solve_sharded(self, kernel, method0='wmc', method1='auto', hard_dc=-1, decompose_dc=-2, qintervals=None, latencies=None,
+                      adder_size=-1, carry_size=-1, search_all_decompose_dc=True, rank=0, world=1, allreduce=None):  # fmt: skip
+        """Column-sharded solve through the PRODUCT's orchestration (csrc/cmvm_shard.cc) on the sequential engine model;
+        'model' only.  ``allreduce``: ctypes callback from da4ml_amd.multi_gpu.make_allreduce_callback.  Returns
+        (Pipeline, {sharded_chains, greedy_steps, allreduce_calls})."""
+        assert self.kind == 'model'
+        k = np.ascontiguousarray(kernel, dtype=np.float32)
+        n_in, n_out = k.shape
+        q, l = self._opt(qintervals, latencies, n_in)
+        fn = self.lib.mdl_solve_sharded
+        fn.restype = C.c_void_p
+        fn.argtypes = [_f32p, C.c_int64, C.c_int64, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                       C.c_int, C.c_int, C.c_void_p, C.c_void_p, _i64p]  # fmt: skip
+        st = np.zeros(3, np.int64)
+        h = fn(k, n_in, n_out, method0.encode(), method1.encode(), hard_dc, decompose_dc, None if q is None else q.ctypes.data,
+               None if l is None else l.ctypes.data, adder_size, carry_size, int(search_all_decompose_dc), rank, world,
+               C.cast(allreduce, C.c_void_p), None, st)  # fmt: skip
+        return self._collect(h), dict(zip(('sharded_chains', 'greedy_steps', 'allreduce_calls'), st.tolist()))
+
     def chains_run(self, reset=True) -> int:
         """Chains handed to the model backend since the last reset ('model' only)."""
         self.lib.mdl_chains_run.restype = C.c_longlong

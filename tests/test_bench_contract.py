@@ -34,7 +34,16 @@ def test_committed_bench_line_has_the_contract_fields():
     for key in ('value', 'unit', 'cores', 'kind', 'sample'):
         assert key in c, key
     assert c['kind'] in ('reference', 'port') and c['cores'] >= 1 and c['unit'] == line['unit']
-    assert line['check']['adders_match_oracle'] is True
+    chk = line['check']
+    if 'verify' in chk:  # round 2 on: every result of the last step replayed, digests of the first seeds against the oracle records
+        v = chk['verify']
+        assert v['all_ok'] is True and v['kernel_reproduced'] == v['of'] == line['config']['batch_per_gpu']
+        assert len(v['digests_vs_oracle']) >= 4 and all(d['match'] for d in v['digests_vs_oracle'].values())
+        assert c['cores'] > 1 or c.get('host_cores', 1) == 1  # all host cores, not one
+        assert 'extrapolated' in c and c['measured_64x64']['value'] > 0
+        assert r['valu'] is None or 0 < r['valu']['frac'] < 1
+    else:
+        assert chk['adders_match_oracle'] is True
 
 
 def test_pmc_traffic_helper_reads_the_committed_passes():
@@ -46,6 +55,8 @@ def test_pmc_traffic_helper_reads_the_committed_passes():
     r = _last_bench_line()['roofline']
     # within 1 %: the PMC passes were collected once more after the committed bench line was produced
     assert abs(per_chain * r['chains_per_launch'] - r['traffic']) < 1e-2 * r['traffic']
+    insts = bench.pmc_per_dispatch('SQ_INSTS_VALU')
+    assert insts and insts[0] > 0 and insts[1] >= 1
     assert 'c3_256x256_int8_batch64_single_chain' in bench.WORKLOADS and bench.WORKLOADS['c3_256x256_int8_batch64_single_chain'][:3] == (256, 256, 64)
     ks = bench.make_batch(4, 3, 2, first_seed=5)
     assert len(ks) == 2 and ks[0].shape == (4, 3) and ks[0].dtype.name == 'float32' and abs(ks[0]).max() <= 128
@@ -60,3 +71,63 @@ def test_bench_needs_a_gpu():
         pytest.skip('a GPU is present')
     r = subprocess.run([sys.executable, str(ROOT / 'bench.py'), '--steps', '1', '--warmup', '0'], capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and 'needs a HIP device' in (r.stdout + r.stderr)
+
+
+def test_replay_used_by_the_bench_verification(oracle):
+    """bench.py verifies all results of the timed batch with its own replay of the C arrays: it reproduces the matrix of
+    oracle results (both stages), and notices a corrupted statement"""
+    sys.path.insert(0, str(ROOT))
+    import numpy as np
+
+    import bench
+    from cases import int_matrix
+
+    def arrays(sol):
+        ops_i = np.asarray([[op.id0, op.id1, op.opcode, op.data] for op in sol.ops], dtype=np.int64).reshape(-1, 4)
+        return sol.shape[0], np.asarray(sol.inp_shifts, np.int64), np.asarray(sol.out_idxs, np.int64), np.asarray(sol.out_shifts, np.int64), np.asarray(sol.out_negs, np.int64), ops_i
+
+    for seed, opts in ((3, {}), (4, dict(method0='wmc', method1='wmc', decompose_dc=-1, search_all_decompose_dc=False)), (5, dict(decompose_dc=1))):
+        k = int_matrix(seed, 14, 11, -64, 64)
+        p = oracle.solve(k, **opts)
+        m0, m1 = (bench.replay_stage(*arrays(s)) for s in p.solutions)
+        assert np.array_equal(m0 @ m1, k.astype(np.float64))
+        a = list(arrays(p.solutions[0]))
+        adders = np.nonzero(a[5][:, 2] >= 0)[0]
+        if len(adders):
+            a[5][adders[-1], 3] += 1  # one wrong shift
+            assert not np.array_equal(bench.replay_stage(*a) @ m1, k.astype(np.float64))
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` started directly (no torchrun environment) spawns the two ranks itself; here with the
+    launcher self-test (gloo on this CPU host, nccl on a GPU host): rank 0 reports n_gpus 2 and the reduced values"""
+    r = subprocess.run([sys.executable, str(ROOT / 'bench.py'), '--gpus', '2', '--selftest-launcher'], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+    assert line['n_gpus'] == 2 and line['max_elapsed'] == 2.0 and line['total_solves'] == 128.0
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    from da4ml_amd import _binary
+
+    if _binary.device_count() >= 2:
+        import pytest
+
+        pytest.skip('two GPUs are present')
+    r = subprocess.run([sys.executable, str(ROOT / 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'], capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and 'HIP device' in (r.stdout + r.stderr)
+
+
+def test_cpu_pool_times_complete_solves():
+    """the process pool behind cpu_baseline: spawned single-threaded workers, results in job order, identical to a direct call"""
+    from oracle import cpu_pool
+    from oracle.oracle import Oracle
+
+    jobs = [('port', 12, 9, seed, dict(adder_size=1, carry_size=-1)) for seed in range(3)]
+    out, wall = cpu_pool.run_pool(cpu_pool.solve_worker, jobs, 2)
+    assert wall > 0 and len(out) == 3
+    for (dt, cost, n_ops), job in zip(out, jobs):
+        p = Oracle('port').solve(cpu_pool._matrix(12, 9, job[3]), **job[4])
+        assert dt > 0 and cost == p.cost and n_ops == [len(s.ops) for s in p.solutions]
+    s, _ = cpu_pool.run_pool(cpu_pool.sample_worker, [('port', 16, 16, 0, 'wmc', 5.0)], 1)
+    assert s[0]['finished'] and s[0]['iterations'] > 0

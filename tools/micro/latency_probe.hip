@@ -1,0 +1,51 @@
+// Dependent-load latency of random 128-byte lines vs footprint and vs the number of chasing waves (MI355X).
+// Decides whether the greedy loop's round trips are stretched by address translation / footprint or by queueing.
+//   hipcc --offload-arch=gfx950 -O3 -o latency_probe latency_probe.hip && ./latency_probe
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s\n", hipGetErrorString(e), #x); exit(1); } } while (0)
+
+// every wave chases its own pseudo-random sequence of lines: next = hash(value read); all 64 lanes read one line
+__global__ void chase(const unsigned long long *buf, unsigned long long n_lines, int steps, unsigned long long *out, long long *cycles) {
+    const int lane = threadIdx.x & 63;
+    unsigned long long gw = (blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64);
+    unsigned long long x = gw * 0x9E3779B97F4A7C15ull + 12345;
+    long long t0 = wall_clock64();
+    for (int s = 0; s < steps; ++s) {
+        x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 29;
+        unsigned long long line = x % n_lines;
+        unsigned long long v = buf[line * 16 + (lane & 15)];
+        x += v;  // dependent
+    }
+    long long t1 = wall_clock64();
+    if (lane == 0) { out[gw] = x; cycles[gw] = t1 - t0; }
+}
+int main() {
+    const size_t GB = 1ull << 30;
+    size_t max_bytes = 48 * GB;
+    unsigned long long *buf;
+    CK(hipMalloc(&buf, max_bytes));
+    CK(hipMemset(buf, 0, max_bytes));
+    unsigned long long *out; long long *cyc;
+    CK(hipMalloc(&out, 8 << 20)); CK(hipMalloc(&cyc, 8 << 20));
+    int rate = 0; CK(hipDeviceGetAttribute(&rate, hipDeviceAttributeWallClockRate, 0));  // kHz
+    printf("wall clock %d kHz\n", rate);
+    const int steps = 2000;
+    for (double gb : {0.25, 1.0, 4.0, 8.0, 16.0, 32.0, 48.0}) {
+        unsigned long long n_lines = (unsigned long long)(gb * GB) / 128;
+        for (int waves_per_cu : {1, 8, 24}) {
+            int blocks = 256 * waves_per_cu / 4;
+            if (blocks < 1) blocks = 1;
+            hipLaunchKernelGGL(chase, dim3(blocks), dim3(256), 0, 0, buf, n_lines, steps, out, cyc);
+            CK(hipDeviceSynchronize());
+            std::vector<long long> h(blocks * 4);
+            CK(hipMemcpy(h.data(), cyc, h.size() * 8, hipMemcpyDeviceToHost));
+            double s = 0; for (auto v : h) s += v;
+            double ns = s / h.size() / steps * 1e6 / rate;
+            printf("footprint %6.2f GB  waves/CU %2d : %7.1f ns per dependent random line load  (%.0f GB/s aggregate)\n", gb, waves_per_cu, ns, (double)h.size() * 128 / ns);
+        }
+    }
+    return 0;
+}
