@@ -27,7 +27,7 @@ _i32p = np.ctypeslib.ndpointer(np.int32, flags='C_CONTIGUOUS')
 
 EXPORTS = (
     'da_last_error da_last_error_code da_version da_device_count da_set_device da_get_lsb_loc da_iceil_log2 da_cost_add da_int_arr_to_csd '
-    'da_csd_decompose da_kernel_decompose da_solve da_solve_batch da_n_stages da_picked da_stage_info da_stage_copy '
+    'da_csd_decompose da_kernel_decompose da_solve da_solve_batch da_solve_sharded da_n_stages da_picked da_stage_info da_stage_copy '
     'da_result_stats da_free da_timings da_dais_run da_dais_last_error da_dais_run_on'
 ).split()
 
@@ -77,6 +77,9 @@ def lib():
     L.da_solve.restype = C.c_void_p
     L.da_solve.argtypes = [_f32p, C.c_int64, C.c_int64, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
     L.da_solve_batch.argtypes = [C.c_int, C.c_void_p, _i64p, _i64p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]  # fmt: skip
+    L.da_solve_sharded.restype = C.c_void_p
+    L.da_solve_sharded.argtypes = [_f32p, C.c_int64, C.c_int64, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                   C.c_int, C.c_int, C.c_void_p, C.c_void_p, _i64p]  # fmt: skip
     L.da_n_stages.argtypes = [C.c_void_p]
     L.da_picked.argtypes = [C.c_void_p]
     L.da_stage_info.argtypes = [C.c_void_p, C.c_int, _i64p]
@@ -224,6 +227,25 @@ def solve(
     if not h:
         _raise(lib().da_last_error_code())
     return _collect(h, _stats)
+
+
+def solve_sharded(kernel, method0: str = 'wmc', method1: str = 'auto', hard_dc: int = -1, decompose_dc: int = -2, qintervals=None, latencies=None,
+                  adder_size: int = -1, carry_size: int = -1, search_all_decompose_dc: bool = True, rank: int = 0, world: int = 1, allreduce=None):  # fmt: skip
+    """``solve`` with every greedy chain sharded over the output columns of its matrix across ``world`` processes
+    (``da_solve_sharded``, include/da4ml_hip.h).  ``allreduce``: ctypes callback ``void(ctx, buf, count, on_device)``, see
+    ``da4ml_amd.multi_gpu.solve_column_sharded`` (the user-facing entry).  Returns (Pipeline, exchange statistics)."""
+    k = _kernel(kernel)
+    if k.ndim != 2:
+        raise RuntimeError('csd_decompose only supports 2D arrays.')
+    n_in, n_out = k.shape
+    q, l = _opt_arrays(qintervals, latencies, n_in)
+    st = np.zeros(3, np.int64)
+    h = lib().da_solve_sharded(k, n_in, n_out, method0.encode(), method1.encode(), int(hard_dc), int(decompose_dc),
+                               None if q is None else q.ctypes.data, None if l is None else l.ctypes.data, int(adder_size), int(carry_size),
+                               int(bool(search_all_decompose_dc)), int(rank), int(world), C.cast(allreduce, C.c_void_p) if allreduce is not None else None, None, st)  # fmt: skip
+    if not h:
+        _raise(lib().da_last_error_code())
+    return _collect(h), dict(zip(('sharded_chains', 'greedy_steps', 'allreduce_calls'), st.tolist()))
 
 
 def solve_many(

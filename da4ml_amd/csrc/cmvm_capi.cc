@@ -2,6 +2,7 @@
 // Every compute entry point goes through the HIP backend; there is no CPU fallback: without a usable
 // device the calls fail with DA_ERR_NO_DEVICE / NULL and a message.
 
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -11,6 +12,7 @@
 #include "../../include/da4ml_hip.h"
 #include "cmvm_gpu.h"
 #include "cmvm_host.h"
+#include "cmvm_shard.h"
 
 namespace {
 
@@ -166,6 +168,56 @@ da_result *da_solve(const float *kernel, int64_t n_in, int64_t n_out, const char
     int rc = da_solve_batch(1, &kernel, &n_in, &n_out, method0, method1, hard_dc, decompose_dc, qintervals ? q : nullptr,
                             latencies ? l : nullptr, adder_size, carry_size, search_all_decompose_dc, &r);
     return rc == DA_OK ? r : nullptr;
+}
+
+static std::unique_ptr<da::ShardEngine> make_hip_shard(const da::ChainJob &job, int c0, int c1, void *ctx) {
+    return static_cast<da::gpu::HipBackend *>(ctx)->make_shard_engine(job, c0, c1);
+}
+
+da_result *da_solve_sharded(const float *kernel, int64_t n_in, int64_t n_out, const char *method0, const char *method1, int hard_dc,
+                            int decompose_dc, const float *qintervals, const float *latencies, int adder_size, int carry_size,
+                            int search_all_decompose_dc, int rank, int world, da_allreduce_i32 allreduce, void *ctx, int64_t *stats3) {
+    std::lock_guard<std::mutex> lk(g_mutex);
+    try {
+        if (world < 1 || rank < 0 || rank >= world) throw std::invalid_argument("rank must be in [0, world)");
+        if (world > 255) throw std::invalid_argument("at most 255 ranks (8-bit flag fields)");
+        if (world > 1 && !allreduce) throw std::invalid_argument("an all-reduce callback must be given for world > 1");
+        if (n_in <= 0 || n_out <= 0) throw std::invalid_argument("kernel must be a non-empty 2-D matrix");
+        da::Problem p;
+        p.kernel = kernel;
+        p.n_in = (int)n_in;
+        p.n_out = (int)n_out;
+        p.opt.method0 = method0;
+        p.opt.method1 = method1;
+        p.opt.hard_dc = hard_dc;
+        p.opt.decompose_dc = decompose_dc;
+        check_dyadic_steps(qintervals, p.n_in);
+        if (qintervals)
+            for (int r = 0; r < p.n_in; ++r) p.opt.qints.push_back(da::QInt{qintervals[3 * r], qintervals[3 * r + 1], qintervals[3 * r + 2]});
+        if (latencies) p.opt.lats.assign(latencies, latencies + p.n_in);
+        p.opt.adder_size = adder_size;
+        p.opt.carry_size = carry_size;
+        p.opt.search_all = search_all_decompose_dc != 0;
+        da::gpu::HipBackend &inner = backend();
+        da::ShardComm comm;
+        comm.rank = rank;
+        comm.world = world;
+        comm.allreduce = allreduce;
+        comm.ctx = ctx;
+        da::ShardedBackend be(inner, comm, make_hip_shard, &inner);
+        be.force_single = std::getenv("DA4ML_SHARD_FORCE") != nullptr;
+        std::vector<da::ChainStats> stats;
+        std::vector<da::PipeResult> res = da::solve_batch(be, {p}, &stats);
+        if (stats3) {
+            stats3[0] = be.sharded_chains;
+            stats3[1] = be.sharded_steps;
+            stats3[2] = be.comm().calls;
+        }
+        return new da_result{std::move(res[0]), stats.empty() ? da::ChainStats{} : stats[0]};
+    } catch (const std::exception &e) {
+        fail(e);
+        return nullptr;
+    }
 }
 
 int da_n_stages(const da_result *r) { return (int)r->pipe.stages.size(); }

@@ -197,6 +197,14 @@ struct ChainDev {
     unsigned long long *pk_cell;   // ... and their cells
     float *pk_lat;                 // [n_rows] latency of every row
     int pk_cap;
+    // column-sharded chains (cmvm_shard.h): the matrix handed to k_prepare has pn_out columns of which this chain holds
+    // [col0, col0 + n_out); exchange buffers of the greedy step.  Ordinary chains: pn_out == n_out, col0 == 0.
+    int pn_out, col0;
+    int32_t *cs_init;             // [n_pairs][K] partial initial pair counts (summed over the ranks in place)
+    int32_t *cs_flags;            // [(rcap + 3) / 4] 8-bit fields: row shares a substituted column
+    uint32_t *cs_uni;             // [rcap] union of the partner rows of all ranks, ascending
+    int cs_nuni;
+    int32_t *cs_slab;             // [(3 cs_nuni + 6)][K] partial / summed count changes
     // statistics
     unsigned long long st_rescans, st_partners, st_matches, st_found, st_inserts, st_cells;
     unsigned long long st_phase[12];  // shader-clock cycles per kernel phase (select: 0-6, update: 7-11)
@@ -454,7 +462,7 @@ __global__ void __launch_bounds__(256) k_prepare(ChainDev *chains) {
     __shared__ unsigned int s_max;
     __shared__ unsigned long long s_digits, s_pairs;
     __shared__ int s_maxd;
-    const int n_in = ch.n_in, n_out = ch.n_out;
+    const int n_in = ch.n_in, n_out = ch.pn_out;  // the whole matrix (a column-sharded chain holds a slice of it)
     const float *k = ch.kernel;
     if (threadIdx.x == 0) {
         s_max = 0;
@@ -525,7 +533,7 @@ template <class Cell> __global__ void __launch_bounds__(256) k_init_cells(ChainD
         if (i < ch.n_in) {
             bool dead = ch.qints[3 * i] == 0.0f && ch.qints[3 * i + 1] == 0.0f;
             uint32_t p, m;
-            naf_masks(ch.xint[(size_t)i * ch.n_out + j], p, m);
+            naf_masks(ch.xint[(size_t)i * ch.pn_out + ch.col0 + j], p, m);
             c = dead ? (Cell)0 : O::make(p, m);
             rl[(size_t)i * ch.n_out + j] = F::pack((uint32_t)j, c);  // dense row: entry j is column j, empty cells included
         }
@@ -600,7 +608,10 @@ template <class Cell> __global__ void __launch_bounds__(256) k_init_pairs(ChainD
 // of the chosen pair in the lists of rows A and B (the new row's list is their match set), (3) exact recount of the
 // pairs among the modified rows {A, B, new}, (4) the de-duplicated list of partner rows (rows sharing a substituted
 // column) for k_iter_update.
-template <class Cell> __global__ void __launch_bounds__(SEL_THREADS) k_iter_select(ChainDev *chains, unsigned int *n_done) {
+// SHARDED (column-sharded chain, cmvm_shard.h): the chain holds a slice of the columns and a replica of the pair table.
+// The arg-max and the substitution are the same; the counts of the pairs among {A, B, new} are only PARTIAL here and go to
+// the head of the exchange slab instead of the table, and instead of a partner list the kernel leaves one flag per row.
+template <class Cell, bool SHARDED = false> __global__ void __launch_bounds__(SEL_THREADS) k_iter_select(ChainDev *chains, unsigned int *n_done) {
     using O = CellOps<Cell>;
     using F = RowFmt<Cell>;
     using Entry = typename F::Entry;
@@ -979,6 +990,20 @@ template <class Cell> __global__ void __launch_bounds__(SEL_THREADS) k_iter_sele
         DA_GLOBAL unsigned long long *plist = (DA_GLOBAL unsigned long long *)g->plist;
         const uint32_t tag = (uint32_t)iter + 1u;
         constexpr int CLAIM_ILP = 8;  // independent list reads in flight per thread: one pass covers 5120 list entries
+        if constexpr (SHARDED) {  // flags only: the union over the ranks is formed after the exchange (k_cs_union)
+            for (int f = tid; f < total; f += CLAIM_THREADS) {
+                int lo = 0, hi = m;
+                while (hi - lo > 1) {
+                    int mid = (lo + hi) >> 1;
+                    if (s_len[mid] <= f)
+                        lo = mid;
+                    else
+                        hi = mid;
+                }
+                const uint32_t row = ref_row(collist[(size_t)s_col[lo] * lcap + (f - s_len[lo])]);
+                if (row != A && row != B) atomicOr(&s_bits[row >> 5], 1u << (row & 31));
+            }
+        } else
         for (int fb = wid * WAVE; fb < total; fb += CLAIM_ILP * CLAIM_THREADS) {  // wave-uniform trip count: all lanes stay active
             unsigned long long r[CLAIM_ILP];
             bool ok[CLAIM_ILP];
@@ -1035,7 +1060,10 @@ template <class Cell> __global__ void __launch_bounds__(SEL_THREADS) k_iter_sele
         case 4: lo = B, hi = Nw, active = !same; break;
         default: lo = Nw, hi = Nw; break;
         }
-        if (active) {
+        if constexpr (SHARDED) {  // partial counts of the six special pairs: head of the exchange slab, [6][K]
+            DA_GLOBAL int32_t *spec = (DA_GLOBAL int32_t *)g->cs_slab + (size_t)sp * c.K;
+            for (int k = lane; k < c.K; k += WAVE) spec[k] = active ? (int32_t)cnt[k] : 0;
+        } else if (active) {
             unsigned long long key = pack_pair(lo, hi);
             int slot = existed ? table_find(c, key, hash_pair(lo, hi)) : -1;
             if (slot >= 0)
@@ -1050,6 +1078,13 @@ template <class Cell> __global__ void __launch_bounds__(SEL_THREADS) k_iter_sele
     tp[6] = clock64();
     __syncthreads();
     tp[7] = clock64();
+    if constexpr (SHARDED) {  // claim bitmap -> 8-bit flag fields, four rows per word (summed over the ranks without carry)
+        DA_GLOBAL int32_t *flags = (DA_GLOBAL int32_t *)g->cs_flags;
+        for (int w = tid; w < (int)((Nw + 3) / 4); w += SEL_THREADS) {
+            const uint32_t b = (s_bits[w >> 3] >> ((w & 7) * 4)) & 0xFu;
+            flags[w] = (int32_t)((b & 1u) | ((b & 2u) << 7) | ((b & 4u) << 14) | ((b & 8u) << 21));
+        }
+    }
     if (tid == 0) {
         for (int q = 0; q < 7; ++q) g->st_phase[q] += (unsigned long long)(tp[q + 1] - tp[q]);
         rowoff[Nw] = da_u2{offN, (uint32_t)m};
@@ -1384,6 +1419,182 @@ __global__ void __launch_bounds__(UPD_THREADS, DA_UPD_OCC) __attribute__((amdgpu
     }
 }
 
+// ================================================================================= column-sharded chains (cmvm_shard.h)
+// The chain holds the digits of a slice of the columns and a replica of the pair table; counts are sums over columns,
+// exchanged between the ranks as int32 slabs (all-reduce(sum) between the kernels below, driven by cmvm_shard.cc).
+
+// grid (ceil(n_pairs / 4)): one wave per pair of input rows: partial counts over the own columns -> cs_init [n_pairs][K]
+template <class Cell> __global__ void __launch_bounds__(256) k_cs_init_counts(ChainDev *g) {
+    const Ctx c = make_ctx(g, 0);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t *cnt = reinterpret_cast<uint32_t *>(smem) + (size_t)wave_id() * c.Kpad;
+    const long long n_in = g->n_in, n_pairs = n_in * (n_in + 1) / 2;
+    const long long p = (long long)blockIdx.x * (blockDim.x / WAVE) + wave_id();
+    if (p >= n_pairs) return;
+    long long i1 = (long long)((sqrt(8.0 * (double)p + 1.0) - 1.0) * 0.5);
+    while (i1 * (i1 + 1) / 2 > p) --i1;
+    while ((i1 + 1) * (i1 + 2) / 2 <= p) ++i1;
+    const uint32_t hi = (uint32_t)i1, lo = (uint32_t)(p - i1 * (i1 + 1) / 2);
+    count_row_pair<Cell>(c, reinterpret_cast<const typename RowFmt<Cell>::Entry *>(g->rlist), lo, hi, cnt);
+    for (int k = lane_id(); k < c.K; k += WAVE) g->cs_init[(size_t)p * c.K + k] = (int32_t)cnt[k];
+}
+// same grid: the summed counts into the (replicated) table
+template <class Cell> __global__ void __launch_bounds__(256) k_cs_init_table(ChainDev *g) {
+    const Ctx c = make_ctx(g, 0);
+    const long long n_in = g->n_in, n_pairs = n_in * (n_in + 1) / 2;
+    const long long p = (long long)blockIdx.x * (blockDim.x / WAVE) + wave_id();
+    if (p >= n_pairs) return;
+    long long i1 = (long long)((sqrt(8.0 * (double)p + 1.0) - 1.0) * 0.5);
+    while (i1 * (i1 + 1) / 2 > p) --i1;
+    while ((i1 + 1) * (i1 + 2) / 2 <= p) ++i1;
+    const uint32_t hi = (uint32_t)i1, lo = (uint32_t)(p - i1 * (i1 + 1) / 2);
+    const int32_t *cnt = g->cs_init + (size_t)p * c.K;
+    int f = 0;
+    for (int k = lane_id(); k < c.K; k += WAVE) f |= cnt[k] >= 2;
+    if (!__any(f)) return;
+    if (c.method < 0) {  // unknown method string with a non-empty table: the reference throws here
+        if (lane_id() == 0) g->unknown_hit = 1;
+        return;
+    }
+    table_insert(c, lo, hi, load_row(c.rows, lo), load_row(c.rows, hi), [&](int k) { return (uint32_t)cnt[k]; });
+}
+
+// one block: union of the partner rows of all ranks (summed flag fields != 0), ascending row ids -> cs_uni, cs_nuni
+__global__ void __launch_bounds__(1024) k_cs_union(ChainDev *g) {
+    __shared__ int s_part[16], s_base[17];
+    const int tid = threadIdx.x, lane = lane_id(), wid = wave_id();
+    const int n_rows = (int)g->Nw;  // rows that existed before this step's new row
+    const int per = (n_rows + 1023) / 1024;
+    const int r0 = min(tid * per, n_rows), r1 = min(r0 + per, n_rows);
+    int mine = 0;
+    for (int r = r0; r < r1; ++r) mine += ((g->cs_flags[r >> 2] >> (8 * (r & 3))) & 0xFF) != 0;
+    int inc = mine;
+    for (int o = 1; o < WAVE; o <<= 1) {
+        int t = __shfl_up(inc, o);
+        if (lane >= o) inc += t;
+    }
+    if (lane == WAVE - 1) s_part[wid] = inc;
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int w = 0; w < 16; ++w) {
+            s_base[w] = run;
+            run += s_part[w];
+        }
+        s_base[16] = run;
+        g->cs_nuni = run;
+    }
+    __syncthreads();
+    int at = s_base[wid] + inc - mine;
+    for (int r = r0; r < r1; ++r)
+        if (((g->cs_flags[r >> 2] >> (8 * (r & 3))) & 0xFF) != 0) g->cs_uni[at++] = (uint32_t)r;
+}
+
+// grid (ceil(n_union / 4)): one wave per row of the union: this rank's partial count changes over its own substituted
+// columns -> slab [6 + 3 u .. 6 + 3 u + 2][K] = {lost with A, lost with B, gained with the new row}
+template <class Cell> __global__ void __launch_bounds__(256) k_cs_partial(ChainDev *g) {
+    using F = RowFmt<Cell>;
+    using Entry = typename F::Entry;
+    const Ctx c = make_ctx(g, 0);
+    const int m = g->m, nb = c.n_bits, n_out = c.n_out, K = c.K, Kpad = c.Kpad;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    Cell *s_mA = reinterpret_cast<Cell *>(smem);
+    Cell *s_mB = s_mA + n_out;
+    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_mB + n_out);  // [4][3][Kpad]
+    uint16_t *s_cmap = reinterpret_cast<uint16_t *>(s_cnt + 4 * 3 * Kpad);
+    const int tid = threadIdx.x, lane = lane_id(), wid = wave_id();
+    for (int j = tid; j < n_out; j += 256) s_cmap[j] = 0;
+    __syncthreads();
+    for (int j = tid; j < m; j += 256) {
+        s_cmap[g->mcol[j]] = (uint16_t)(j + 1);
+        s_mA[j] = reinterpret_cast<const Cell *>(g->mA)[j];
+        s_mB[j] = reinterpret_cast<const Cell *>(g->mB)[j];
+    }
+    __syncthreads();
+    const int u = (int)blockIdx.x * 4 + wid;
+    if (u >= g->cs_nuni) return;
+    const uint32_t A = g->A, B = g->B, r = g->cs_uni[u];
+    const bool same = A == B;
+    uint32_t *dA = s_cnt + (size_t)wid * 3 * Kpad, *dB = dA + Kpad, *cN = dB + Kpad;
+    for (int k = lane; k < 3 * Kpad; k += WAVE) dA[k] = 0;
+    lds_fence();
+    const da_u2 ref = g->rowoff[r];
+    const Entry *row = reinterpret_cast<const Entry *>(g->rlist) + ref.x;
+    for (int j = lane; j < (int)ref.y; j += WAVE) {
+        const Entry en = row[j];
+        const Cell x = F::cell(en);
+        if (!x) continue;
+        const int at = (int)s_cmap[F::col(en)];
+        if (!at) continue;
+        const Cell ma = s_mA[at - 1], mb = s_mB[at - 1];
+        for_pairs_part<Cell>(ma, x, A < r, nb, [&](int k) { atomicAdd(&dA[k], 1u); });
+        if (same)
+            for_pairs_part<Cell>(mb, x, A < r, nb, [&](int k) { atomicAdd(&dA[k], 1u); });
+        else
+            for_pairs_part<Cell>(mb, x, B < r, nb, [&](int k) { atomicAdd(&dB[k], 1u); });
+        for_pairs_cross<Cell>(x, ma, nb, [&](int k) { atomicAdd(&cN[k], 1u); });
+    }
+    lds_fence();
+    int32_t *out = g->cs_slab + (size_t)(6 + 3 * u) * K;
+    for (int k = lane; k < K; k += WAVE) {
+        out[k] = (int32_t)dA[k];
+        out[K + k] = (int32_t)dB[k];
+        out[2 * K + k] = (int32_t)cN[k];
+    }
+}
+
+// grid (ceil((n_union + 6) / 4)): the summed slab into the table.  Waves 0-5: the six pairs among {A, B, new} (their
+// blocks are replaced); wave 6 + u: row u of the union (blocks with A and B reduced, block with the new row created).
+template <class Cell> __global__ void __launch_bounds__(256) k_cs_apply(ChainDev *g) {
+    const Ctx c = make_ctx(g, 2 * g->iter - 1);
+    const int K = c.K;
+    const int w = (int)blockIdx.x * 4 + wave_id();
+    const uint32_t A = g->A, B = g->B, Nw = g->Nw;
+    const bool same = A == B;
+    if (w < 6) {
+        uint32_t lo = A, hi = A;
+        bool active = true, existed = false;
+        switch (w) {
+        case 0: lo = A, hi = A, existed = true; break;
+        case 1: lo = A, hi = B, existed = true, active = !same; break;
+        case 2: lo = B, hi = B, existed = true, active = !same; break;
+        case 3: lo = A, hi = Nw; break;
+        case 4: lo = B, hi = Nw, active = !same; break;
+        default: lo = Nw, hi = Nw; break;
+        }
+        if (!active) return;
+        const int32_t *cnt = g->cs_slab + (size_t)w * K;
+        const unsigned long long key = pack_pair(lo, hi);
+        const int slot = existed ? table_find(c, key, hash_pair(lo, hi)) : -1;
+        if (slot >= 0)
+            table_update(c, slot, key, [&](int k, uint32_t) { return (uint32_t)cnt[k]; });
+        else {
+            int f = 0;
+            for (int k = lane_id(); k < K; k += WAVE) f |= cnt[k] >= 2;
+            if (__any(f)) table_insert(c, lo, hi, load_row(c.rows, lo), load_row(c.rows, hi), [&](int k) { return (uint32_t)cnt[k]; });
+        }
+        return;
+    }
+    const int u = w - 6;
+    if (u >= g->cs_nuni) return;
+    const uint32_t r = g->cs_uni[u];
+    const int32_t *dA = g->cs_slab + (size_t)(6 + 3 * u) * K, *dB = dA + K, *cN = dB + K;
+    {
+        const uint32_t lo = min(A, r), hi = max(A, r);
+        const int slot = table_find(c, pack_pair(lo, hi), hash_pair(lo, hi));
+        if (slot >= 0) table_update(c, slot, pack_pair(lo, hi), [&](int k, uint32_t old) { return old - (uint32_t)dA[k]; });
+    }
+    if (!same) {
+        const uint32_t lo = min(B, r), hi = max(B, r);
+        const int slot = table_find(c, pack_pair(lo, hi), hash_pair(lo, hi));
+        if (slot >= 0) table_update(c, slot, pack_pair(lo, hi), [&](int k, uint32_t old) { return old - (uint32_t)dB[k]; });
+    }
+    int f = 0;
+    for (int k = lane_id(); k < K; k += WAVE) f |= cN[k] >= 2;
+    if (__any(f)) table_insert(c, r, Nw, load_row(c.rows, r), load_row(c.rows, Nw), [&](int k) { return (uint32_t)cN[k]; });
+    if (lane_id() == 0) atomicAdd(&g->st_partners, 1ull);
+}
+
 // ------------------------------------------------------------------------------------------------ k_extract
 // grid (ceil(n_out / 4), n_chains): one wave per column compacts the surviving (row, cell) entries in row order.
 template <class Cell> __global__ void __launch_bounds__(256) k_extract(ChainDev *chains) {
@@ -1707,6 +1918,7 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
         std::memset(&d, 0, sizeof d);
         d.n_in = j.n_in;
         d.n_out = j.n_out;
+        d.pn_out = j.n_out;
         d.method = j.method;
         d.adder_size = j.adder_size;
         d.carry_size = j.carry_size;
@@ -2205,6 +2417,256 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
     (void)max_n_in;
 }
 
+// ------------------------------------------------------------------------------------------------ column-sharded chain
+namespace {
+
+// da::ShardEngine on the GPU: one chain, the digits of the columns [c0, c1), a replica of the pair table.  Phases are
+// kernel launches on the backend's stream, each followed by a stream synchronisation: the exchange between the phases
+// (all-reduce of the buffers handed out here) is issued by the caller on its own stream / library.
+class HipShardEngine : public ShardEngine {
+  public:
+    HipShardEngine(hipStream_t st, int device, const ChainJob &job, int c0, int c1, double table_scale, double row_scale)
+        : st_(st), device_(device), job_(job), c0_(c0), n_loc_(c1 - c0) {
+        HIP_CHECK(hipSetDevice(device_));
+        const size_t e = (size_t)job.n_in * job.n_out;
+        // inputs + centred matrix of the WHOLE matrix (centring and digit width are global properties)
+        const size_t kb = align_up(e * 4, 256), qb = align_up((size_t)job.n_in * 12, 256), lb = align_up((size_t)job.n_in * 4, 256);
+        io_.get(2 * kb + qb + lb + align_up(job.n_in, 256) + align_up(job.n_out, 256) + 256);
+        unsigned char *io = static_cast<unsigned char *>(io_.ptr);
+        std::memset(&d_, 0, sizeof d_);
+        d_.n_in = job.n_in;
+        d_.n_out = n_loc_;
+        d_.pn_out = job.n_out;
+        d_.col0 = c0;
+        d_.method = job.method;
+        d_.adder_size = job.adder_size;
+        d_.carry_size = job.carry_size;
+        d_.kernel = reinterpret_cast<const float *>(io);
+        d_.qints = reinterpret_cast<const float *>(io + kb);
+        d_.lats = reinterpret_cast<const float *>(io + kb + qb);
+        d_.xint = reinterpret_cast<int32_t *>(io + kb + qb + lb);
+        d_.shift0 = reinterpret_cast<int8_t *>(io + 2 * kb + qb + lb);
+        d_.shift1 = d_.shift0 + align_up(job.n_in, 256);
+        HIP_CHECK(hipMemcpyAsync(io, job.kernel, e * 4, hipMemcpyHostToDevice, st_));
+        HIP_CHECK(hipMemcpyAsync(io + kb, job.qints, (size_t)job.n_in * 12, hipMemcpyHostToDevice, st_));
+        HIP_CHECK(hipMemcpyAsync(io + kb + qb, job.lats, (size_t)job.n_in * 4, hipMemcpyHostToDevice, st_));
+        desc_.get(sizeof(ChainDev));
+        dd_ = static_cast<ChainDev *>(desc_.ptr);
+        push();
+        hipLaunchKernelGGL(k_prepare, dim3(1), dim3(256), (size_t)job.n_out * 4, st_, dd_);
+        HIP_CHECK(hipGetLastError());
+        pull();
+        // geometry: as HipBackend::run_chains, with the statistics of the whole matrix (the table is global)
+        Geometry &g = geo_;
+        g.n_bits = d_.prep_nbits;
+        if (g.n_bits > 30) throw std::runtime_error("kernel needs more than 30 CSD digits per entry; unsupported");
+        g.wide = g.n_bits > 12 || n_loc_ > 256;
+        g.K = key_count(g.n_bits);
+        g.Kpad = (g.K + 3) & ~3;
+        g.pb_log2 = 5;
+        while ((1 << g.pb_log2) < 16 + 2 * g.Kpad) ++g.pb_log2;
+        const long long D0 = d_.prep_digits;
+        long long steps = std::max<long long>(16, (long long)(D0 * row_scale / 4));
+        if (steps > D0) steps = std::max<long long>(D0, 1);
+        g.rcap = job.n_in + (int)steps + 1;
+        g.lcap = job.n_in + d_.prep_maxdcol + 1;
+        g.pk_cap = (int)std::min<long long>(D0 + 1, (long long)1 << 30);
+        const long long rl_want = (long long)job.n_in * n_loc_ + D0 + n_loc_ + 64;
+        if (rl_want >= (1ll << REF_OFF_BITS) || g.rcap >= (1 << REF_ROW_BITS) || n_loc_ >= (1 << REF_LEN_BITS))
+            throw std::runtime_error("problem too large for the row-reference format");
+        g.rl_cap = (uint32_t)rl_want;
+        const long long pairs0 = std::min<long long>((long long)job.n_in * (job.n_in + 1) / 2, std::max<long long>(d_.prep_pairs, 1));
+        g.C = pow2_ceil((uint64_t)std::max(1024.0, 0.8 * pairs0 * std::max(4.0, job.n_in / 5.0) * table_scale));
+        g.gs_log2 = 8;
+        while ((g.C >> g.gs_log2) > (uint32_t)MAX_GROUPS) ++g.gs_log2;
+        if (g.gs_log2 > 14) throw std::runtime_error("pair table larger than 64M slots is not supported");
+        if (g.C < 256) g.C = 256;
+        g.n_groups = (int)(g.C >> g.gs_log2);
+        if (((size_t)g.rcap + 31) / 32 * 4 > 64 * 1024) throw std::runtime_error("column-sharded chain: more rows than the LDS claim bitmap holds");
+        n_pairs_ = (long long)job.n_in * (job.n_in + 1) / 2;
+        // arena: the chain's arrays (local column count) + the exchange buffers
+        ChainJob local = job;
+        local.n_out = n_loc_;
+        ChainDev tmp;
+        const size_t chain_bytes = carve_chain(nullptr, local, g, tmp);
+        const size_t init_b = align_up((size_t)n_pairs_ * g.K * 4, 256), flag_b = align_up(((size_t)g.rcap + 3) / 4 * 4 + 64, 256),
+                     uni_b = align_up((size_t)g.rcap * 4, 256), slab_b = align_up((size_t)(6 + 3 * (size_t)g.rcap) * g.K * 4, 256);
+        arena_.get(chain_bytes + init_b + flag_b + uni_b + slab_b);
+        unsigned char *a = static_cast<unsigned char *>(arena_.ptr);
+        carve_chain(a, local, g, d_);
+        d_.cs_init = reinterpret_cast<int32_t *>(a + chain_bytes);
+        d_.cs_flags = reinterpret_cast<int32_t *>(a + chain_bytes + init_b);
+        d_.cs_uni = reinterpret_cast<uint32_t *>(a + chain_bytes + init_b + flag_b);
+        d_.cs_slab = reinterpret_cast<int32_t *>(a + chain_bytes + init_b + flag_b + uni_b);
+        d_.n_bits = g.n_bits;
+        d_.K = g.K;
+        d_.Kpad = g.Kpad;
+        d_.rcap = g.rcap;
+        d_.lcap = g.lcap;
+        d_.gs_log2 = g.gs_log2;
+        d_.n_groups = g.n_groups;
+        d_.C = g.C;
+        d_.cmask = g.C - 1;
+        d_.pb_log2 = g.pb_log2;
+        d_.rl_cap = g.rl_cap;
+        d_.rl_used = (uint32_t)job.n_in * (uint32_t)n_loc_;
+        d_.n_rows = job.n_in;
+        d_.claim_words = (g.rcap + 31) / 32;
+        HIP_CHECK(hipMemsetAsync(d_.stamp, 0, sizeof(uint32_t) * (size_t)g.rcap, st_));
+        HIP_CHECK(hipMemsetAsync(d_.hkey, 0xFF, sizeof(unsigned long long) * (size_t)g.C, st_));
+        HIP_CHECK(hipMemsetAsync(d_.hrank, 0, sizeof(uint32_t) * (size_t)g.C, st_));
+        HIP_CHECK(hipMemsetAsync(d_.ub, 0, sizeof(unsigned long long) * (size_t)g.n_groups, st_));
+        HIP_CHECK(hipMemsetAsync(d_.gdirty, 1, (size_t)g.n_groups, st_));
+        push();
+        HIP_CHECK(hipMalloc(&d_done_, sizeof(unsigned int)));
+        HIP_CHECK(hipMemsetAsync(d_done_, 0, sizeof(unsigned int), st_));
+        dim3 colgrid((n_loc_ + 3) / 4, 1);
+        if (!g.wide)
+            hipLaunchKernelGGL(k_init_cells<uint32_t>, colgrid, dim3(256), 0, st_, dd_);
+        else
+            hipLaunchKernelGGL(k_init_cells<uint64_t>, colgrid, dim3(256), 0, st_, dd_);
+        HIP_CHECK(hipGetLastError());
+        sel_lds_ = align_up((size_t)n_loc_ * (g.wide ? 16 : 4) + 6 * (size_t)g.Kpad * 4 + (3 * (size_t)n_loc_ + 1) * 4 + (size_t)d_.claim_words * 4, 16);
+        if (sel_lds_ > 150 * 1024) throw std::runtime_error("selection kernel needs more than 150 KiB of LDS");
+        if (!g.wide)
+            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_iter_select<uint32_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sel_lds_));
+        else
+            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_iter_select<uint64_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sel_lds_));
+        part_lds_ = align_up(2 * (size_t)n_loc_ * (g.wide ? 8 : 4) + 4 * 3 * (size_t)g.Kpad * 4 + (size_t)n_loc_ * 2, 16);
+        HIP_CHECK(hipStreamSynchronize(st_));
+    }
+    ~HipShardEngine() override {
+        (void)hipSetDevice(device_);
+        if (d_done_) (void)hipFree(d_done_);
+    }
+    bool on_device() const override { return true; }
+    int n_keys() const override { return geo_.K; }
+    int32_t *init_counts(int64_t &count) override {
+        const dim3 grid((unsigned)((n_pairs_ + 3) / 4));
+        if (!geo_.wide)
+            hipLaunchKernelGGL(k_cs_init_counts<uint32_t>, grid, dim3(256), (size_t)4 * geo_.Kpad * 4, st_, dd_);
+        else
+            hipLaunchKernelGGL(k_cs_init_counts<uint64_t>, grid, dim3(256), (size_t)4 * geo_.Kpad * 4, st_, dd_);
+        sync();
+        count = n_pairs_ * geo_.K;
+        return d_.cs_init;
+    }
+    void init_table() override {
+        const dim3 grid((unsigned)((n_pairs_ + 3) / 4));
+        if (!geo_.wide)
+            hipLaunchKernelGGL(k_cs_init_table<uint32_t>, grid, dim3(256), 0, st_, dd_);
+        else
+            hipLaunchKernelGGL(k_cs_init_table<uint64_t>, grid, dim3(256), 0, st_, dd_);
+        HIP_CHECK(hipGetLastError());
+    }
+    bool select(int32_t *&flags, int64_t &fcount) override {
+        if (!geo_.wide)
+            hipLaunchKernelGGL((k_iter_select<uint32_t, true>), dim3(1), dim3(SEL_THREADS), sel_lds_, st_, dd_, d_done_);
+        else
+            hipLaunchKernelGGL((k_iter_select<uint64_t, true>), dim3(1), dim3(SEL_THREADS), sel_lds_, st_, dd_, d_done_);
+        pull();
+        if (d_.done) return false;
+        flags = d_.cs_flags;
+        fcount = flag_words((int)d_.Nw);
+        return true;
+    }
+    int32_t *partial(int64_t &scount) override {
+        hipLaunchKernelGGL(k_cs_union, dim3(1), dim3(1024), 0, st_, dd_);
+        int nuni = 0;
+        HIP_CHECK(hipMemcpyAsync(&nuni, &dd_->cs_nuni, sizeof(int), hipMemcpyDeviceToHost, st_));
+        sync();
+        nuni_ = nuni;
+        if (nuni > 0) {
+            const dim3 grid((unsigned)((nuni + 3) / 4));
+            if (!geo_.wide)
+                hipLaunchKernelGGL(k_cs_partial<uint32_t>, grid, dim3(256), part_lds_, st_, dd_);
+            else
+                hipLaunchKernelGGL(k_cs_partial<uint64_t>, grid, dim3(256), part_lds_, st_, dd_);
+        }
+        sync();
+        scount = (int64_t)(6 + 3 * (int64_t)nuni) * geo_.K;
+        return d_.cs_slab;
+    }
+    void apply() override {
+        const dim3 grid((unsigned)((nuni_ + 6 + 3) / 4));
+        if (!geo_.wide)
+            hipLaunchKernelGGL(k_cs_apply<uint32_t>, grid, dim3(256), 0, st_, dd_);
+        else
+            hipLaunchKernelGGL(k_cs_apply<uint64_t>, grid, dim3(256), 0, st_, dd_);
+        HIP_CHECK(hipGetLastError());
+    }
+    void finish(ChainOut &o) override {
+        dim3 colgrid((n_loc_ + 3) / 4, 1);
+        if (!geo_.wide)
+            hipLaunchKernelGGL(k_extract<uint32_t>, colgrid, dim3(256), 0, st_, dd_);
+        else
+            hipLaunchKernelGGL(k_extract<uint64_t>, colgrid, dim3(256), 0, st_, dd_);
+        hipLaunchKernelGGL(k_pack, dim3(1), dim3(256), 0, st_, dd_);
+        pull();
+        o = ChainOut{};
+        o.error = d_.error;
+        o.unknown_method_hit = d_.unknown_hit != 0;
+        o.n_bits = d_.n_bits;
+        const size_t iters = (size_t)d_.iter;
+        o.shift0.resize(job_.n_in);
+        o.shift1.resize(job_.n_out);
+        o.picks.resize(iters * 4);
+        o.row_lat.resize((size_t)d_.n_rows);
+        o.col_start.resize((size_t)n_loc_ + 1);
+        HIP_CHECK(hipMemcpyAsync(o.shift0.data(), d_.shift0, job_.n_in, hipMemcpyDeviceToHost, st_));
+        HIP_CHECK(hipMemcpyAsync(o.shift1.data(), d_.shift1, job_.n_out, hipMemcpyDeviceToHost, st_));
+        if (iters) HIP_CHECK(hipMemcpyAsync(o.picks.data(), d_.picks, iters * sizeof(int4), hipMemcpyDeviceToHost, st_));
+        HIP_CHECK(hipMemcpyAsync(o.row_lat.data(), d_.pk_lat, (size_t)d_.n_rows * 4, hipMemcpyDeviceToHost, st_));
+        HIP_CHECK(hipMemcpyAsync(o.col_start.data(), d_.fin_start, ((size_t)n_loc_ + 1) * 4, hipMemcpyDeviceToHost, st_));
+        sync();
+        const size_t total = o.col_start[n_loc_];
+        o.dig_row.resize(total);
+        std::vector<unsigned long long> cells(total);
+        if (total) {
+            HIP_CHECK(hipMemcpyAsync(o.dig_row.data(), d_.pk_row, total * 4, hipMemcpyDeviceToHost, st_));
+            HIP_CHECK(hipMemcpyAsync(cells.data(), d_.pk_cell, total * 8, hipMemcpyDeviceToHost, st_));
+            sync();
+        }
+        o.dig_cell.assign(cells.begin(), cells.end());
+        o.stats.iterations = d_.iter;
+        o.stats.digits0 = d_.prep_digits;
+        o.stats.table_peak = d_.live_peak;
+        o.stats.partners = (long long)d_.st_partners;
+        o.stats.matches = (long long)d_.st_matches;
+        o.stats.scan_slots = (long long)d_.st_rescans << d_.gs_log2;
+    }
+
+  private:
+    void sync() {
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipStreamSynchronize(st_));
+    }
+    void push() { HIP_CHECK(hipMemcpyAsync(dd_, &d_, sizeof d_, hipMemcpyHostToDevice, st_)); }
+    void pull() {
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipMemcpyAsync(&d_, dd_, sizeof d_, hipMemcpyDeviceToHost, st_));
+        HIP_CHECK(hipStreamSynchronize(st_));
+    }
+    hipStream_t st_;
+    int device_;
+    ChainJob job_;
+    int c0_, n_loc_;
+    ChainDev d_;
+    ChainDev *dd_ = nullptr;
+    Geometry geo_;
+    DeviceBuffer io_, desc_, arena_;
+    unsigned int *d_done_ = nullptr;
+    long long n_pairs_ = 0;
+    int nuni_ = 0;
+    size_t sel_lds_ = 0, part_lds_ = 0;
+};
+
+}  // namespace
+
+std::unique_ptr<ShardEngine> HipBackend::make_shard_engine(const ChainJob &job, int c0, int c1) {
+    return std::unique_ptr<ShardEngine>(new HipShardEngine(impl_->stream, impl_->device, job, c0, c1, impl_->table_scale, row_scale_));
+}
+
 void HipBackend::column_distances(const int32_t *aug, int n_in, int W, int64_t *d0, int64_t *d1) {
     Impl &im = *impl_;
     HIP_CHECK(hipSetDevice(im.device));
@@ -2276,6 +2738,7 @@ int HipBackend::csd_decompose(const float *kernel, int n_in, int n_out, bool cen
         std::memset(&d, 0, sizeof d);
         d.n_in = n_in;
         d.n_out = n_out;
+        d.pn_out = n_out;
         d.kernel = reinterpret_cast<const float *>(buf);
         d.qints = reinterpret_cast<const float *>(buf + kb);
         d.xint = reinterpret_cast<int32_t *>(buf + kb + qb);

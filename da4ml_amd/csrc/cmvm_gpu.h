@@ -4,6 +4,7 @@
 #include <memory>
 
 #include "cmvm_host.h"
+#include "cmvm_shard.h"
 
 namespace da {
 namespace gpu {
@@ -46,6 +47,9 @@ class HipBackend : public Backend {
     const GpuTimings &timings() const;
     void reset_timings();
     void *stream() const;  // hipStream_t the kernels are launched on
+    // one greedy chain on the columns [c0, c1) of its matrix, pair table replicated (cmvm_shard.h); the engine lives on
+    // this backend's device and stream and must not outlive it
+    std::unique_ptr<ShardEngine> make_shard_engine(const ChainJob &job, int c0, int c1);
 
   private:
     struct Impl;

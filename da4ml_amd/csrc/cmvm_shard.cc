@@ -11,7 +11,7 @@ namespace da {
 void ShardedBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
     for (int i = 0; i < n; ++i) {
         const ChainJob &j = jobs[i];
-        const bool shardable = comm_.world > 1 && j.n_out >= comm_.world && j.method >= 0 && j.method != M_DUMMY;
+        const bool shardable = (comm_.world > 1 || force_single) && j.n_out >= comm_.world && j.method >= 0 && j.method != M_DUMMY;
         if (shardable)
             run_one(j, outs[i]);
         else

@@ -61,8 +61,8 @@ class ShardEngine {
     // the chain is finished.  flags: packed 8-bit fields, field r != 0 <=> row r shares a substituted column here.
     virtual bool select(int32_t *&flags, int64_t &flag_count) = 0;
     // phase 2: from the summed flags, the union of partner rows (ascending ids, identical on every rank) and this
-    // rank's partial count changes: slab int32 [(3 n_union + 6)][K] = per partner {lost with A, lost with B, gained with
-    // the new row}, then the six pairs among {A, B, new}
+    // rank's partial count changes: slab int32 [(6 + 3 n_union)][K] = the six pairs among {A, B, new} (AA, AB, BB, AN, BN,
+    // NN), then per partner {lost with A, lost with B, gained with the new row}
     virtual int32_t *partial(int64_t &slab_count) = 0;
     virtual void apply() = 0;  // phase 3: the summed slab into the table
     // own columns of the finished chain (col_start covers the own columns only; everything row-related is global)
@@ -86,6 +86,7 @@ class ShardedBackend : public Backend {
     int int_to_csd(const int32_t *x, int64_t n, std::vector<int8_t> &csd) override { return inner_.int_to_csd(x, n, csd); }
     const ShardComm &comm() const { return comm_; }
     long long sharded_chains = 0, sharded_steps = 0;
+    bool force_single = false;  // test aid: run the sharded phases with a single rank too (the exchanges are no-ops)
 
   private:
     void run_one(const ChainJob &job, ChainOut &out);

@@ -73,6 +73,22 @@ int da_solve_batch(int count, const float *const *kernels, const int64_t *n_in, 
                    const float *const *latencies, int adder_size, int carry_size, int search_all_decompose_dc,
                    da_result **results);
 
+/* ---- column-sharded solve (BASELINE config C4; addition, no reference counterpart) ------------------------------------------
+ * da_solve with every greedy chain sharded over the output COLUMNS of its matrix across `world` processes (one per GPU):
+ * rank g holds the digits of columns [g n_out / world, (g+1) n_out / world), the pair-count table is replicated, and per
+ * greedy step the ranks exchange two int32 slabs by all-reduce(sum) -- the loops it shards are column-outermost in the
+ * reference (state_opr.cc:117,249,307; adder trees cmvm_core.cc:103).  Every rank calls this with identical arguments and
+ * receives the identical, complete result (= da_solve's).  The library does not link a communication library: the host
+ * process supplies the collective (RCCL through torch.distributed in da4ml_amd.multi_gpu.solve_column_sharded).
+ * `allreduce(ctx, buf, count, on_device)`: in-place sum of `count` int32 at `buf` over all ranks; `buf` is device memory
+ * of the current device when on_device != 0 (the producing kernels have completed), host memory otherwise; returns when
+ * the result is in place.  stats3 (may be NULL) = {sharded chains, greedy steps, all-reduce calls}.  Latency-bound by
+ * construction (two collectives per greedy step); the layout that scales is one matrix per rank (da_solve_batch). */
+typedef void (*da_allreduce_i32)(void *ctx, void *buf, int64_t count, int on_device);
+da_result *da_solve_sharded(const float *kernel, int64_t n_in, int64_t n_out, const char *method0, const char *method1, int hard_dc,
+                            int decompose_dc, const float *qintervals, const float *latencies, int adder_size, int carry_size,
+                            int search_all_decompose_dc, int rank, int world, da_allreduce_i32 allreduce, void *ctx, int64_t *stats3);
+
 /* ---- result access (da4ml.types.Pipeline / CombLogic / Op, bindings.cc:106-151) ---------------------------- */
 int da_n_stages(const da_result *r);
 /* index of the winning decompose_dc candidate when search_all_decompose_dc was set, else -1 */

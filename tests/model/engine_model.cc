@@ -376,10 +376,10 @@ template <class Cell> struct ShardChain : Chain<Cell>, ShardEngine {
         for (uint32_t r = 0; r < Nw; ++r)
             if ((flags[r >> 2] >> (8 * (r & 3))) & 0xFF) uni.push_back(r);
         const int Kk = K;
-        slab.assign((3 * uni.size() + 6) * (size_t)Kk, 0);
+        slab.assign((6 + 3 * uni.size()) * (size_t)Kk, 0);
         for (size_t u = 0; u < uni.size(); ++u) {
             uint32_t r = uni[u];
-            int32_t *dA = slab.data() + (3 * u) * Kk, *dB = dA + Kk, *cN = dB + Kk;
+            int32_t *dA = slab.data() + (6 + 3 * u) * Kk, *dB = dA + Kk, *cN = dB + Kk;
             for (size_t q = 0; q < mcol.size(); ++q) {
                 Cell x = cells[r][mcol[q]];
                 if (!x) continue;
@@ -391,7 +391,7 @@ template <class Cell> struct ShardChain : Chain<Cell>, ShardEngine {
                 for_pairs_cross<Cell>(x, MA[q], N, [&](int k) { cN[k]++; });
             }
         }
-        int32_t *sp = slab.data() + 3 * uni.size() * Kk;  // AA, AB, BB, AN, BN, NN
+        int32_t *sp = slab.data();  // AA, AB, BB, AN, BN, NN
         count_pair(A, A, sp);
         if (A != B) {
             count_pair(A, B, sp + Kk);
@@ -405,7 +405,7 @@ template <class Cell> struct ShardChain : Chain<Cell>, ShardEngine {
     }
     void apply() override {
         const int Kk = K;
-        const int32_t *sp = slab.data() + 3 * uni.size() * Kk;
+        const int32_t *sp = slab.data();
         put_block(A, A, sp);
         if (A != B) {
             put_block(A, B, sp + Kk);
@@ -417,7 +417,7 @@ template <class Cell> struct ShardChain : Chain<Cell>, ShardEngine {
         for (size_t u = 0; u < uni.size(); ++u) {
             uint32_t r = uni[u];
             st.partners++;
-            const int32_t *dA = slab.data() + (3 * u) * Kk, *dB = dA + Kk, *cN = dB + Kk;
+            const int32_t *dA = slab.data() + (6 + 3 * u) * Kk, *dB = dA + Kk, *cN = dB + Kk;
             auto sub = [&](uint32_t m, const int32_t *d) {
                 auto it = table.find(Base::pkey(std::min(m, r), std::max(m, r)));
                 if (it == table.end()) return;
