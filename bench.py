@@ -192,7 +192,9 @@ def cpu_baseline(n_in, n_out, opts, budget_s, batch):
     kind = 'reference' if (HERE / '_ref' / 'libref.so').exists() else 'port'  # the reference's own sources when the build travelled
     okind = 'ref' if kind == 'reference' else 'port'
     cores = cpu_pool.host_cores()
-    workers = max(1, min(cores, batch))
+    # one 256x256 chain of the reference holds its 64.7 M initial pairs (24 bytes each) plus the sort buffer: ~4 GB per process
+    need_gb = 4.0 * (n_in * n_out / 65536.0) ** 2 + 0.5
+    workers = max(1, min(cores, batch, int(cpu_pool.mem_available_gb() / need_gb)))
     method = opts.get('method0', 'wmc')
     # (1) a time-bounded prefix of every chain of the batch, all cores busy at once
     samples, wall = cpu_pool.run_pool(cpu_pool.sample_worker, [(okind, n_in, n_out, seed, method, budget_s) for seed in range(workers)], workers)
@@ -317,7 +319,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--workload', default='c3_256x256_int8_batch64_single_chain', choices=sorted(WORKLOADS))
     ap.add_argument('--batch', type=int, default=0, help='override the per-GPU batch size')
-    ap.add_argument('--cpu-seconds', type=float, default=20.0, help='budget of the CPU baseline sample (0 = skip)')
+    ap.add_argument('--cpu-seconds', type=float, default=15.0, help='budget of the CPU baseline sample (0 = skip)')
     ap.add_argument('--no-verify', action='store_true', help='skip the replay of all results after the timed region')
     ap.add_argument('--selftest-launcher', action='store_true', help=argparse.SUPPRESS)
     args = ap.parse_args()

@@ -175,6 +175,7 @@ struct ChainDev {
     uint8_t *gdirty;           // [n_groups] a block's best (rank, key) changed since the group was last verified
     // per-iteration hand-off select -> update
     int *mcol;
+    int *colin;        // [n_out] number of INPUT rows at the head of each column list (fixed after k_init_cells)
     void *mA, *mB;
     unsigned long long *plist;
     int m, n_partners;
@@ -542,7 +543,10 @@ template <class Cell> __global__ void __launch_bounds__(256) k_init_cells(ChainD
             ch.collist[(size_t)j * ch.lcap + len + __popcll(nz & ((1ull << lane) - 1))] = ref_pack((uint32_t)i, (uint32_t)ch.n_out, (uint32_t)i * (uint32_t)ch.n_out);
         len += __popcll(nz);
     }
-    if (lane == 0) ch.collen[j] = len;
+    if (lane == 0) {
+        ch.collen[j] = len;
+        ch.colin[j] = len;
+    }
     if (j == 0)
         for (int i = lane; i < ch.n_in; i += WAVE) {
             ch.rows[i] = RowInfo{ch.qints[3 * i], ch.qints[3 * i + 1], ch.qints[3 * i + 2], ch.lats[i]};
@@ -616,9 +620,10 @@ template <class Cell, bool SHARDED = false> __global__ void __launch_bounds__(SE
     using F = RowFmt<Cell>;
     using Entry = typename F::Entry;
     ChainDev *g = &chains[blockIdx.x];
-    if (g->done) return;
+    const int was_done = g->done, had_error = g->error;  // read together with the rest of the descriptor: one round trip
     const Ctx c = make_ctx(g, 2 * g->iter);
     const int n_groups = g->n_groups, n_out = c.n_out, Kpad = c.Kpad, nb = c.n_bits, lcap = g->lcap;
+    if (was_done) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // dynamic LDS carve: B's list | special-pair counters | per-matched-column scratch | column -> position in B | claim bitmap
     Entry *s_bent = reinterpret_cast<Entry *>(smem);                                  // [n_out] entries of row B (updated in place)
@@ -626,7 +631,8 @@ template <class Cell, bool SHARDED = false> __global__ void __launch_bounds__(SE
     int *s_len = reinterpret_cast<int *>(s_cnt + 6 * Kpad);                           // [n_out + 1] list lengths -> offsets
     int *s_col = s_len + n_out + 1;                                                   // [n_out] matched columns
     int *s_bpos = s_col + n_out;                                                      // [n_out] 1 + position of a column in B's list, 0 = absent
-    uint32_t *s_bits = reinterpret_cast<uint32_t *>(s_bpos + n_out);                 // [claim_words] rows already claimed (if it fits)
+    int *s_cin = s_bpos + n_out;                                                      // [n_out] input rows at the head of a matched column's list
+    uint32_t *s_bits = reinterpret_cast<uint32_t *>(s_cin + n_out);                  // [claim_words] rows already claimed (if it fits)
     const int claim_words = g->claim_words;
     constexpr int NW = SEL_THREADS / WAVE;
     __shared__ unsigned long long s_red_tie[NW], s_floor0, s_floor;
@@ -641,7 +647,7 @@ template <class Cell, bool SHARDED = false> __global__ void __launch_bounds__(SE
 
     long long tp[8];
     tp[0] = clock64();
-    if (g->error != E_OK) {  // a capacity error poisons the chain: stop it (the host retries with a larger arena)
+    if (had_error != E_OK) {  // a capacity error poisons the chain: stop it (the host retries with a larger arena)
         if (tid == 0) {
             g->done = 1;
             g->n_partners = 0;
@@ -856,6 +862,8 @@ template <class Cell, bool SHARDED = false> __global__ void __launch_bounds__(SE
         }
     }
     const int clen0 = tid < lenA ? collen[F::col(eA0)] : 0;  // pre-append list length of this thread's column (used if it matches)
+    // ... and how many of them are input rows: those are made partners wholesale below, only the tail of the list is claimed
+    const int cin0 = (!SHARDED && tid < lenA) ? ((DA_GLOBAL int *)g->colin)[F::col(eA0)] : 0;
     __syncthreads();
     tp[3] = clock64();
     DA_GLOBAL Cell *mA = (DA_GLOBAL Cell *)g->mA, *mB = (DA_GLOBAL Cell *)g->mB;
@@ -906,6 +914,7 @@ template <class Cell, bool SHARDED = false> __global__ void __launch_bounds__(SE
             mA[at] = ma;
             mB[at] = mb;
             s_len[at] = t0 == 0 ? clen0 : collen[colA];  // the pre-append length: the new row itself is not a partner
+            s_cin[at] = SHARDED ? 0 : (t0 == 0 ? cin0 : ((DA_GLOBAL int *)g->colin)[colA]);
             s_col[at] = (int)colA;
             my_matches += popc32(O::plus(ma) | O::minus(ma));
         }
@@ -940,6 +949,7 @@ template <class Cell, bool SHARDED = false> __global__ void __launch_bounds__(SE
                 collen[j] = len + 1;
             } else
                 g->error = E_LIST_CAPACITY;
+            s_len[k] = len - s_cin[k];  // from here on: the length of the list's tail (rows created by substitutions)
         }
     }
     __syncthreads();
@@ -982,15 +992,15 @@ template <class Cell, bool SHARDED = false> __global__ void __launch_bounds__(SE
     }
     const int total = s_len[m];
     tp[5] = clock64();
-    // ---------------- (4) partner rows: every row listed in a matched column, claimed once and appended to the
-    // partner list -- by the first NW-6 waves; the last six waves store the six special pairs meanwhile.
+    // ---------------- (4) partner rows: every row that may share a substituted column, once, into the partner list -- by the
+    // first NW-6 waves; the last six waves store the six special pairs meanwhile.  A superset is harmless (a partner without
+    // digits in the substituted columns changes nothing), so ALL input rows are partners wholesale: they head every column
+    // list, and re-reading them m times was most of this phase.  Only the tails of the lists (rows created by
+    // substitutions) are read and de-duplicated.  A column-sharded chain leaves one flag per row instead of the list
+    // (exact: its lists are read whole).
     constexpr int CLAIM_WAVES = NW - 6, CLAIM_THREADS = CLAIM_WAVES * WAVE;
     if (wid < CLAIM_WAVES) {
-        DA_GLOBAL uint32_t *stamp = (DA_GLOBAL uint32_t *)g->stamp;
-        DA_GLOBAL unsigned long long *plist = (DA_GLOBAL unsigned long long *)g->plist;
-        const uint32_t tag = (uint32_t)iter + 1u;
-        constexpr int CLAIM_ILP = 8;  // independent list reads in flight per thread: one pass covers 5120 list entries
-        if constexpr (SHARDED) {  // flags only: the union over the ranks is formed after the exchange (k_cs_union)
+        if constexpr (SHARDED) {
             for (int f = tid; f < total; f += CLAIM_THREADS) {
                 int lo = 0, hi = m;
                 while (hi - lo > 1) {
@@ -1003,48 +1013,59 @@ template <class Cell, bool SHARDED = false> __global__ void __launch_bounds__(SE
                 const uint32_t row = ref_row(collist[(size_t)s_col[lo] * lcap + (f - s_len[lo])]);
                 if (row != A && row != B) atomicOr(&s_bits[row >> 5], 1u << (row & 31));
             }
-        } else
-        for (int fb = wid * WAVE; fb < total; fb += CLAIM_ILP * CLAIM_THREADS) {  // wave-uniform trip count: all lanes stay active
-            unsigned long long r[CLAIM_ILP];
-            bool ok[CLAIM_ILP];
-#pragma unroll
-            for (int u = 0; u < CLAIM_ILP; ++u) {  // CLAIM_ILP independent list reads in flight
-                const int f = fb + lane + u * CLAIM_THREADS;
-                ok[u] = f < total;
-                r[u] = 0;
-                if (ok[u]) {
-                    int lo = 0, hi = m;
-                    while (hi - lo > 1) {
-                        int mid = (lo + hi) >> 1;
-                        if (s_len[mid] <= f)
-                            lo = mid;
-                        else
-                            hi = mid;
-                    }
-                    r[u] = collist[(size_t)s_col[lo] * lcap + (f - s_len[lo])];
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < CLAIM_ILP; ++u) {
-                const uint32_t row = ref_row(r[u]);
-                if (!ok[u] || row == A || row == B) {
-                    ok[u] = false;
-                    continue;
-                }
-                if (claim_words) {  // de-duplicate in the LDS bitmap: no global round trip
-                    const uint32_t bit = 1u << (row & 31);
-                    ok[u] = (atomicOr(&s_bits[row >> 5], bit) & bit) == 0;
-                } else
-                    ok[u] = atomicExch(gen(&stamp[row]), tag) != tag;
-            }
-#pragma unroll
-            for (int u = 0; u < CLAIM_ILP; ++u) {  // one LDS atomic per wave (not per row: same-address atomics serialise)
-                const unsigned long long okm = __ballot(ok[u]);
-                if (!okm) continue;
+        } else {
+            DA_GLOBAL uint32_t *stamp = (DA_GLOBAL uint32_t *)g->stamp;
+            DA_GLOBAL unsigned long long *plist = (DA_GLOBAL unsigned long long *)g->plist;
+            const uint32_t tag = (uint32_t)iter + 1u;
+            const int n_in = g->n_in;
+            auto append = [&](bool ok, unsigned long long ref) {  // one LDS atomic per wave (same-address atomics serialise)
+                const unsigned long long okm = __ballot(ok);
+                if (!okm) return;
                 int base = 0;
                 if (lane == 0) base = atomicAdd(&s_np, (int)__popcll(okm));
                 base = __builtin_amdgcn_readfirstlane(base);
-                if (ok[u]) plist[base + __popcll(okm & ((1ull << lane) - 1))] = r[u];
+                if (ok) plist[base + __popcll(okm & ((1ull << lane) - 1))] = ref;
+            };
+            for (int ib = wid * WAVE; ib < n_in; ib += CLAIM_THREADS) {  // the input rows (dense lists: offset = id * n_out)
+                const int i = ib + lane;
+                append(i < n_in && (uint32_t)i != A && (uint32_t)i != B, ref_pack((uint32_t)i, (uint32_t)n_out, (uint32_t)i * (uint32_t)n_out));
+            }
+            constexpr int CLAIM_ILP = 4;
+            for (int fb = wid * WAVE; fb < total; fb += CLAIM_ILP * CLAIM_THREADS) {  // wave-uniform trip count: all lanes stay active
+                unsigned long long r[CLAIM_ILP];
+                bool ok[CLAIM_ILP];
+#pragma unroll
+                for (int u = 0; u < CLAIM_ILP; ++u) {  // CLAIM_ILP independent list reads in flight
+                    const int f = fb + lane + u * CLAIM_THREADS;
+                    ok[u] = f < total;
+                    r[u] = 0;
+                    if (ok[u]) {
+                        int lo = 0, hi = m;
+                        while (hi - lo > 1) {
+                            int mid = (lo + hi) >> 1;
+                            if (s_len[mid] <= f)
+                                lo = mid;
+                            else
+                                hi = mid;
+                        }
+                        r[u] = collist[(size_t)s_col[lo] * lcap + s_cin[lo] + (f - s_len[lo])];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < CLAIM_ILP; ++u) {
+                    const uint32_t row = ref_row(r[u]);
+                    if (!ok[u] || row == A || row == B) {
+                        ok[u] = false;
+                        continue;
+                    }
+                    if (claim_words) {  // de-duplicate in the LDS bitmap: no global round trip
+                        const uint32_t bit = 1u << (row & 31);
+                        ok[u] = (atomicOr(&s_bits[row >> 5], bit) & bit) == 0;
+                    } else
+                        ok[u] = atomicExch(gen(&stamp[row]), tag) != tag;
+                }
+#pragma unroll
+                for (int u = 0; u < CLAIM_ILP; ++u) append(ok[u], r[u]);
             }
         }
     } else {
@@ -1100,19 +1121,8 @@ template <class Cell, bool SHARDED = false> __global__ void __launch_bounds__(SE
     }
 }
 
-// ------------------------------------------------------------------------------------------------ k_iter_update
-// grid (U, n_chains).  Every partner row (a row other than A, B, new that shares a substituted column) is handled
-// by ONE wavefront: it subtracts the pair occurrences lost with A's / B's consumed digits from the blocks (A,r),
-// (B,r) and creates the block (r,new).
-//
-// The kernel is bound by dependent memory round trips (list reference -> list + two key buckets -> two payload lines),
-// not by bytes, so a wave takes a contiguous chunk of the partner list and works on UPD_BATCH partners at once: all
-// their lists and key buckets are loaded together, then all their payload lines (ONE 32-bit word per lane covers a
-// whole line: header in lanes 0-3, two u16 counts per lane after them), the digit pairs are enumerated into per-partner
-// LDS counters while the payload lines are in flight, and only then the blocks are re-evaluated.  Three round trips per
-// batch instead of per partner.  Rare cases (key not in its first bucket, block creation) run after the batch from LDS.
 #ifndef DA_UPD_OCC
-#define DA_UPD_OCC 6  // blocks of 256 threads per CU the register budget is capped for
+#define DA_UPD_OCC 5  // blocks of 256 threads per CU the register budget is capped for (88 VGPRs, no spills)
 #endif
 #if DA_UPD_OCC >= 8
 #define DA_UPD_SGPRS 80  // 800 SGPRs per SIMD: more than 80 per wave would cap the residency below 8 waves per SIMD
@@ -1121,88 +1131,44 @@ template <class Cell, bool SHARDED = false> __global__ void __launch_bounds__(SE
 #else
 #define DA_UPD_SGPRS 102
 #endif
-#ifndef DA_UPD_BATCH
-#define DA_UPD_BATCH 6
-#endif
-constexpr int UPD_BATCH = DA_UPD_BATCH;
-
-__device__ __forceinline__ unsigned long long bcast64(unsigned long long v, int src_lane) {  // wave-uniform copy of lane src_lane's value
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src_lane);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), src_lane);
-    return ((unsigned long long)hi << 32) | lo;
-}
-
-// Which 32-bit word of a block's payload line a lane prefetches.  DIRECT (narrow layout, K <= 46): lane k < K the word that
-// holds count k (lanes 2j and 2j+1 share a word), lanes 60-63 the four header words -- no cross-lane traffic afterwards.
-// Otherwise (K up to 118): lane L word L, the counts are redistributed with a wave shuffle.
-template <bool DIRECT> __device__ __forceinline__ int payload_word(int lane, int K, int nwords, bool &active) {
-    if (DIRECT) {
-        active = lane < K || lane >= 60;
-        return lane < K ? 4 + (lane >> 1) : lane - 60;
-    }
-    active = lane < nwords;
-    return lane;
-}
-// Re-evaluate one block from its prefetched payload word `w` (see payload_word) and the deltas `d` (LDS): new counts
-// stored, best key / rank / group state published by lane 0.
-template <bool DIRECT> __device__ __forceinline__ void apply_block(const Ctx &c, int slot, unsigned long long key, uint32_t w, const uint32_t *d) {
-    const int lane = lane_id();
-    constexpr int H = DIRECT ? 60 : 0;
-    BlkHdr h;
-    h.ov = __builtin_amdgcn_readlane((int)w, H);
-    h.dl = __int_as_float(__builtin_amdgcn_readlane((int)w, H + 1));
-    h.rank = (uint32_t)__builtin_amdgcn_readlane((int)w, H + 2);
-    h.idx = (uint32_t)__builtin_amdgcn_readlane((int)w, H + 3);
-    DA_GLOBAL uint16_t *cnt = blk_cnt(c, slot);
-    unsigned long long best = 0;
-    int alive = 0;
-    for (int k0 = 0; k0 < c.K; k0 += WAVE) {  // at most two rounds (K <= 118); one when DIRECT
-        const int k = k0 + lane;
-        const uint32_t v = DIRECT ? w : (uint32_t)__shfl((int)w, 4 + (k >> 1));
-        if (k < c.K) {
-            const uint32_t old = (k & 1) ? (v >> 16) : (v & 0xFFFFu);
-            const uint32_t n = old - d[k];
-            if (n != old) cnt[k] = (uint16_t)n;
-            alive |= n >= 2;
-            const uint32_t r = entry_rank(n, h.ov, h.dl, c.method);
-            const unsigned long long cand = r ? (((unsigned long long)r << 8) | (unsigned)k) : 0ull;
-            best = cand > best ? cand : best;
-        }
-    }
-    best = wave_max_u64(best);
-    alive = __any(alive);
-    if (lane == 0) block_commit(c, slot, key, h, best, alive);
-}
-
-__device__ __forceinline__ unsigned long long uniform64(unsigned long long v) {  // a value all lanes agree on, made wave-uniform for the compiler
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
-    return ((unsigned long long)hi << 32) | lo;
-}
 constexpr int SLOT_NONE = -1, SLOT_SLOW = -2;  // no such block / to be searched beyond its first bucket
+
+// ------------------------------------------------------------------------------------------------ k_iter_update (quad)
+// The greedy loop is bound by VALU issue, not by memory: one wavefront per partner row executed ~260 vector and ~185
+// scalar instructions per partner with a handful of lanes doing useful work (PMC: profiles/r02_*).  Here a partner row is
+// handled by a 16-LANE GROUP -- one DPP row -- and a wavefront works on FOUR partners at once with one instruction
+// stream: a key bucket is 16 slots = one load per lane, a typical row list has <= 16 entries, the K <= 32 counts of a
+// block are 16 words = one word (two counts) per lane, and the reductions stay inside the DPP row.  Everything that was
+// wave-uniform per partner (slots, keys, hashes) is now a per-lane value, identical across the lanes of a group.
+// Rare cases (key not in its first bucket, block creation) fall back to the wave-wide table functions, one group at a time.
+constexpr int QG = 16, QN = WAVE / QG;  // lanes per partner, partners per wavefront
+
+__device__ __forceinline__ unsigned long long row_max_u64(unsigned long long v) {  // max over each 16-lane row, valid in lane 15 of the row
+    v = dpp_max_u64<DPP_ROW_SHR1, 0xF>(v);
+    v = dpp_max_u64<DPP_ROW_SHR2, 0xF>(v);
+    v = dpp_max_u64<DPP_ROW_SHR4, 0xF>(v);
+    v = dpp_max_u64<DPP_ROW_SHR8, 0xF>(v);
+    return v;
+}
 
 template <class Cell>
 __global__ void __launch_bounds__(UPD_THREADS, DA_UPD_OCC) __attribute__((amdgpu_num_sgpr(DA_UPD_SGPRS))) k_iter_update(ChainDev *chains) {
     using F = RowFmt<Cell>;
     using Entry = typename F::Entry;
-    constexpr int PB = UPD_BATCH;
-    constexpr bool DIRECT = sizeof(Cell) == 4;  // narrow layout: K <= 46 counts, one payload word per lane without a shuffle
+    constexpr int QCW = sizeof(Cell) == 4 ? 2 : 4;  // count words per lane: narrow layout Kpad / 2 <= 24 words, wide <= 60
     ChainDev *g = &chains[blockIdx.y];
     if (g->done) return;
     const int n_partners = g->n_partners;
     if (n_partners == 0) return;
     const Ctx c = make_ctx(g, 2 * g->iter - 1);
-    const int m = g->m, nb = c.n_bits, Kpad = c.Kpad, n_out = c.n_out;
+    const int m = g->m, nb = c.n_bits, Kpad = c.Kpad, n_out = c.n_out, K = c.K;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // LDS: consumed digits of A [n_out] and B [n_out] | per-wave references
-    // [UPD_WAVES][PB] | per-wave, per-partner counters [UPD_WAVES][PB][3][Kpad] | per-wave slots [UPD_WAVES][2 PB] |
-    // column -> 1 + index of the substituted column, 0 = not substituted [n_out]
+    // LDS: consumed digits of A [n_out] and B [n_out] | per-wave, per-partner counters [UPD_WAVES][QN][3][Kpad] | the
+    // substituted columns [n_out] | column -> 1 + index of the substituted column, 0 = not substituted [n_out]
     Cell *s_mA = reinterpret_cast<Cell *>(smem);
     Cell *s_mB = s_mA + n_out;
-    unsigned long long *s_ref = reinterpret_cast<unsigned long long *>(s_mB + n_out);
-    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_ref + UPD_WAVES * PB);
-    int *s_slot = reinterpret_cast<int *>(s_cnt + (size_t)UPD_WAVES * PB * 3 * Kpad);
-    int *s_col = s_slot + UPD_WAVES * 2 * PB;  // [n_out] the substituted columns (their order is the order of mA / mB)
+    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_mB + n_out);
+    int *s_col = reinterpret_cast<int *>(s_cnt + (size_t)UPD_WAVES * QN * 3 * Kpad);
     uint16_t *s_cmap = reinterpret_cast<uint16_t *>(s_col + n_out);
     const int tid = threadIdx.x, lane = lane_id(), wid = wave_id();
     for (int j = tid; j < n_out; j += UPD_THREADS) s_cmap[j] = 0;
@@ -1221,194 +1187,154 @@ __global__ void __launch_bounds__(UPD_THREADS, DA_UPD_OCC) __attribute__((amdgpu
     __syncthreads();
     const uint32_t A = g->A, B = g->B, Nw = g->Nw;
     const bool same = A == B;
+    const int n_in = g->n_in;
     const DA_GLOBAL Entry *rl = (const DA_GLOBAL Entry *)g->rlist;
     const DA_GLOBAL unsigned long long *plist = (const DA_GLOBAL unsigned long long *)g->plist;
     const RowInfo rnew = load_row(c.rows, Nw);
-    uint32_t *wcnt = s_cnt + (size_t)wid * PB * 3 * Kpad;
-    unsigned long long *wref = s_ref + wid * PB;
-    int *wslot = s_slot + wid * 2 * PB;
-    const int nwords = 4 + Kpad / 2;  // 32-bit words of a payload line in use (<= 64)
+    const int q = lane >> 4, l = lane & (QG - 1), qsh = q * QG;
+    uint32_t *dA = s_cnt + ((size_t)wid * QN + q) * 3 * Kpad, *dB = dA + Kpad, *cN = dB + Kpad;  // this group's counters
+    const int KW = Kpad / 2;  // 32-bit words of counts per block (two u16 counts each)
     unsigned int partners = 0, found = 0, inserts = 0;
     UPD_TIMER_DECL
-    // Partner q of the list goes to wave q mod total_waves: the expensive partners (the dense input rows at the head of
-    // the list) spread over all waves.  A wave's partners are processed in batches of PB.
+    // partner p of the list: pass p / (QN total_waves), wave (p / QN) mod total_waves, group p mod QN -- all groups of all
+    // waves are busy except in the last pass
+#ifndef DA_UPD_CH
+#define DA_UPD_CH 4  // measured on MI355X (C3 batch 64): 1 -> 52.7, 2 -> 53.8, 4 -> 54.5 solves/s
+#endif
+    constexpr int CH = DA_UPD_CH;  // list chunks (16 entries each) fetched together; longer lists continue in the loop below
     const int total_waves = (int)gridDim.x * UPD_WAVES, gw = (int)blockIdx.x * UPD_WAVES + wid;
-    const int mine = gw < n_partners ? (n_partners - 1 - gw) / total_waves + 1 : 0;
-    const int n_in = g->n_in;
-    const bool second = lane >= (int)BUCKET;
-    const bool probing = lane < (int)BUCKET || (!same && lane < 2 * (int)BUCKET);
-    for (int b0 = 0; b0 < mine; b0 += PB) {
-        const int nbat = min(PB, mine - b0);
-        partners += (unsigned)nbat;
-        // ---- round trip 1: the references of the batch
-        const unsigned long long myref = lane < nbat ? plist[gw + (size_t)(b0 + lane) * total_waves] : 0ull;
-        if (lane < PB) wref[lane] = myref;
-        // ---- round trip 2: every partner's list head (lane = entry) and its two key buckets (lanes 0-15: block with A,
-        // lanes 16-31: block with B), all in flight together
-        unsigned long long kk[PB];
-        uint32_t hb[PB];  // first slot of the key bucket this lane's half probes (lanes 0-15: block with A, 16-31: with B)
-        Entry e[PB];
+    for (int base = gw * QN; base < n_partners; base += total_waves * QN) {
+        const int idx = base + q;
+        const bool valid = idx < n_partners;
+        partners += (unsigned)min(QN, n_partners - base);
+        // ---- round trip 1: the group's partner reference
+        const unsigned long long ref = valid ? plist[idx] : 0ull;
+        const uint32_t pr = ref_row(ref), off = ref_off(ref);
+        const bool dense = valid && (int)pr < n_in;  // dense input row: entry j is column j -- fetch the substituted columns only
+        const int cnt = !valid ? 0 : dense ? m : (int)ref_len(ref);
+        // ---- round trip 2: the two key buckets (16 slots = one per lane) and the head of the row list
+        const uint32_t lA = min(A, pr), hA = max(A, pr), lB = min(B, pr), hB = max(B, pr);
+        const unsigned long long keyA = pack_pair(lA, hA), keyB = pack_pair(lB, hB);
+        const uint32_t baseA = (hash_pair(lA, hA) & ~(BUCKET - 1)) & c.cmask, baseB = (hash_pair(lB, hB) & ~(BUCKET - 1)) & c.cmask;
+        const unsigned long long kA = valid ? c.hkey[baseA + l] : KEY_TOMB;
+        const unsigned long long kB = (valid && !same) ? c.hkey[baseB + l] : KEY_TOMB;
+        Entry e[CH];
 #pragma unroll
-        for (int p = 0; p < PB; ++p) {
-            const unsigned long long ref = bcast64(myref, p);
-            e[p] = F::none();
-            kk[p] = KEY_TOMB;
-            hb[p] = 0;
-            if (p < nbat) {
-                const uint32_t row = ref_row(ref);
-                if ((int)row < n_in) {  // dense input row: entry j is column j -- fetch the substituted columns only
-                    if (lane < m) e[p] = rl[(size_t)ref_off(ref) + s_col[lane]];
-                } else if (lane < (int)ref_len(ref))
-                    e[p] = rl[(size_t)ref_off(ref) + lane];
-                const uint32_t other = second ? B : A;
-                hb[p] = (hash_pair(min(other, row), max(other, row)) & ~(BUCKET - 1)) & c.cmask;
-                if (probing) kk[p] = c.hkey[hb[p] + (lane & (BUCKET - 1))];
+        for (int u = 0; u < CH; ++u) {
+            const int j = l + u * QG;
+            e[u] = j < cnt ? rl[(size_t)off + (dense ? s_col[j] : j)] : F::none();
+        }
+        for (int k = l; k < 3 * Kpad; k += QG) dA[k] = 0;  // while the loads are in flight
+        // ---- resolve the probes (per group: 16 bits of the wave ballots)
+        int sA = SLOT_NONE, sB = SLOT_NONE;
+        {
+            const uint32_t hitA = (uint32_t)(__ballot(kA == keyA) >> qsh) & 0xFFFFu, empA = (uint32_t)(__ballot(kA == KEY_EMPTY) >> qsh) & 0xFFFFu;
+            const uint32_t hitB = (uint32_t)(__ballot(kB == keyB) >> qsh) & 0xFFFFu, empB = (uint32_t)(__ballot(kB == KEY_EMPTY) >> qsh) & 0xFFFFu;
+            if (valid) {
+                sA = hitA ? (int)(baseA + (uint32_t)ctz32(hitA)) : (empA ? SLOT_NONE : SLOT_SLOW);
+                if (!same) sB = hitB ? (int)(baseB + (uint32_t)ctz32(hitB)) : (empB ? SLOT_NONE : SLOT_SLOW);
             }
         }
-        for (int k = lane; k < PB * 3 * Kpad; k += WAVE) wcnt[k] = 0;  // while the loads are in flight
-        // ---- resolve the first-bucket probes; round trip 3: the payload lines of the blocks that exist
-        uint32_t wA[PB], wB[PB];
-        bool pw_active;
-        const int pw = payload_word<DIRECT>(lane, c.K, nwords, pw_active);
+        UPD_TIMER_MARK(1)  // reference + list + table probes
+        // ---- round trip 3: the payload lines of the blocks that exist: header (same 16 bytes for the group) + count words
+        const da_i4 z4 = da_i4{0, 0, 0, 0};
+        const da_i4 hdA = sA >= 0 ? *reinterpret_cast<const DA_GLOBAL da_i4 *>(blk_ptr(c, sA)) : z4;
+        const da_i4 hdB = sB >= 0 ? *reinterpret_cast<const DA_GLOBAL da_i4 *>(blk_ptr(c, sB)) : z4;
+        uint32_t wA[QCW], wB[QCW];
 #pragma unroll
-        for (int p = 0; p < PB; ++p) {
-            int sA = SLOT_NONE, sB = SLOT_NONE;
-            if (p < nbat) {
-                const uint32_t pr = ref_row(bcast64(myref, p));
-                const uint32_t lA = min(A, pr), hA = max(A, pr), lB = min(B, pr), hB = max(B, pr);
-                const unsigned long long want = second ? pack_pair(lB, hB) : pack_pair(lA, hA);
-                const unsigned long long hit = __ballot(probing && kk[p] == want), emp = __ballot(probing && kk[p] == KEY_EMPTY);
-                const unsigned long long m0 = 0xFFFFull, m1 = 0xFFFF0000ull;
-                if (hit & m0)
-                    sA = __builtin_amdgcn_readlane((int)hb[p], 0) + (__ffsll((long long)(hit & m0)) - 1);
-                else if (!(emp & m0))
-                    sA = SLOT_SLOW;
-                if (!same) {
-                    if (hit & m1)
-                        sB = __builtin_amdgcn_readlane((int)hb[p], BUCKET) + (__ffsll((long long)(hit & m1)) - 1 - (int)BUCKET);
-                    else if (!(emp & m1))
-                        sB = SLOT_SLOW;
-                }
-            }
-            wA[p] = (sA >= 0 && pw_active) ? reinterpret_cast<const DA_GLOBAL uint32_t *>(blk_ptr(c, sA))[pw] : 0u;
-            wB[p] = (sB >= 0 && pw_active) ? reinterpret_cast<const DA_GLOBAL uint32_t *>(blk_ptr(c, sB))[pw] : 0u;
-            if (lane == 0) {
-                wslot[2 * p] = sA;
-                wslot[2 * p + 1] = sB;
-            }
+        for (int u = 0; u < QCW; ++u) {
+            const int j = l + u * QG;
+            wA[u] = (sA >= 0 && j < KW) ? reinterpret_cast<const DA_GLOBAL uint32_t *>(blk_ptr(c, sA) + 16)[j] : 0u;
+            wB[u] = (sB >= 0 && j < KW) ? reinterpret_cast<const DA_GLOBAL uint32_t *>(blk_ptr(c, sB) + 16)[j] : 0u;
         }
-        UPD_TIMER_MARK(1)  // references + lists + table probes
-        lds_fence();  // counters zero, references and slots readable
-        // ---- digit pairs lost with A's / B's consumed digits and gained with the new row, into the per-partner LDS counters.
-        // All partners of the batch at once: a lane holds (at most) one entry of every partner; it walks the entries of
-        // its own that lie in a substituted column (a bit mask), so the loop runs max-over-lanes(matched entries) times --
-        // two or three -- instead of once per partner with a handful of lanes active.
-        auto pairs_of = [&](int p, Cell x, int at) {  // per-lane p: everything about the partner comes from LDS
+        lds_fence();  // counters are zero
+        // ---- digit pairs lost with A's / B's consumed digits and gained with the new row: a lane per list entry
+        auto pairs_of = [&](const Entry en) {
+            const Cell x = F::cell(en);
+            const int at = x ? (int)s_cmap[F::col(en)] : 0;
+            if (!at) return;  // empty cell, or a column that was not substituted
             const Cell ma = s_mA[at - 1], mb = s_mB[at - 1];
-            const uint32_t pr = ref_row(wref[p]);
-            const int sA = wslot[2 * p], sB = wslot[2 * p + 1];
-            uint32_t *dA = wcnt + (size_t)p * 3 * Kpad, *dB = dA + Kpad, *cN = dB + Kpad;
             if (sA != SLOT_NONE) {
                 for_pairs_part<Cell>(ma, x, A < pr, nb, [&](int k) { atomicAdd(&dA[k], 1u); });
                 if (same) for_pairs_part<Cell>(mb, x, A < pr, nb, [&](int k) { atomicAdd(&dA[k], 1u); });
             }
             if (!same && sB != SLOT_NONE) for_pairs_part<Cell>(mb, x, B < pr, nb, [&](int k) { atomicAdd(&dB[k], 1u); });
-            for_pairs_cross<Cell>(x, ma, nb, [&](int k) { atomicAdd(&cN[k], 1u); });  // no return value: nothing waits for it
+            for_pairs_cross<Cell>(x, ma, nb, [&](int k) { atomicAdd(&cN[k], 1u); });
         };
-        unsigned mine_mask = 0;  // bit p: this lane's entry of partner p lies in a substituted column
 #pragma unroll
-        for (int p = 0; p < PB; ++p)
-            if (F::cell(e[p]) && s_cmap[F::col(e[p])]) mine_mask |= 1u << p;
-        while (__any(mine_mask != 0)) {
-            if (mine_mask) {
-                const int p = __ffs((int)mine_mask) - 1;
-                mine_mask &= mine_mask - 1;
-                Entry en = e[0];
-#pragma unroll
-                for (int q = 1; q < PB; ++q) en = p == q ? e[q] : en;
-                pairs_of(p, F::cell(en), (int)s_cmap[F::col(en)]);
-            }
-        }
-        // rows with more than 64 entries (created by the early, wide substitutions) / more than 64 substituted columns
-        // of a dense input row: the rest of the list, one partner at a time
-        unsigned gotnew = 0, slow = 0;
-        for (int p = 0; p < nbat; ++p) {
-            const unsigned long long ref = uniform64(wref[p]);
-            const bool dense = (int)ref_row(ref) < n_in;
-            const int cnt = dense ? m : (int)ref_len(ref);
-            const int sA = __builtin_amdgcn_readfirstlane(wslot[2 * p]), sB = __builtin_amdgcn_readfirstlane(wslot[2 * p + 1]);
-            if (sA == SLOT_SLOW || sB == SLOT_SLOW) slow |= 1u << p;
-            if (cnt <= WAVE) continue;
-            const DA_GLOBAL Entry *rowR = rl + (size_t)ref_off(ref);
-            for (int j = WAVE + lane; j < cnt; j += WAVE) {
-                const Entry en = rowR[dense ? s_col[j] : j];
-                const Cell x = F::cell(en);
-                if (!x) continue;
-                const int at = (int)s_cmap[F::col(en)];
-                if (at) pairs_of(p, x, at);
-            }
-        }
+        for (int u = 0; u < CH; ++u)
+            if (__any(u * QG < cnt)) pairs_of(e[u]);  // e[u] is empty beyond the list
+        for (int j = l + CH * QG; __any(j < cnt); j += QG)
+            if (j < cnt) pairs_of(rl[(size_t)off + (dense ? s_col[j] : j)]);
         lds_fence();
-        // a block (partner, new row) is created when one of its counts reached 2: one scan of the counters per partner
-#pragma unroll
-        for (int p = 0; p < PB; ++p) {
-            if (p < nbat) {
-                const uint32_t *cN = wcnt + ((size_t)p * 3 + 2) * Kpad;
-                int f = 0;
-                for (int k = lane; k < c.K; k += WAVE) f |= cN[k] >= 2u;
-                if (__any(f)) gotnew |= 1u << p;
-            }
-        }
+        int fnew = 0;  // a block (partner, new row) is created when one of its counts reached 2
+        for (int k = l; k < K; k += QG) fnew |= cN[k] >= 2u;
+        const bool gnew = valid && (((uint32_t)(__ballot(fnew != 0) >> qsh) & 0xFFFFu) != 0);
         UPD_TIMER_MARK(2)  // pair enumeration
-        // ---- re-evaluate the blocks from their prefetched payload lines.  A plain loop (the body is emitted once: the
-        // unrolled form was 12 k instructions); the partner's payload words are picked from the register arrays by
-        // a select chain on the (uniform) loop index.
-        for (int p = 0; p < nbat; ++p) {
-            const int sA = __builtin_amdgcn_readfirstlane(wslot[2 * p]), sB = __builtin_amdgcn_readfirstlane(wslot[2 * p + 1]);
-            if (sA < 0 && sB < 0) continue;
-            uint32_t pa = wA[0], pb = wB[0];
+        // ---- re-evaluate the blocks: two counts per lane and word, reduction inside the DPP row, lane 15 publishes
+        auto apply = [&](int slot, unsigned long long key, const da_i4 &hd, const uint32_t (&w)[QCW], const uint32_t *d) {
+            const bool has = slot >= 0;
+            const int ov = hd.x;
+            const float dl = __int_as_float(hd.y);
+            unsigned long long best = 0;
+            int alive = 0;
 #pragma unroll
-            for (int q = 1; q < PB; ++q) {
-                pa = p == q ? wA[q] : pa;
-                pb = p == q ? wB[q] : pb;
+            for (int u = 0; u < QCW; ++u) {
+                const int j = l + u * QG;
+                if (has && j < KW) {
+                    const uint32_t o0 = w[u] & 0xFFFFu, o1 = w[u] >> 16;
+                    const uint32_t n0 = o0 - d[2 * j], n1 = o1 - d[2 * j + 1];
+                    if (n0 != o0 || n1 != o1) reinterpret_cast<DA_GLOBAL uint32_t *>(blk_ptr(c, slot) + 16)[j] = (n0 & 0xFFFFu) | (n1 << 16);
+                    alive |= (n0 >= 2u) | (n1 >= 2u);
+                    const uint32_t r0 = entry_rank(n0, ov, dl, c.method), r1 = entry_rank(n1, ov, dl, c.method);
+                    const unsigned long long c0 = r0 ? (((unsigned long long)r0 << 8) | (unsigned)(2 * j)) : 0ull;
+                    const unsigned long long c1 = r1 ? (((unsigned long long)r1 << 8) | (unsigned)(2 * j + 1)) : 0ull;
+                    best = c0 > best ? c0 : best;
+                    best = c1 > best ? c1 : best;
+                }
             }
-            const uint32_t pr = ref_row(uniform64(wref[p]));
-            const uint32_t *dA = wcnt + (size_t)p * 3 * Kpad, *dB = dA + Kpad;
-            if (sA >= 0) apply_block<DIRECT>(c, sA, pack_pair(min(A, pr), max(A, pr)), pa, dA);
-            if (sB >= 0) apply_block<DIRECT>(c, sB, pack_pair(min(B, pr), max(B, pr)), pb, dB);
-            found += (sA >= 0) + (sB >= 0);
-        }
+            best = row_max_u64(best);  // all lanes take part (the DPP source lanes must be active); lane 15 of the row holds the result
+            const bool any_alive = (((uint32_t)(__ballot(alive != 0) >> qsh) & 0xFFFFu) != 0);
+            if (has && l == QG - 1) block_commit(c, slot, key, BlkHdr{ov, dl, (uint32_t)hd.z, (uint32_t)hd.w}, best, any_alive);
+        };
+        apply(sA, keyA, hdA, wA, dA);
+        apply(sB, keyB, hdB, wB, dB);
         UPD_TIMER_MARK(3)  // block updates
-        // ---- rare: blocks beyond their first bucket, block creation (one partner at a time, state from LDS)
-        if (slow | gotnew) {
-            for (int p = 0; p < nbat; ++p) {
-                if (!(((slow | gotnew) >> p) & 1u)) continue;
-                const uint32_t pr = ref_row(uniform64(wref[p]));
-                const uint32_t *dA = wcnt + (size_t)p * 3 * Kpad, *dB = dA + Kpad, *cN = dB + Kpad;
-                if (__builtin_amdgcn_readfirstlane(wslot[2 * p]) == SLOT_SLOW) {
-                    const uint32_t lo = min(A, pr), hi = max(A, pr);
+        // ---- rare: blocks beyond their first bucket, block creation -- the whole wave, one group at a time
+        const unsigned long long rare = __ballot(valid && (sA == SLOT_SLOW || sB == SLOT_SLOW || gnew));
+        found += (unsigned)__popcll(__ballot(l == 0 && sA >= 0)) + (unsigned)__popcll(__ballot(l == 0 && sB >= 0));
+        if (rare) {
+#pragma unroll 1
+            for (int qq = 0; qq < QN; ++qq) {  // a plain loop: the wave-wide table functions are emitted once
+                if (!((rare >> (qq * QG)) & 1ull)) continue;
+                const uint32_t rpr = (uint32_t)__builtin_amdgcn_readlane((int)pr, qq * QG);
+                const int rsA = __builtin_amdgcn_readlane(sA, qq * QG), rsB = __builtin_amdgcn_readlane(sB, qq * QG);
+                const int rnewb = __builtin_amdgcn_readlane((int)gnew, qq * QG);
+                const uint32_t *rdA = s_cnt + ((size_t)wid * QN + qq) * 3 * Kpad, *rdB = rdA + Kpad, *rcN = rdB + Kpad;
+                if (rsA == SLOT_SLOW) {
+                    const uint32_t lo = min(A, rpr), hi = max(A, rpr);
                     const int slot = table_find_from(c, pack_pair(lo, hi), hash_pair(lo, hi), 1);
                     if (slot >= 0) {
-                        table_update(c, slot, pack_pair(lo, hi), [&](int k, uint32_t old) { return old - dA[k]; });
+                        table_update(c, slot, pack_pair(lo, hi), [&](int k, uint32_t old) { return old - rdA[k]; });
                         ++found;
                     }
                 }
-                if (__builtin_amdgcn_readfirstlane(wslot[2 * p + 1]) == SLOT_SLOW) {
-                    const uint32_t lo = min(B, pr), hi = max(B, pr);
+                if (rsB == SLOT_SLOW) {
+                    const uint32_t lo = min(B, rpr), hi = max(B, rpr);
                     const int slot = table_find_from(c, pack_pair(lo, hi), hash_pair(lo, hi), 1);
                     if (slot >= 0) {
-                        table_update(c, slot, pack_pair(lo, hi), [&](int k, uint32_t old) { return old - dB[k]; });
+                        table_update(c, slot, pack_pair(lo, hi), [&](int k, uint32_t old) { return old - rdB[k]; });
                         ++found;
                     }
                 }
-                if ((gotnew >> p) & 1u) {
-                    table_insert(c, pr, Nw, load_row(c.rows, pr), rnew, [&](int k) { return cN[k]; });
+                if (rnewb) {
+                    table_insert(c, rpr, Nw, load_row(c.rows, rpr), rnew, [&](int k) { return rcN[k]; });
                     ++inserts;
                 }
             }
         }
         UPD_TIMER_MARK(4)  // slow path + block creation
-        lds_fence();  // the next batch overwrites the per-wave LDS state
+        lds_fence();  // the next pass overwrites the counters
     }
     UPD_TIMER_FLUSH
     if (lane == 0 && partners) {
@@ -1800,8 +1726,8 @@ struct HipBackend::Impl {
     hipStream_t lanes[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // greedy-loop streams of the chain groups
     int n_lanes = 3;  // + the poll stream = 4 hardware queues
     bool use_graph = false;
-    int upd_total_blocks = 4096;  // k_iter_update blocks over all chains of a batch (4 waves each): 64 per chain at batch 64, i.e. a
-                                  // wave's share of <= 2048 partner rows fits one batch of UPD_BATCH
+    int upd_total_blocks = 2560;  // k_iter_update blocks over all chains of a batch (4 waves x 4 groups each); measured (C3 batch 64,
+                                  // solves/s): 1024: 45.3, 1536: 53.3, 2048: 53.8, 2560: 55.5, 4096: 47.5
     bool mt_launch = false;
     DeviceBuffer arena, desc_buf, io_buf;
     unsigned int *d_done = nullptr;
@@ -1868,6 +1794,7 @@ size_t carve_chain(unsigned char *base, const ChainJob &job, const Geometry &g, 
     d.gtie = c.take<unsigned long long>(g.n_groups);
     d.gdirty = c.take<uint8_t>(g.n_groups);
     d.mcol = c.take<int>(n_out);
+    d.colin = c.take<int>(n_out);
     d.mA = c.take<unsigned char>(n_out * cell);
     d.mB = c.take<unsigned char>(n_out * cell);
     d.plist = c.take<unsigned long long>(g.rcap);
@@ -2067,10 +1994,10 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
         size_t claim_bytes = ((size_t)geo[i].rcap + 31) / 32 * 4;
         if (claim_bytes > 64 * 1024) claim_bytes = 0;
         const size_t no = (size_t)jobs[i].n_out, cellb = geo[i].wide ? 8 : 4, entb = geo[i].wide ? 16 : 4;
-        size_t s = no * entb + 6 * (size_t)geo[i].Kpad * 4 + (3 * no + 1) * 4 + claim_bytes;
+        size_t s = no * entb + 6 * (size_t)geo[i].Kpad * 4 + (4 * no + 1) * 4 + claim_bytes;
         s = align_up(s, 16);
         sel_lds[w] = std::max(sel_lds[w], s);
-        upd_lds[w] = std::max(upd_lds[w], align_up((size_t)UPD_WAVES * UPD_BATCH * (8 + 3 * (size_t)geo[i].Kpad * 4 + 8) + 2 * no * cellb + no * 6, 16));
+        upd_lds[w] = std::max(upd_lds[w], align_up((size_t)UPD_WAVES * 4 * 3 * (size_t)geo[i].Kpad * 4 + 2 * no * cellb + no * 6, 16));
         pair_lds[w] = std::max(pair_lds[w], (size_t)4 * geo[i].Kpad * 4);
         max_pairs[w] = std::max(max_pairs[w], (long long)jobs[i].n_in * (jobs[i].n_in + 1) / 2);
     }
@@ -2526,7 +2453,7 @@ class HipShardEngine : public ShardEngine {
         else
             hipLaunchKernelGGL(k_init_cells<uint64_t>, colgrid, dim3(256), 0, st_, dd_);
         HIP_CHECK(hipGetLastError());
-        sel_lds_ = align_up((size_t)n_loc_ * (g.wide ? 16 : 4) + 6 * (size_t)g.Kpad * 4 + (3 * (size_t)n_loc_ + 1) * 4 + (size_t)d_.claim_words * 4, 16);
+        sel_lds_ = align_up((size_t)n_loc_ * (g.wide ? 16 : 4) + 6 * (size_t)g.Kpad * 4 + (4 * (size_t)n_loc_ + 1) * 4 + (size_t)d_.claim_words * 4, 16);
         if (sel_lds_ > 150 * 1024) throw std::runtime_error("selection kernel needs more than 150 KiB of LDS");
         if (!g.wide)
             HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_iter_select<uint32_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sel_lds_));

@@ -20,6 +20,16 @@ def host_cores() -> int:
         return os.cpu_count() or 1
 
 
+def mem_available_gb() -> float:
+    try:
+        for line in open('/proc/meminfo'):
+            if line.startswith('MemAvailable:'):
+                return int(line.split()[1]) / 1048576.0
+    except OSError:
+        pass
+    return 16.0
+
+
 def _matrix(n_in, n_out, seed):
     import numpy as np
 
