@@ -632,7 +632,9 @@ template <class Cell, bool SHARDED = false> __global__ void __launch_bounds__(SE
     int *s_col = s_len + n_out + 1;                                                   // [n_out] matched columns
     int *s_bpos = s_col + n_out;                                                      // [n_out] 1 + position of a column in B's list, 0 = absent
     int *s_cin = s_bpos + n_out;                                                      // [n_out] input rows at the head of a matched column's list
-    uint32_t *s_bits = reinterpret_cast<uint32_t *>(s_cin + n_out);                  // [claim_words] rows already claimed (if it fits)
+    int *s_clen = s_cin + n_out;                                                      // [n_out] list length of every column (fetched while the arg-max runs)
+    int *s_cinall = s_clen + n_out;                                                   // [n_out] input rows at the head of every column's list
+    uint32_t *s_bits = reinterpret_cast<uint32_t *>(s_cinall + n_out);               // [claim_words] rows already claimed (if it fits)
     const int claim_words = g->claim_words;
     constexpr int NW = SEL_THREADS / WAVE;
     __shared__ unsigned long long s_red_tie[NW], s_floor0, s_floor;
@@ -667,6 +669,12 @@ template <class Cell, bool SHARDED = false> __global__ void __launch_bounds__(SE
         s_np = 0;
         s_floor0 = 0;
     }
+    // the list lengths of all columns: needed for the matched columns only, after the substitution -- fetched now, off the
+    // critical path, so that no dependent load is left there
+    for (int j = tid; j < n_out; j += SEL_THREADS) {
+        s_clen[j] = ((const DA_GLOBAL int *)g->collen)[j];
+        s_cinall[j] = SHARDED ? 0 : ((const DA_GLOBAL int *)g->colin)[j];
+    }
     const int GPW = (n_groups + NW - 1) / NW;  // groups per wave, <= 4 * WAVE
     unsigned long long ubr[4];
     int dr[4];  // 0 clean on entry, 1 dirty, 2 verified in this call, 3 absent
@@ -695,6 +703,9 @@ template <class Cell, bool SHARDED = false> __global__ void __launch_bounds__(SE
         unsigned int rescans = 0;
         DA_GLOBAL unsigned long long *gtie_arr = (DA_GLOBAL unsigned long long *)g->gtie;
         while (true) {
+            // the wave's TWO highest dirty groups are re-read together (their loads in flight at the same time): the second
+            // one would usually be next anyway, and an unnecessary re-read only leaves a group clean
+            const unsigned long long fl = __hip_atomic_load(&s_floor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // ds_read_b64, not a FLAT load
             unsigned long long top = 0;
             int top_u = 0;
 #pragma unroll
@@ -704,60 +715,88 @@ template <class Cell, bool SHARDED = false> __global__ void __launch_bounds__(SE
                     top_u = u;
                 }
             const unsigned long long wtop = wave_max_u64(top);
-            if (wtop == 0 || wtop < __hip_atomic_load(&s_floor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;  // ds_read_b64, not a FLAT load
-            const unsigned long long who = __ballot(top == wtop);
-            const int owner = __ffsll((long long)who) - 1;
-            const int own_u = __shfl(top_u, owner);
-            const uint32_t grp = (uint32_t)(wid * GPW + owner + own_u * WAVE);
-            const uint32_t base = grp * gs;
-            uint32_t rk[8];
-            uint32_t grank = 0;
+            if (wtop == 0 || wtop < fl) break;
+            int owner[2], own_u[2];
+            owner[0] = __ffsll((long long)__ballot(top == wtop)) - 1;
+            own_u[0] = __builtin_amdgcn_readlane(top_u, owner[0]);
+            unsigned long long top2 = 0;
+            int top2_u = 0;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                int o = lane + u * WAVE;
-                rk[u] = o < gs ? c.hrank[base + o] : 0u;
-                grank = max(grank, rk[u]);
-            }
-            for (int o = lane + 8 * WAVE; o < gs; o += WAVE) grank = max(grank, c.hrank[base + o]);
-            grank = wave_max_u32(grank);
-            unsigned long long gt = 0;
-            if (grank) {
+            for (int u = 0; u < 4; ++u)
+                if (dr[u] == 1 && !(lane == owner[0] && u == own_u[0]) && ubr[u] > top2) {
+                    top2 = ubr[u];
+                    top2_u = u;
+                }
+            const unsigned long long wtop2 = wave_max_u64(top2);
+            const int n_re = (wtop2 != 0 && wtop2 >= fl) ? 2 : 1;
+            owner[1] = n_re == 2 ? __ffsll((long long)__ballot(top2 == wtop2)) - 1 : 0;
+            own_u[1] = n_re == 2 ? __builtin_amdgcn_readlane(top2_u, owner[1]) : 0;
+            uint32_t grp[2], base[2], rk[2][8], grank[2] = {0, 0};
+            unsigned long long gt[2] = {0, 0};
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                grp[r] = (uint32_t)(wid * GPW + owner[r] + own_u[r] * WAVE);
+                base[r] = grp[r] * gs;
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    int o = lane + u * WAVE;
-                    if (o < gs && rk[u] == grank) {
-                        unsigned long long kk = c.hkey[base + o];
-                        unsigned long long tw = tie_word((uint32_t)kk, (uint32_t)(kk >> 32), (int)load_best_idx(c, base + o));
-                        gt = tw > gt ? tw : gt;
-                    }
+                    const int o = lane + u * WAVE;
+                    rk[r][u] = (r < n_re && o < gs) ? c.hrank[base[r] + o] : 0u;
                 }
-                for (int o = lane + 8 * WAVE; o < gs; o += WAVE)
-                    if (c.hrank[base + o] == grank) {
-                        unsigned long long kk = c.hkey[base + o];
-                        unsigned long long tw = tie_word((uint32_t)kk, (uint32_t)(kk >> 32), (int)load_best_idx(c, base + o));
-                        gt = tw > gt ? tw : gt;
-                    }
-                gt = wave_max_u64(gt);
             }
-            const unsigned long long exact = grank ? bound_word(grank, gt) : 0ull;
-            if (lane == owner) {  // no writer races with this kernel: bound and tie are exact, the group is clean again
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    if (u == own_u) {
-                        ubr[u] = exact;
-                        dr[u] = 2;
+            for (int r = 0; r < 2; ++r) {
+                if (r < n_re) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) grank[r] = max(grank[r], rk[r][u]);
+                    for (int o = lane + 8 * WAVE; o < gs; o += WAVE) grank[r] = max(grank[r], c.hrank[base[r] + o]);
+                }
+                grank[r] = wave_max_u32(grank[r]);
+            }
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                if (grank[r]) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int o = lane + u * WAVE;
+                        if (o < gs && rk[r][u] == grank[r]) {
+                            const unsigned long long kk = c.hkey[base[r] + o];
+                            const unsigned long long tw = tie_word((uint32_t)kk, (uint32_t)(kk >> 32), (int)load_best_idx(c, base[r] + o));
+                            gt[r] = tw > gt[r] ? tw : gt[r];
+                        }
                     }
-                c.ub[grp] = exact;
-                gtie_arr[grp] = gt;
-                c.gdirty[grp] = 0;
-                if (exact) atomicMax(&s_floor, exact);
+                    for (int o = lane + 8 * WAVE; o < gs; o += WAVE)
+                        if (c.hrank[base[r] + o] == grank[r]) {
+                            const unsigned long long kk = c.hkey[base[r] + o];
+                            const unsigned long long tw = tie_word((uint32_t)kk, (uint32_t)(kk >> 32), (int)load_best_idx(c, base[r] + o));
+                            gt[r] = tw > gt[r] ? tw : gt[r];
+                        }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                gt[r] = wave_max_u64(gt[r]);
+                if (r < n_re) {
+                    const unsigned long long exact = grank[r] ? bound_word(grank[r], gt[r]) : 0ull;
+                    if (lane == owner[r]) {  // no writer races with this kernel: bound and tie are exact, the group is clean again
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            if (u == own_u[r]) {
+                                ubr[u] = exact;
+                                dr[u] = 2;
+                            }
+                        c.ub[grp[r]] = exact;
+                        gtie_arr[grp[r]] = gt[r];
+                        c.gdirty[grp[r]] = 0;
+                        if (exact) atomicMax(&s_floor, exact);
+                    }
+                    if (grank[r] > wrank || (grank[r] == wrank && gt[r] > wtie)) {
+                        wrank = grank[r];
+                        wtie = gt[r];
+                    }
+                    ++rescans;
+                }
             }
             lds_fence();
-            if (grank > wrank || (grank == wrank && gt > wtie)) {
-                wrank = grank;
-                wtie = gt;
-            }
-            ++rescans;
         }
         // groups that were clean on entry and tie the floor: their stored tie word decides
         if (floor0) {
@@ -861,9 +900,6 @@ template <class Cell, bool SHARDED = false> __global__ void __launch_bounds__(SE
             s_bpos[F::col(e)] = t + 1;
         }
     }
-    const int clen0 = tid < lenA ? collen[F::col(eA0)] : 0;  // pre-append list length of this thread's column (used if it matches)
-    // ... and how many of them are input rows: those are made partners wholesale below, only the tail of the list is claimed
-    const int cin0 = (!SHARDED && tid < lenA) ? ((DA_GLOBAL int *)g->colin)[F::col(eA0)] : 0;
     __syncthreads();
     tp[3] = clock64();
     DA_GLOBAL Cell *mA = (DA_GLOBAL Cell *)g->mA, *mB = (DA_GLOBAL Cell *)g->mB;
@@ -913,8 +949,8 @@ template <class Cell, bool SHARDED = false> __global__ void __launch_bounds__(SE
             mcol[at] = (int)colA;
             mA[at] = ma;
             mB[at] = mb;
-            s_len[at] = t0 == 0 ? clen0 : collen[colA];  // the pre-append length: the new row itself is not a partner
-            s_cin[at] = SHARDED ? 0 : (t0 == 0 ? cin0 : ((DA_GLOBAL int *)g->colin)[colA]);
+            s_len[at] = s_clen[colA];  // the pre-append length: the new row itself is not a partner
+            s_cin[at] = s_cinall[colA];  // how many of them are input rows: those are made partners wholesale, only the tail is claimed
             s_col[at] = (int)colA;
             my_matches += popc32(O::plus(ma) | O::minus(ma));
         }
@@ -1994,7 +2030,7 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
         size_t claim_bytes = ((size_t)geo[i].rcap + 31) / 32 * 4;
         if (claim_bytes > 64 * 1024) claim_bytes = 0;
         const size_t no = (size_t)jobs[i].n_out, cellb = geo[i].wide ? 8 : 4, entb = geo[i].wide ? 16 : 4;
-        size_t s = no * entb + 6 * (size_t)geo[i].Kpad * 4 + (4 * no + 1) * 4 + claim_bytes;
+        size_t s = no * entb + 6 * (size_t)geo[i].Kpad * 4 + (6 * no + 1) * 4 + claim_bytes;
         s = align_up(s, 16);
         sel_lds[w] = std::max(sel_lds[w], s);
         upd_lds[w] = std::max(upd_lds[w], align_up((size_t)UPD_WAVES * 4 * 3 * (size_t)geo[i].Kpad * 4 + 2 * no * cellb + no * 6, 16));
@@ -2453,7 +2489,7 @@ class HipShardEngine : public ShardEngine {
         else
             hipLaunchKernelGGL(k_init_cells<uint64_t>, colgrid, dim3(256), 0, st_, dd_);
         HIP_CHECK(hipGetLastError());
-        sel_lds_ = align_up((size_t)n_loc_ * (g.wide ? 16 : 4) + 6 * (size_t)g.Kpad * 4 + (4 * (size_t)n_loc_ + 1) * 4 + (size_t)d_.claim_words * 4, 16);
+        sel_lds_ = align_up((size_t)n_loc_ * (g.wide ? 16 : 4) + 6 * (size_t)g.Kpad * 4 + (6 * (size_t)n_loc_ + 1) * 4 + (size_t)d_.claim_words * 4, 16);
         if (sel_lds_ > 150 * 1024) throw std::runtime_error("selection kernel needs more than 150 KiB of LDS");
         if (!g.wide)
             HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_iter_select<uint32_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sel_lds_));
