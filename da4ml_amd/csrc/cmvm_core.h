@@ -252,6 +252,14 @@ DA_HD uint32_t entry_rank(uint32_t count, int ov, float dl, int method) {
     switch (method) {
     case M_MC: return count + 1;
     case M_WMC: {
+#if defined(__HIP_DEVICE_COMPILE__)
+        // counts are stored as u16 and |ov| < 2^7: the product fits 32 bits (the 64-bit multiply was four vector
+        // instructions, eight times per partner pass)
+        if (count <= 0xFFFFu) {
+            const int32_t s32 = (int32_t)count * ov;
+            return s32 >= 0 ? (uint32_t)s32 + 1 : 0;
+        }
+#endif
         int64_t s = (int64_t)count * ov;
         return s >= 0 ? (uint32_t)s + 1 : 0;
     }

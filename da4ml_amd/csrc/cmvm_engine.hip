@@ -176,6 +176,7 @@ struct ChainDev {
     // per-iteration hand-off select -> update
     int *mcol;
     int *colin;        // [n_out] number of INPUT rows at the head of each column list (fixed after k_init_cells)
+    uint16_t *cmap;    // [n_out] 1 + index of a column among the substituted columns of this step, 0 = not substituted
     void *mA, *mB;
     unsigned long long *plist;
     int m, n_partners;
@@ -266,14 +267,18 @@ __device__ __forceinline__ void lds_fence() {
     __builtin_amdgcn_wave_barrier();
 }
 
+// Slot hash of a row pair.  32-bit arithmetic only: since the partner rows moved from wavefronts to 16-lane groups the
+// hash is computed in vector registers (twice per group and pass), and the 64-bit multiplies of a 64-bit finaliser were
+// ~15 % of the update kernel's vector instructions.  Two odd multipliers combine the ids, then the "lowbias32" finaliser;
+// the placement of a block never influences a result, only probe lengths.
 __device__ __forceinline__ uint32_t hash_pair(uint32_t lo, uint32_t hi) {
-    unsigned long long k = ((unsigned long long)hi << 32) | lo;
-    k ^= k >> 33;
-    k *= 0xff51afd7ed558ccdULL;
-    k ^= k >> 33;
-    k *= 0xc4ceb9fe1a85ec53ULL;
-    k ^= k >> 33;
-    return (uint32_t)k;
+    uint32_t h = lo * 0x9E3779B1u + hi * 0x85EBCA77u;
+    h ^= h >> 16;
+    h *= 0x7FEB352Du;
+    h ^= h >> 15;
+    h *= 0x846CA68Bu;
+    h ^= h >> 16;
+    return h;
 }
 __device__ __forceinline__ unsigned long long pack_pair(uint32_t lo, uint32_t hi) {
     return ((unsigned long long)hi << 32) | lo;
@@ -634,7 +639,8 @@ template <class Cell, bool SHARDED = false> __global__ void __launch_bounds__(SE
     int *s_cin = s_bpos + n_out;                                                      // [n_out] input rows at the head of a matched column's list
     int *s_clen = s_cin + n_out;                                                      // [n_out] list length of every column (fetched while the arg-max runs)
     int *s_cinall = s_clen + n_out;                                                   // [n_out] input rows at the head of every column's list
-    uint32_t *s_bits = reinterpret_cast<uint32_t *>(s_cinall + n_out);               // [claim_words] rows already claimed (if it fits)
+    int *s_cm = s_cinall + n_out;                                                     // [n_out] 1 + index among the matched columns, 0 = not matched
+    uint32_t *s_bits = reinterpret_cast<uint32_t *>(s_cm + n_out);                   // [claim_words] rows already claimed (if it fits)
     const int claim_words = g->claim_words;
     constexpr int NW = SEL_THREADS / WAVE;
     __shared__ unsigned long long s_red_tie[NW], s_floor0, s_floor;
@@ -642,6 +648,7 @@ template <class Cell, bool SHARDED = false> __global__ void __launch_bounds__(SE
     __shared__ uint32_t s_best_rank;
     __shared__ unsigned long long s_best_tie;
     __shared__ int s_np, s_part[NW];
+    __shared__ unsigned int s_matches;
     __shared__ RowInfo s_new;
 
     const int tid = threadIdx.x, lane = lane_id(), wid = wave_id();
@@ -667,6 +674,7 @@ template <class Cell, bool SHARDED = false> __global__ void __launch_bounds__(SE
         s_best_rank = 0;
         s_best_tie = 0;
         s_np = 0;
+        s_matches = 0;
         s_floor0 = 0;
     }
     // the list lengths of all columns: needed for the matched columns only, after the substitution -- fetched now, off the
@@ -674,6 +682,7 @@ template <class Cell, bool SHARDED = false> __global__ void __launch_bounds__(SE
     for (int j = tid; j < n_out; j += SEL_THREADS) {
         s_clen[j] = ((const DA_GLOBAL int *)g->collen)[j];
         s_cinall[j] = SHARDED ? 0 : ((const DA_GLOBAL int *)g->colin)[j];
+        s_cm[j] = 0;
     }
     const int GPW = (n_groups + NW - 1) / NW;  // groups per wave, <= 4 * WAVE
     unsigned long long ubr[4];
@@ -702,6 +711,19 @@ template <class Cell, bool SHARDED = false> __global__ void __launch_bounds__(SE
         unsigned long long wtie = 0;
         unsigned int rescans = 0;
         DA_GLOBAL unsigned long long *gtie_arr = (DA_GLOBAL unsigned long long *)g->gtie;
+        // groups that were clean on entry and tie the floor: their stored tie word decides -- fetched now, in flight while
+        // the dirty groups are re-read
+        unsigned long long clean_tie = 0;
+        bool clean_any = false;
+        if (floor0) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (dr[u] == 0 && ubr[u] == floor0) {
+                    const unsigned long long t = gtie_arr[wid * GPW + lane + u * WAVE];
+                    clean_tie = t > clean_tie ? t : clean_tie;
+                    clean_any = true;
+                }
+        }
         while (true) {
             // the wave's TWO highest dirty groups are re-read together (their loads in flight at the same time): the second
             // one would usually be next anyway, and an unnecessary re-read only leaves a group clean
@@ -798,19 +820,9 @@ template <class Cell, bool SHARDED = false> __global__ void __launch_bounds__(SE
             }
             lds_fence();
         }
-        // groups that were clean on entry and tie the floor: their stored tie word decides
         if (floor0) {
-            unsigned long long ct = 0;
-            bool any = false;
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (dr[u] == 0 && ubr[u] == floor0) {
-                    unsigned long long t = gtie_arr[wid * GPW + lane + u * WAVE];
-                    ct = t > ct ? t : ct;
-                    any = true;
-                }
-            ct = wave_max_u64(ct);
-            if (__any(any)) {
+            const unsigned long long ct = wave_max_u64(clean_tie);
+            if (__any(clean_any)) {
                 const uint32_t r0 = (uint32_t)(floor0 >> 32);
                 if (r0 > wrank || (r0 == wrank && ct > wtie)) {
                     wrank = r0;
@@ -824,16 +836,15 @@ template <class Cell, bool SHARDED = false> __global__ void __launch_bounds__(SE
             if (rescans) atomicAdd(&g->st_rescans, (unsigned long long)rescans);
         }
         __syncthreads();
-        if (tid == 0) {
-            uint32_t br = 0;
-            unsigned long long bt = 0;
-            for (int w = 0; w < NW; ++w)
-                if (s_red_rank[w] > br || (s_red_rank[w] == br && s_red_tie[w] > bt)) {
-                    br = s_red_rank[w];
-                    bt = s_red_tie[w];
-                }
-            s_best_rank = br;
-            s_best_tie = bt;
+        if (wid == 0) {  // the waves' results, one per lane: highest rank, then highest tie word among its holders
+            const uint32_t r = lane < NW ? s_red_rank[lane] : 0u;
+            const unsigned long long t = lane < NW ? s_red_tie[lane] : 0ull;
+            const uint32_t br = wave_max_u32(r);
+            const unsigned long long bt = wave_max_u64(r == br ? t : 0ull);
+            if (lane == 0) {
+                s_best_rank = br;
+                s_best_tie = bt;
+            }
         }
         __syncthreads();
     }
@@ -949,6 +960,7 @@ template <class Cell, bool SHARDED = false> __global__ void __launch_bounds__(SE
             mcol[at] = (int)colA;
             mA[at] = ma;
             mB[at] = mb;
+            s_cm[colA] = at + 1;
             s_len[at] = s_clen[colA];  // the pre-append length: the new row itself is not a partner
             s_cin[at] = s_cinall[colA];  // how many of them are input rows: those are made partners wholesale, only the tail is claimed
             s_col[at] = (int)colA;
@@ -966,7 +978,7 @@ template <class Cell, bool SHARDED = false> __global__ void __launch_bounds__(SE
         m += chunk;
         __syncthreads();  // s_part is reused by the next chunk; s_bent updates visible to pass 2
     }
-    if (my_matches) atomicAdd(&g->st_matches, (unsigned long long)my_matches);
+    if (my_matches) atomicAdd(&s_matches, my_matches);  // LDS; added to the chain's statistics by thread 0 at the end
     // pass 2: B's list back to memory, self pairs of what is left of B
     if (!same)
         for (int t = tid; t < lenB; t += SEL_THREADS) {
@@ -975,6 +987,8 @@ template <class Cell, bool SHARDED = false> __global__ void __launch_bounds__(SE
             const Cell nbv = F::cell(e);
             if (nbv) for_pairs_self<Cell>(nbv, nb, [&](int k) { atomicAdd(&cBB[k], 1u); });
         }
+    // the map column -> matched index for the update blocks (one coalesced copy; pass 1 has completed: its last barrier)
+    for (int j = tid; j < n_out; j += SEL_THREADS) ((DA_GLOBAL uint16_t *)g->cmap)[j] = (uint16_t)s_cm[j];
     // the new row joins the lists of its columns
     {
         const unsigned long long refN = ref_pack(Nw, (uint32_t)m, offN);
@@ -1148,6 +1162,9 @@ template <class Cell, bool SHARDED = false> __global__ void __launch_bounds__(SE
         g->rl_used = offN + (uint32_t)m;
         g->m = m;
         g->n_partners = s_np;
+        g->st_matches += (unsigned long long)s_matches;
+        g->st_partners += (unsigned long long)s_np;
+        g->st_cells += (unsigned long long)s_np * (unsigned)m;
         g->work_ctr = 0;
         g->A = A;
         g->B = B;
@@ -1207,15 +1224,15 @@ __global__ void __launch_bounds__(UPD_THREADS, DA_UPD_OCC) __attribute__((amdgpu
     int *s_col = reinterpret_cast<int *>(s_cnt + (size_t)UPD_WAVES * QN * 3 * Kpad);
     uint16_t *s_cmap = reinterpret_cast<uint16_t *>(s_col + n_out);
     const int tid = threadIdx.x, lane = lane_id(), wid = wave_id();
-    for (int j = tid; j < n_out; j += UPD_THREADS) s_cmap[j] = 0;
-    __syncthreads();
-    {
+    __shared__ unsigned int s_stat[2];
+    if (tid < 2) s_stat[tid] = 0;
+    {  // the hand-off of k_iter_select into LDS: one pass, one barrier (the column map arrives ready-made)
         const DA_GLOBAL int *mcol = (const DA_GLOBAL int *)g->mcol;
         const DA_GLOBAL Cell *mA = (const DA_GLOBAL Cell *)g->mA, *mB = (const DA_GLOBAL Cell *)g->mB;
+        const DA_GLOBAL uint16_t *cmap = (const DA_GLOBAL uint16_t *)g->cmap;
+        for (int j = tid; j < n_out; j += UPD_THREADS) s_cmap[j] = cmap[j];
         for (int j = tid; j < m; j += UPD_THREADS) {
-            const int col = mcol[j];
-            s_col[j] = col;
-            s_cmap[col] = (uint16_t)(j + 1);
+            s_col[j] = mcol[j];
             s_mA[j] = mA[j];
             s_mB[j] = mB[j];
         }
@@ -1230,7 +1247,7 @@ __global__ void __launch_bounds__(UPD_THREADS, DA_UPD_OCC) __attribute__((amdgpu
     const int q = lane >> 4, l = lane & (QG - 1), qsh = q * QG;
     uint32_t *dA = s_cnt + ((size_t)wid * QN + q) * 3 * Kpad, *dB = dA + Kpad, *cN = dB + Kpad;  // this group's counters
     const int KW = Kpad / 2;  // 32-bit words of counts per block (two u16 counts each)
-    unsigned int partners = 0, found = 0, inserts = 0;
+    unsigned int found = 0, inserts = 0;
     UPD_TIMER_DECL
     // partner p of the list: pass p / (QN total_waves), wave (p / QN) mod total_waves, group p mod QN -- all groups of all
     // waves are busy except in the last pass
@@ -1239,12 +1256,13 @@ __global__ void __launch_bounds__(UPD_THREADS, DA_UPD_OCC) __attribute__((amdgpu
 #endif
     constexpr int CH = DA_UPD_CH;  // list chunks (16 entries each) fetched together; longer lists continue in the loop below
     const int total_waves = (int)gridDim.x * UPD_WAVES, gw = (int)blockIdx.x * UPD_WAVES + wid;
+    unsigned long long ref_next = gw * QN + q < n_partners ? plist[gw * QN + q] : 0ull;
     for (int base = gw * QN; base < n_partners; base += total_waves * QN) {
         const int idx = base + q;
         const bool valid = idx < n_partners;
-        partners += (unsigned)min(QN, n_partners - base);
-        // ---- round trip 1: the group's partner reference
-        const unsigned long long ref = valid ? plist[idx] : 0ull;
+        // ---- round trip 1: the group's partner reference (the next pass's one is fetched now: off the critical path there)
+        const unsigned long long ref = ref_next;
+        ref_next = idx + total_waves * QN < n_partners ? plist[idx + total_waves * QN] : 0ull;
         const uint32_t pr = ref_row(ref), off = ref_off(ref);
         const bool dense = valid && (int)pr < n_in;  // dense input row: entry j is column j -- fetch the substituted columns only
         const int cnt = !valid ? 0 : dense ? m : (int)ref_len(ref);
@@ -1373,11 +1391,17 @@ __global__ void __launch_bounds__(UPD_THREADS, DA_UPD_OCC) __attribute__((amdgpu
         lds_fence();  // the next pass overwrites the counters
     }
     UPD_TIMER_FLUSH
-    if (lane == 0 && partners) {
-        atomicAdd(&g->st_partners, (unsigned long long)partners);
-        atomicAdd(&g->st_cells, (unsigned long long)partners * (unsigned)m);
-        if (found) atomicAdd(&g->st_found, (unsigned long long)found);
-        if (inserts) atomicAdd(&g->st_inserts, (unsigned long long)inserts);
+    // statistics: summed per block in LDS, then ONE pair of device atomics per block.  (Four atomics per wave on one line
+    // of the chain descriptor -- 640 per chain and launch, from all XCDs -- serialise at ~12 ns each and every launch had
+    // to wait for them; the partner / cell counts are added by k_iter_select, which knows them without counting.)
+    if (lane == 0 && (found | inserts)) {
+        if (found) atomicAdd(&s_stat[0], found);
+        if (inserts) atomicAdd(&s_stat[1], inserts);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        if (s_stat[0]) atomicAdd(&g->st_found, (unsigned long long)s_stat[0]);
+        if (s_stat[1]) atomicAdd(&g->st_inserts, (unsigned long long)s_stat[1]);
     }
 }
 
@@ -1831,6 +1855,7 @@ size_t carve_chain(unsigned char *base, const ChainJob &job, const Geometry &g, 
     d.gdirty = c.take<uint8_t>(g.n_groups);
     d.mcol = c.take<int>(n_out);
     d.colin = c.take<int>(n_out);
+    d.cmap = c.take<uint16_t>(n_out);
     d.mA = c.take<unsigned char>(n_out * cell);
     d.mB = c.take<unsigned char>(n_out * cell);
     d.plist = c.take<unsigned long long>(g.rcap);
@@ -2030,7 +2055,7 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
         size_t claim_bytes = ((size_t)geo[i].rcap + 31) / 32 * 4;
         if (claim_bytes > 64 * 1024) claim_bytes = 0;
         const size_t no = (size_t)jobs[i].n_out, cellb = geo[i].wide ? 8 : 4, entb = geo[i].wide ? 16 : 4;
-        size_t s = no * entb + 6 * (size_t)geo[i].Kpad * 4 + (6 * no + 1) * 4 + claim_bytes;
+        size_t s = no * entb + 6 * (size_t)geo[i].Kpad * 4 + (7 * no + 1) * 4 + claim_bytes;
         s = align_up(s, 16);
         sel_lds[w] = std::max(sel_lds[w], s);
         upd_lds[w] = std::max(upd_lds[w], align_up((size_t)UPD_WAVES * 4 * 3 * (size_t)geo[i].Kpad * 4 + 2 * no * cellb + no * 6, 16));
@@ -2489,7 +2514,7 @@ class HipShardEngine : public ShardEngine {
         else
             hipLaunchKernelGGL(k_init_cells<uint64_t>, colgrid, dim3(256), 0, st_, dd_);
         HIP_CHECK(hipGetLastError());
-        sel_lds_ = align_up((size_t)n_loc_ * (g.wide ? 16 : 4) + 6 * (size_t)g.Kpad * 4 + (6 * (size_t)n_loc_ + 1) * 4 + (size_t)d_.claim_words * 4, 16);
+        sel_lds_ = align_up((size_t)n_loc_ * (g.wide ? 16 : 4) + 6 * (size_t)g.Kpad * 4 + (7 * (size_t)n_loc_ + 1) * 4 + (size_t)d_.claim_words * 4, 16);
         if (sel_lds_ > 150 * 1024) throw std::runtime_error("selection kernel needs more than 150 KiB of LDS");
         if (!g.wide)
             HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_iter_select<uint32_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sel_lds_));

@@ -83,6 +83,18 @@ def test_wide_digits(hip, oracle):
     assert hip.solve(k) == oracle.solve(k)
 
 
+@pytest.mark.parametrize('shape,lo,hi', [((20, 300), -8, 8), ((300, 24), -8, 8), ((9, 513), -4, 4), ((24, 20), -(2**13), 2**13), ((10, 260), -(2**14), 2**14)])
+def test_layout_boundaries(hip, oracle, shape, lo, hi):
+    """the narrow row-list entry holds col:8 | minus:12 | plus:12: more than 256 columns or more than 12 digits switch the
+    chain to the wide layout (64-bit cells, 16-byte entries); more than 256 INPUT rows keep the narrow one.  Rows longer
+    than 64 entries / more than 16 and 64 substituted columns exercise the chunk loops of the update kernel."""
+    k = int_matrix(shape[0] + shape[1], shape[0], shape[1], lo, hi)
+    for opts in (dict(), dict(method0='wmc', method1='wmc', decompose_dc=-1, search_all_decompose_dc=False)):
+        got = hip.solve(k, **opts)
+        assert got == oracle.solve(k, **opts)
+        assert np.all(got.kernel == k)
+
+
 def test_errors(hip):
     with pytest.raises(TypeError):
         hip.solve(np.eye(3))
