@@ -1081,6 +1081,7 @@ template <class Cell, bool SHARDED = false> __global__ void __launch_bounds__(SE
                 append(i < n_in && (uint32_t)i != A && (uint32_t)i != B, ref_pack((uint32_t)i, (uint32_t)n_out, (uint32_t)i * (uint32_t)n_out));
             }
             constexpr int CLAIM_ILP = 4;
+            const int search_steps = m > 1 ? 32 - __builtin_clz((unsigned)(m - 1)) : 0;  // ceil(log2 m)
             for (int fb = wid * WAVE; fb < total; fb += CLAIM_ILP * CLAIM_THREADS) {  // wave-uniform trip count: all lanes stay active
                 unsigned long long r[CLAIM_ILP];
                 bool ok[CLAIM_ILP];
@@ -1090,13 +1091,14 @@ template <class Cell, bool SHARDED = false> __global__ void __launch_bounds__(SE
                     ok[u] = f < total;
                     r[u] = 0;
                     if (ok[u]) {
+                        // which matched column's tail holds entry f: binary search with a trip count that is the same for
+                        // every lane and every u, so that the CLAIM_ILP searches (LDS round trips) run interleaved
                         int lo = 0, hi = m;
-                        while (hi - lo > 1) {
-                            int mid = (lo + hi) >> 1;
-                            if (s_len[mid] <= f)
-                                lo = mid;
-                            else
-                                hi = mid;
+                        for (int st = 0; st < search_steps; ++st) {
+                            const int mid = (lo + hi) >> 1;
+                            const bool open = hi - lo > 1, up = open && s_len[mid] <= f;
+                            lo = up ? mid : lo;
+                            hi = (open && !up) ? mid : hi;
                         }
                         r[u] = collist[(size_t)s_col[lo] * lcap + s_cin[lo] + (f - s_len[lo])];
                     }
@@ -2314,32 +2316,31 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
         return;
     }
     size_t down_bytes = 0;
-    for (int s = 0; s < n; ++s) {
-        const ChainDev &d = fin[s];
-        int i = order[s];
-        const ChainJob &j = jobs[i];
-        ChainOut &o = outs[i];
-        size_t iters = (size_t)d.iter;
-        o.shift0.resize(j.n_in);
-        o.shift1.resize(j.n_out);
-        HIP_CHECK(hipMemcpyAsync(o.shift0.data(), d.shift0, j.n_in, hipMemcpyDeviceToHost, st));
-        HIP_CHECK(hipMemcpyAsync(o.shift1.data(), d.shift1, j.n_out, hipMemcpyDeviceToHost, st));
-        o.picks.resize(iters * 4);
-        if (iters) HIP_CHECK(hipMemcpyAsync(o.picks.data(), d.picks, iters * sizeof(int4), hipMemcpyDeviceToHost, st));
-        down_bytes += iters * 16;
-    }
-    // packed results through one pinned staging buffer: first the column offsets (sizes), then exactly the digits
-    std::vector<size_t> st_off(n), lat_off(n), row_off(n), cell_off(n);
+    // Results through ONE pinned staging buffer (copies into pageable memory are staged and block, ~80 us each, and there
+    // are seven per chain): first the column offsets (= sizes of the digit arrays), the shifts and the picks, then exactly
+    // the digits.
+    std::vector<size_t> st_off(n), s0_off(n), s1_off(n), pk_off(n), lat_off(n), row_off(n), cell_off(n);
     size_t pin_bytes = 0;
     for (int s = 0; s < n; ++s) {
         const ChainJob &j = jobs[order[s]];
         st_off[s] = pin_bytes;
         pin_bytes += align_up(((size_t)j.n_out + 1) * 4, 64);
+        s0_off[s] = pin_bytes;
+        pin_bytes += align_up((size_t)j.n_in, 64);
+        s1_off[s] = pin_bytes;
+        pin_bytes += align_up((size_t)j.n_out, 64);
+        pk_off[s] = pin_bytes;
+        pin_bytes += align_up((size_t)fin[s].iter * sizeof(int4), 64);
     }
     unsigned char *pin = static_cast<unsigned char *>(im.pinned.get(pin_bytes));
     for (int s = 0; s < n; ++s) {
+        const ChainDev &d = fin[s];
         const ChainJob &j = jobs[order[s]];
-        HIP_CHECK(hipMemcpyAsync(pin + st_off[s], fin[s].fin_start, ((size_t)j.n_out + 1) * 4, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipMemcpyAsync(pin + st_off[s], d.fin_start, ((size_t)j.n_out + 1) * 4, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipMemcpyAsync(pin + s0_off[s], d.shift0, j.n_in, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipMemcpyAsync(pin + s1_off[s], d.shift1, j.n_out, hipMemcpyDeviceToHost, st));
+        if (d.iter) HIP_CHECK(hipMemcpyAsync(pin + pk_off[s], d.picks, (size_t)d.iter * sizeof(int4), hipMemcpyDeviceToHost, st));
+        down_bytes += (size_t)d.iter * 16;
     }
     HIP_CHECK(hipStreamSynchronize(st));
     std::vector<uint32_t> totals(n);
@@ -2350,6 +2351,10 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
         const uint32_t *cs = reinterpret_cast<const uint32_t *>(pin + st_off[s]);
         o.col_start.assign(cs, cs + j.n_out + 1);
         totals[s] = cs[j.n_out];
+        o.shift0.assign(reinterpret_cast<const int8_t *>(pin + s0_off[s]), reinterpret_cast<const int8_t *>(pin + s0_off[s]) + j.n_in);
+        o.shift1.assign(reinterpret_cast<const int8_t *>(pin + s1_off[s]), reinterpret_cast<const int8_t *>(pin + s1_off[s]) + j.n_out);
+        const int32_t *pk = reinterpret_cast<const int32_t *>(pin + pk_off[s]);
+        o.picks.assign(pk, pk + (size_t)fin[s].iter * 4);
         lat_off[s] = pin2;
         pin2 += align_up((size_t)fin[s].n_rows * 4, 64);
         row_off[s] = pin2;
@@ -2357,7 +2362,7 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
         cell_off[s] = pin2;
         pin2 += align_up((size_t)totals[s] * 8, 64);
     }
-    pin = static_cast<unsigned char *>(im.pinned.get(pin2));
+    pin = static_cast<unsigned char *>(im.pinned.get(pin2));  // (the first area has been consumed above)
     for (int s = 0; s < n; ++s) {
         const ChainDev &d = fin[s];
         HIP_CHECK(hipMemcpyAsync(pin + lat_off[s], d.pk_lat, (size_t)d.n_rows * 4, hipMemcpyDeviceToHost, st));
