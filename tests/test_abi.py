@@ -105,3 +105,26 @@ def test_error_class_comes_from_the_library_not_from_the_message():
     assert L.da_last_error_code() in (0, -1, -2, -3)
     if B.device_count() == 0:  # no GPU here: set_device must fail with the NO_DEVICE class and say so
         assert L.da_set_device(0) == -3 and L.da_last_error_code() == -3
+
+
+def test_sharded_entry_point_validates_its_arguments():
+    """da_solve_sharded (column-sharded chains): rank / world / callback are checked before any device work -- ValueError class"""
+    import ctypes as C
+
+    import numpy as np
+
+    import da4ml_amd._binary as B
+
+    L = B.lib()
+    k = np.eye(4, dtype=np.float32)
+    st = np.zeros(3, np.int64)
+    for rank, world in ((2, 2), (-1, 1), (0, 0), (0, 300)):
+        h = L.da_solve_sharded(k, 4, 4, b'wmc', b'auto', -1, -2, None, None, -1, -1, 1, rank, world, None, None, st)
+        assert not h and L.da_last_error_code() == -2, (rank, world)
+    h = L.da_solve_sharded(k, 4, 4, b'wmc', b'auto', -1, -2, None, None, -1, -1, 1, 0, 2, None, None, st)  # world 2 needs a collective
+    assert not h and L.da_last_error_code() == -2 and b'all-reduce' in L.da_last_error()
+    if B.device_count() == 0:  # valid arguments, no GPU: fails loudly, no CPU path
+        import pytest
+
+        with pytest.raises(RuntimeError, match='no HIP device'):
+            B.solve_sharded(k, rank=0, world=1)
