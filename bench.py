@@ -166,17 +166,21 @@ def verify(hip, raw, kernels, n_in, n_out, opts, first_seed):
         if path.exists():
             records.update(json.loads(path.read_text()))
     kind = 'default' if not opts else 'single_chain'
-    digests = {}
+    digests, marshal_s = {}, []
     for i in range(len(kernels)):
         gold = records.get(f'{n_in}x{n_out}_seed{first_seed + i}_{kind}')
         if gold is None:
             continue
-        p = raw.pipeline(i)  # consumes the handle
+        t_obj = time.perf_counter()
+        p = raw.pipeline(i)  # consumes the handle; builds the Python Pipeline / CombLogic / Op objects (reference: bindings.cc:106-151)
+        marshal_s.append(time.perf_counter() - t_obj)
         dump = json.loads(json.dumps(p, default=lambda o: o.to_dict()))
         sha = hashlib.sha256(json.dumps(dump, separators=(',', ':')).encode()).hexdigest()
         digests[f'seed{first_seed + i}'] = {'match': sha == gold['sha256'], 'cost': p.cost, 'adders': p.n_adders, 'oracle_adders': gold['adders'],
                                             'oracle': gold.get('oracle', 'oracle/liboracle.so')}  # fmt: skip
     out['digests_vs_oracle'] = digests
+    # Python object construction is reported separately from the timed C-ABI call
+    out['python_objects_seconds_per_result'] = float(np.mean(marshal_s)) if marshal_s else None
     out['all_ok'] = not bad and all(d['match'] for d in digests.values())
     out['seconds'] = time.perf_counter() - t
     return out
