@@ -181,7 +181,6 @@ struct ChainDev {
     unsigned long long *plist;
     int m, n_partners;
     int claim_words;   // words of the LDS claim bitmap in k_iter_select (0: use the global stamp array)
-    unsigned int work_ctr;
     uint32_t A, B, Nw;
     // progress
     int n_rows, iter, done, error, unknown_hit;
@@ -1167,7 +1166,6 @@ template <class Cell, bool SHARDED = false> __global__ void __launch_bounds__(SE
         g->st_matches += (unsigned long long)s_matches;
         g->st_partners += (unsigned long long)s_np;
         g->st_cells += (unsigned long long)s_np * (unsigned)m;
-        g->work_ctr = 0;
         g->A = A;
         g->B = B;
         g->Nw = Nw;
@@ -1787,10 +1785,8 @@ struct HipBackend::Impl {
     static constexpr int MAX_LANES = 8;
     hipStream_t lanes[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // greedy-loop streams of the chain groups
     int n_lanes = 3;  // + the poll stream = 4 hardware queues
-    bool use_graph = false;
     int upd_total_blocks = 2560;  // k_iter_update blocks over all chains of a batch (4 waves x 4 groups each); measured (C3 batch 64,
                                   // solves/s): 1024: 45.3, 1536: 53.3, 2048: 53.8, 2560: 55.5, 4096: 47.5
-    bool mt_launch = false;
     DeviceBuffer arena, desc_buf, io_buf;
     unsigned int *d_done = nullptr;
     unsigned int *h_done = nullptr;  // pinned, two words: done counters of alternating poll windows
@@ -1808,8 +1804,6 @@ HipBackend::HipBackend(int device) : impl_(new Impl) {
     if (const char *e = std::getenv("DA4ML_HIP_TABLE_SCALE")) impl_->table_scale = std::max(1e-4, std::atof(e));
     if (const char *e = std::getenv("DA4ML_HIP_ROW_SCALE")) row_scale_ = std::max(1e-4, std::atof(e));
     if (const char *e = std::getenv("DA4ML_HIP_UPD_BLOCKS")) impl_->upd_total_blocks = std::max(64, std::atoi(e));
-    if (const char *e = std::getenv("DA4ML_HIP_MT")) impl_->mt_launch = std::atoi(e) != 0;
-    if (const char *e = std::getenv("DA4ML_HIP_GRAPH")) impl_->use_graph = std::atoi(e) != 0;
     if (const char *e = std::getenv("DA4ML_HIP_LANES")) impl_->n_lanes = std::max(1, std::min((int)Impl::MAX_LANES, std::atoi(e)));
     HIP_CHECK(hipMalloc(&impl_->d_done, sizeof(unsigned int)));
     HIP_CHECK(hipHostMalloc(&impl_->h_done, 2 * sizeof(unsigned int), hipHostMallocDefault));
@@ -2131,48 +2125,16 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
             hipLaunchKernelGGL(k_iter_update<uint64_t>, dim3(upd_blocks[1], gr.count), dim3(UPD_THREADS), upd_lds[1], gr.stream, base);
         if (se) HIP_CHECK(hipEventRecord(se[2], gr.stream));
     };
-    // The launch-bound window of GRAPH_ITERS iterations x all groups is captured once into a hipGraph (fork/join over
-    // the group streams) and replayed; one eager, event-bracketed iteration per window samples the kernel durations.
-    constexpr int GRAPH_ITERS = 63, MAX_SAMPLES = 4096;
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t graph_exec = nullptr;
-    if (im.use_graph) {
-        hipEvent_t fork_ev;
-        std::vector<hipEvent_t> join_ev(groups.size());
-        bool ok = hipEventCreateWithFlags(&fork_ev, hipEventDisableTiming) == hipSuccess;
-        for (auto &e : join_ev) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
-        ok = ok && hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess;
-        if (ok) {
-            bool cap = hipEventRecord(fork_ev, st) == hipSuccess;
-            for (const Group &gr : groups) cap = cap && hipStreamWaitEvent(gr.stream, fork_ev, 0) == hipSuccess;
-            if (cap) {
-                try {
-                    for (int it = 0; it < GRAPH_ITERS; ++it)
-                        for (const Group &gr : groups) launch_pair(gr, nullptr);
-                } catch (...) {
-                    cap = false;
-                }
-            }
-            for (size_t gi = 0; gi < groups.size(); ++gi) {
-                cap = cap && hipEventRecord(join_ev[gi], groups[gi].stream) == hipSuccess;
-                cap = cap && hipStreamWaitEvent(st, join_ev[gi], 0) == hipSuccess;
-            }
-            hipError_t e = hipStreamEndCapture(st, &graph);
-            if (!cap || e != hipSuccess || graph == nullptr || hipGraphInstantiate(&graph_exec, graph, nullptr, nullptr, 0) != hipSuccess) {
-                if (graph) (void)hipGraphDestroy(graph);
-                graph = nullptr;
-                graph_exec = nullptr;
-                (void)hipGetLastError();
-            }
-        }
-        (void)hipEventDestroy(fork_ev);
-        for (auto &e : join_ev) (void)hipEventDestroy(e);
-    }
+    // Windows of up to WINDOW_ITERS iterations x all groups are queued eagerly; one event-bracketed iteration per window
+    // samples the kernel durations.  (A hipGraph replay of the window and one launching host thread per group were
+    // re-measured in round 2 with the shorter kernels: no gain at batch 64 or 8 -- the host keeps the queues full at
+    // ~8 us per launch -- and were removed.)
+    constexpr int WINDOW_ITERS = 63, MAX_SAMPLES = 4096;
     std::vector<hipEvent_t> sample_ev;
     int n_samples = 0;
     long long launched_iters = 0, iter_cap = 0;
     for (int i = 0; i < n; ++i) iter_cap = std::max<long long>(iter_cap, geo[i].rcap - jobs[i].n_in + 2);
-    const int poll_every = GRAPH_ITERS + 1;
+    const int poll_every = WINDOW_ITERS + 1;
     int pre_done = 0;
     for (int i = 0; i < n; ++i) pre_done += (jobs[i].method == M_DUMMY || jobs[i].method < 0) ? 1 : 0;
     // The done counter is read back ONE WINDOW BEHIND on a separate stream: after window w is queued, the poll stream
@@ -2187,7 +2149,6 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
     long long window = 0;
     while (active > 0) {
         if (launched_iters > iter_cap + 2 * poll_every) throw std::runtime_error("greedy loop did not terminate within its row capacity (internal error)");
-        int this_window = GRAPH_ITERS;
         // sampled eager iteration (all groups; the first group's kernels are bracketed by events on its stream)
         for (size_t gi = 0; gi < groups.size(); ++gi) {
             hipEvent_t se[3];
@@ -2201,32 +2162,10 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
             }
             launch_pair(groups[gi], sample ? se : nullptr);
         }
-        if (graph_exec) {
-            for (const Group &gr : groups) HIP_CHECK(hipStreamSynchronize(gr.stream));
-            HIP_CHECK(hipGraphLaunch(graph_exec, st));
-        } else if (im.mt_launch && groups.size() > 1) {
-            // one host thread per group
-            std::vector<std::thread> th;
-            std::exception_ptr err;
-            std::mutex mu;
-            for (const Group &gr : groups)
-                th.emplace_back([&, gr] {
-                    try {
-                        HIP_CHECK(hipSetDevice(im.device));
-                        for (int it = 0; it < GRAPH_ITERS; ++it) launch_pair(gr, nullptr);
-                    } catch (...) {
-                        std::lock_guard<std::mutex> lk(mu);
-                        if (!err) err = std::current_exception();
-                    }
-                });
-            for (auto &t : th) t.join();
-            if (err) std::rethrow_exception(err);
-        } else {
-            // small problems finish within a few iterations: start with short windows, double up to the full length
-            this_window = (int)std::min<long long>(GRAPH_ITERS, (8ll << std::min<long long>(window, 8)) - 1);
-            for (int it = 0; it < this_window; ++it)
-                for (const Group &gr : groups) launch_pair(gr, nullptr);
-        }
+        // small problems finish within a few iterations: start with short windows, double up to the full length
+        const int this_window = (int)std::min<long long>(WINDOW_ITERS, (8ll << std::min<long long>(window, 8)) - 1);
+        for (int it = 0; it < this_window; ++it)
+            for (const Group &gr : groups) launch_pair(gr, nullptr);
         launched_iters += this_window + 1;
         HIP_CHECK(hipGetLastError());
         const int p = (int)(window & 1);
@@ -2248,9 +2187,6 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
         (void)hipEventDestroy(copy_ev[p]);
         for (size_t gi = 0; gi < groups.size(); ++gi) (void)hipEventDestroy(win_ev[p][gi]);
     }
-    if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
-    if (graph) (void)hipGraphDestroy(graph);
-    im.timings.graph_used += graph_exec ? 1 : 0;
     HIP_CHECK(hipEventRecord(ev1, st));
 
     lap("greedy loop");

@@ -19,7 +19,6 @@ struct GpuTimings {  // accumulated since the last reset; read by the benchmark 
     long long partners = 0;        // partner rows processed by the update kernel
     long long chains = 0;
     long long retries = 0;         // capacity retries (arena heuristics too small)
-    long long graph_used = 0;      // run_chains calls whose loop ran from a captured hipGraph
     long long dist_calls = 0;
     // sampled per-kernel durations (HIP events around every 16th lockstep iteration)
     double select_ms_sampled = 0, update_ms_sampled = 0;
