@@ -1780,7 +1780,7 @@ struct PinnedBuffer {  // grow-only pinned host allocation reused across calls
 
 struct HipBackend::Impl {
     int device = 0;
-    PinnedBuffer pinned;
+    PinnedBuffer pinned, pinned_up;  // staging of the downloads / of the upload
     hipStream_t stream = nullptr;
     static constexpr int MAX_LANES = 8;
     hipStream_t lanes[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // greedy-loop streams of the chain groups
@@ -1894,7 +1894,7 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
     }
     unsigned char *io = static_cast<unsigned char *>(im.io_buf.get(std::max<size_t>(in_bytes, 256)));
     std::vector<ChainDev> desc(n);
-    std::vector<unsigned char> stage(in_bytes);
+    unsigned char *stage_ptr = static_cast<unsigned char *>(im.pinned_up.get(std::max<size_t>(in_bytes, 256)));  // pinned: the upload is one asynchronous DMA
     for (int i = 0; i < n; ++i) {
         const ChainJob &j = jobs[i];
         size_t e = (size_t)j.n_in * j.n_out, o = in_off[i];
@@ -1907,13 +1907,13 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
         d.adder_size = j.adder_size;
         d.carry_size = j.carry_size;
         d.kernel = reinterpret_cast<const float *>(io + o);
-        std::memcpy(stage.data() + o, j.kernel, e * 4);
+        std::memcpy(stage_ptr + o, j.kernel, e * 4);
         o += align_up(e * 4, 256);
         d.qints = reinterpret_cast<const float *>(io + o);
-        std::memcpy(stage.data() + o, j.qints, (size_t)j.n_in * 12);
+        std::memcpy(stage_ptr + o, j.qints, (size_t)j.n_in * 12);
         o += align_up((size_t)j.n_in * 12, 256);
         d.lats = reinterpret_cast<const float *>(io + o);
-        std::memcpy(stage.data() + o, j.lats, (size_t)j.n_in * 4);
+        std::memcpy(stage_ptr + o, j.lats, (size_t)j.n_in * 4);
         o += align_up((size_t)j.n_in * 4, 256);
         d.xint = reinterpret_cast<int32_t *>(io + o);
         o += align_up(e * 4, 256);
@@ -1921,7 +1921,7 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
         o += align_up(j.n_in, 256);
         d.shift1 = reinterpret_cast<int8_t *>(io + o);
     }
-    HIP_CHECK(hipMemcpyAsync(io, stage.data(), in_bytes, hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipMemcpyAsync(io, stage_ptr, in_bytes, hipMemcpyHostToDevice, st));
     ChainDev *d_desc = static_cast<ChainDev *>(im.desc_buf.get(sizeof(ChainDev) * (size_t)n));
     HIP_CHECK(hipMemcpyAsync(d_desc, desc.data(), sizeof(ChainDev) * (size_t)n, hipMemcpyHostToDevice, st));
     int max_n_out = 0, max_n_in = 0;

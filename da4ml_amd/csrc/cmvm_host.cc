@@ -238,6 +238,56 @@ inline int64_t magnitude_bits(const QInt &q) { return (int64_t)std::log2(std::ma
 
 }  // namespace
 
+// Chains without a greedy loop never need the device: the "dummy" method (the minimal-latency probe, api.cc:11-26: adder
+// trees straight from the CSD digits) and matrices in which no column holds two digits, so that no digit pair exists at
+// all -- above all the identity second stage of every decompose_dc = -1 solve.  The result is what the device kernels
+// produce for such a chain (k_prepare + k_init_cells + k_extract): centring shifts, digit width, the digits of every
+// column in row order.  Returns false when the chain has to run on the device.
+static bool host_chain(const ChainJob &job, ChainOut &out) {
+    const int n_in = job.n_in, n_out = job.n_out;
+    std::vector<float> a(job.kernel, job.kernel + (size_t)n_in * n_out);
+    std::vector<int8_t> s0, s1;
+    center_matrix(a, n_in, n_out, s0, s1);
+    std::vector<uint8_t> dead(n_in);
+    for (int i = 0; i < n_in; ++i) dead[i] = job.qints[i].lo == 0.0f && job.qints[i].hi == 0.0f;
+    uint32_t mx = 0;
+    long long digits0 = 0;
+    std::vector<int> dcol(n_out, 0);
+    for (int i = 0; i < n_in; ++i)
+        for (int j = 0; j < n_out; ++j) {
+            const int32_t x = (int32_t)a[(size_t)i * n_out + j];
+            mx = std::max(mx, (uint32_t)(x < 0 ? -(int64_t)x : x));
+            if (!dead[i] && x != 0) dcol[j] += naf_weight(x);
+        }
+    if (job.method != M_DUMMY) {
+        if (job.method < 0) return false;  // unknown method string: the device path decides whether it has to raise
+        for (int j = 0; j < n_out; ++j)
+            if (dcol[j] > 1) return false;
+    }
+    const int n_bits = csd_width(mx);
+    if (n_bits > 30) return false;  // rejected with a message by the device path
+    out = ChainOut{};
+    out.n_bits = n_bits;
+    out.shift0 = s0;
+    out.shift1 = s1;
+    out.row_lat.assign(job.lats, job.lats + n_in);
+    out.col_start.assign((size_t)n_out + 1, 0);
+    for (int j = 0; j < n_out; ++j) {
+        for (int i = 0; i < n_in; ++i) {
+            const int32_t x = (int32_t)a[(size_t)i * n_out + j];
+            if (dead[i] || x == 0) continue;
+            uint32_t p, m;
+            naf_masks(x, p, m);
+            out.dig_row.push_back((uint32_t)i);
+            out.dig_cell.push_back((uint64_t)p | ((uint64_t)m << 32));
+        }
+        out.col_start[j + 1] = (uint32_t)out.dig_row.size();
+        digits0 += dcol[j];
+    }
+    out.stats.digits0 = digits0;
+    return true;
+}
+
 StageResult finalize_chain(const ChainJob &job, const ChainOut &out) {
     if (out.error != E_OK) throw std::runtime_error("CMVM chain failed on the device (error " + std::to_string(out.error) + ")");
     StageResult r;
@@ -565,7 +615,22 @@ std::vector<PipeResult> solve_batch_unique(Backend &be, const std::vector<Proble
         if (jobs.empty()) break;
         std::vector<ChainOut> outs(jobs.size());
         auto t_rc = std::chrono::steady_clock::now();
-        be.run_chains(jobs.data(), outs.data(), (int)jobs.size());
+        {  // chains without a greedy loop are finished on the host; the others go to the backend together
+            std::vector<uint8_t> on_host(jobs.size(), 0);
+            parallel_for(jobs.size(), [&](size_t k) { on_host[k] = host_chain(jobs[k], outs[k]) ? 1 : 0; });
+            std::vector<ChainJob> dev_jobs;
+            std::vector<size_t> dev_idx;
+            for (size_t k = 0; k < jobs.size(); ++k)
+                if (!on_host[k]) {
+                    dev_jobs.push_back(jobs[k]);
+                    dev_idx.push_back(k);
+                }
+            if (!dev_jobs.empty()) {
+                std::vector<ChainOut> dev_outs(dev_jobs.size());
+                be.run_chains(dev_jobs.data(), dev_outs.data(), (int)dev_jobs.size());
+                for (size_t k = 0; k < dev_idx.size(); ++k) outs[dev_idx[k]] = std::move(dev_outs[k]);
+            }
+        }
         auto t_fin = std::chrono::steady_clock::now();
         for (size_t k = 0; k < jobs.size(); ++k)
             if (outs[k].unknown_method_hit) {
