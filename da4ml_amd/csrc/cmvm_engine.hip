@@ -177,6 +177,10 @@ struct ChainDev {
     int *mcol;
     int *colin;        // [n_out] number of INPUT rows at the head of each column list (fixed after k_init_cells)
     uint16_t *cmap;    // [n_out] 1 + index of a column among the substituted columns of this step, 0 = not substituted
+    uint32_t *colbits; // [n_out][cb_words] bit r of column j: row r has digits in column j NOW.  The partner rows of a step are the
+                       // OR of the substituted columns' bitmaps -- no list reads, no de-duplication, no stale entries
+    int cb_words;
+    uint32_t *pl_ids;  // [rcap] partner row ids of the step (before their list references are attached)
     void *mA, *mB;
     unsigned long long *plist;
     int m, n_partners;
@@ -543,6 +547,7 @@ template <class Cell> __global__ void __launch_bounds__(256) k_init_cells(ChainD
             rl[(size_t)i * ch.n_out + j] = F::pack((uint32_t)j, c);  // dense row: entry j is column j, empty cells included
         }
         unsigned long long nz = __ballot(c != 0);
+        if (lane < 2 && base + 32 * lane < ch.n_in) ch.colbits[(size_t)j * ch.cb_words + (base >> 5) + lane] = (uint32_t)(nz >> (32 * lane));
         if (c != 0)
             ch.collist[(size_t)j * ch.lcap + len + __popcll(nz & ((1ull << lane) - 1))] = ref_pack((uint32_t)i, (uint32_t)ch.n_out, (uint32_t)i * (uint32_t)ch.n_out);
         len += __popcll(nz);
@@ -960,6 +965,12 @@ template <class Cell, bool SHARDED = false> __global__ void __launch_bounds__(SE
             mA[at] = ma;
             mB[at] = mb;
             s_cm[colA] = at + 1;
+            {  // row bitmaps of this column: the new row enters, a row whose cell just lost its last digit leaves
+                DA_GLOBAL uint32_t *cb = (DA_GLOBAL uint32_t *)g->colbits + (size_t)colA * g->cb_words;
+                atomicOr(gen(&cb[Nw >> 5]), 1u << (Nw & 31));
+                if (na == 0) atomicAnd(gen(&cb[A >> 5]), ~(1u << (A & 31)));
+                if (!same && nbv == 0) atomicAnd(gen(&cb[B >> 5]), ~(1u << (B & 31)));
+            }
             s_len[at] = s_clen[colA];  // the pre-append length: the new row itself is not a partner
             s_cin[at] = s_cinall[colA];  // how many of them are input rows: those are made partners wholesale, only the tail is claimed
             s_col[at] = (int)colA;
@@ -1003,6 +1014,8 @@ template <class Cell, bool SHARDED = false> __global__ void __launch_bounds__(SE
     }
     __syncthreads();
     tp[4] = clock64();
+    int total = 0;
+    if constexpr (SHARDED) {  // only the column-sharded chain still walks the column lists
     // exclusive prefix sum of the list lengths of the matched columns (m <= n_out)
     for (int k = tid; k < claim_words; k += SEL_THREADS) s_bits[k] = 0;
     if (m <= WAVE) {  // the common case: one wave, shuffle scan
@@ -1039,7 +1052,8 @@ template <class Cell, bool SHARDED = false> __global__ void __launch_bounds__(SE
         if (tid == SEL_THREADS - 1) s_len[m] = wbase + inc;
         __syncthreads();
     }
-    const int total = s_len[m];
+    total = s_len[m];
+    }
     tp[5] = clock64();
     // ---------------- (4) partner rows: every row that may share a substituted column, once, into the partner list -- by the
     // first NW-6 waves; the last six waves store the six special pairs meanwhile.  A superset is harmless (a partner without
@@ -1063,61 +1077,39 @@ template <class Cell, bool SHARDED = false> __global__ void __launch_bounds__(SE
                 if (row != A && row != B) atomicOr(&s_bits[row >> 5], 1u << (row & 31));
             }
         } else {
-            DA_GLOBAL uint32_t *stamp = (DA_GLOBAL uint32_t *)g->stamp;
-            DA_GLOBAL unsigned long long *plist = (DA_GLOBAL unsigned long long *)g->plist;
-            const uint32_t tag = (uint32_t)iter + 1u;
-            const int n_in = g->n_in;
-            auto append = [&](bool ok, unsigned long long ref) {  // one LDS atomic per wave (same-address atomics serialise)
-                const unsigned long long okm = __ballot(ok);
-                if (!okm) return;
+            // Partner rows = rows that have digits in a substituted column = OR of those columns' row bitmaps (A, B and the
+            // new row masked out: their bits are being changed by this very kernel).  Word w of the OR covers rows 32 w ..;
+            // the set bits are counted, one LDS atomic per wave reserves the places, the row ids go to pl_ids; then, one
+            // thread per partner, the list reference is attached (a parallel gather from rowoff).
+            const DA_GLOBAL uint32_t *cb = (const DA_GLOBAL uint32_t *)g->colbits;
+            const int cbw = g->cb_words, nwords = (int)((Nw + 31) >> 5);
+            DA_GLOBAL uint32_t *ids = (DA_GLOBAL uint32_t *)g->pl_ids;
+            for (int wb = wid * WAVE; wb < nwords; wb += CLAIM_THREADS) {  // wave-uniform trip count
+                const int w = wb + lane;
+                uint32_t bits = 0;
+                if (w < nwords) {
+                    for (int k = 0; k < m; ++k) bits |= cb[(size_t)s_col[k] * cbw + w];
+                    if ((int)(A >> 5) == w) bits &= ~(1u << (A & 31));
+                    if ((int)(B >> 5) == w) bits &= ~(1u << (B & 31));
+                    if ((int)(Nw >> 5) == w) bits &= ~(1u << (Nw & 31));
+                }
+                int cnt = popc32(bits), inc = cnt;  // exclusive prefix inside the wave
+                for (int o = 1; o < WAVE; o <<= 1) {
+                    const int t = __shfl_up(inc, o);
+                    if (lane >= o) inc += t;
+                }
+                const int wave_total = __builtin_amdgcn_readlane(inc, WAVE - 1);
+                if (wave_total == 0) continue;
                 int base = 0;
-                if (lane == 0) base = atomicAdd(&s_np, (int)__popcll(okm));
-                base = __builtin_amdgcn_readfirstlane(base);
-                if (ok) plist[base + __popcll(okm & ((1ull << lane) - 1))] = ref;
-            };
-            for (int ib = wid * WAVE; ib < n_in; ib += CLAIM_THREADS) {  // the input rows (dense lists: offset = id * n_out)
-                const int i = ib + lane;
-                append(i < n_in && (uint32_t)i != A && (uint32_t)i != B, ref_pack((uint32_t)i, (uint32_t)n_out, (uint32_t)i * (uint32_t)n_out));
-            }
-            constexpr int CLAIM_ILP = 4;
-            const int search_steps = m > 1 ? 32 - __builtin_clz((unsigned)(m - 1)) : 0;  // ceil(log2 m)
-            for (int fb = wid * WAVE; fb < total; fb += CLAIM_ILP * CLAIM_THREADS) {  // wave-uniform trip count: all lanes stay active
-                unsigned long long r[CLAIM_ILP];
-                bool ok[CLAIM_ILP];
-#pragma unroll
-                for (int u = 0; u < CLAIM_ILP; ++u) {  // CLAIM_ILP independent list reads in flight
-                    const int f = fb + lane + u * CLAIM_THREADS;
-                    ok[u] = f < total;
-                    r[u] = 0;
-                    if (ok[u]) {
-                        // which matched column's tail holds entry f: binary search with a trip count that is the same for
-                        // every lane and every u, so that the CLAIM_ILP searches (LDS round trips) run interleaved
-                        int lo = 0, hi = m;
-                        for (int st = 0; st < search_steps; ++st) {
-                            const int mid = (lo + hi) >> 1;
-                            const bool open = hi - lo > 1, up = open && s_len[mid] <= f;
-                            lo = up ? mid : lo;
-                            hi = (open && !up) ? mid : hi;
-                        }
-                        r[u] = collist[(size_t)s_col[lo] * lcap + s_cin[lo] + (f - s_len[lo])];
-                    }
+                if (lane == 0) base = atomicAdd(&s_np, wave_total);
+                int at = __builtin_amdgcn_readfirstlane(base) + inc - cnt;
+                while (bits) {
+                    ids[at++] = (uint32_t)(w << 5) + (uint32_t)ctz32(bits);
+                    bits &= bits - 1;
                 }
-#pragma unroll
-                for (int u = 0; u < CLAIM_ILP; ++u) {
-                    const uint32_t row = ref_row(r[u]);
-                    if (!ok[u] || row == A || row == B) {
-                        ok[u] = false;
-                        continue;
-                    }
-                    if (claim_words) {  // de-duplicate in the LDS bitmap: no global round trip
-                        const uint32_t bit = 1u << (row & 31);
-                        ok[u] = (atomicOr(&s_bits[row >> 5], bit) & bit) == 0;
-                    } else
-                        ok[u] = atomicExch(gen(&stamp[row]), tag) != tag;
-                }
-#pragma unroll
-                for (int u = 0; u < CLAIM_ILP; ++u) append(ok[u], r[u]);
             }
+            // all claim waves have written their ids (named barrier over the claim waves only is not available: the six
+            // special-pair waves are elsewhere; so the references are attached after the block barrier below)
         }
     } else {
         const int sp = wid - CLAIM_WAVES;
@@ -1149,6 +1141,16 @@ template <class Cell, bool SHARDED = false> __global__ void __launch_bounds__(SE
     }
     tp[6] = clock64();
     __syncthreads();
+    if constexpr (!SHARDED) {  // partner ids -> partner list entries (row id, list length, list offset)
+        const int np = s_np;
+        const DA_GLOBAL uint32_t *ids = (const DA_GLOBAL uint32_t *)g->pl_ids;
+        DA_GLOBAL unsigned long long *plist = (DA_GLOBAL unsigned long long *)g->plist;
+        for (int t = tid; t < np; t += SEL_THREADS) {
+            const uint32_t r = ids[t];
+            const da_u2 ro = rowoff[r];
+            plist[t] = ref_pack(r, ro.y, ro.x);
+        }
+    }
     tp[7] = clock64();
     if constexpr (SHARDED) {  // claim bitmap -> 8-bit flag fields, four rows per word (summed over the ranks without carry)
         DA_GLOBAL int32_t *flags = (DA_GLOBAL int32_t *)g->cs_flags;
@@ -1852,6 +1854,8 @@ size_t carve_chain(unsigned char *base, const ChainJob &job, const Geometry &g, 
     d.mcol = c.take<int>(n_out);
     d.colin = c.take<int>(n_out);
     d.cmap = c.take<uint16_t>(n_out);
+    d.colbits = c.take<uint32_t>(n_out * (size_t)((g.rcap + 31) / 32));
+    d.pl_ids = c.take<uint32_t>(g.rcap);
     d.mA = c.take<unsigned char>(n_out * cell);
     d.mB = c.take<unsigned char>(n_out * cell);
     d.plist = c.take<unsigned long long>(g.rcap);
@@ -2018,6 +2022,8 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
         HIP_CHECK(hipMemsetAsync(d.hrank, 0, sizeof(uint32_t) * (size_t)g.C, st));
         HIP_CHECK(hipMemsetAsync(d.ub, 0, sizeof(unsigned long long) * (size_t)g.n_groups, st));
         HIP_CHECK(hipMemsetAsync(d.gdirty, 1, (size_t)g.n_groups, st));
+        d.cb_words = (g.rcap + 31) / 32;
+        HIP_CHECK(hipMemsetAsync(d.colbits, 0, sizeof(uint32_t) * (size_t)jobs[i].n_out * d.cb_words, st));
     }
     HIP_CHECK(hipMemcpyAsync(d_desc, desc.data(), sizeof(ChainDev) * (size_t)n, hipMemcpyHostToDevice, st));
     HIP_CHECK(hipMemsetAsync(im.d_done, 0, sizeof(unsigned int), st));
@@ -2446,6 +2452,8 @@ class HipShardEngine : public ShardEngine {
         HIP_CHECK(hipMemsetAsync(d_.hrank, 0, sizeof(uint32_t) * (size_t)g.C, st_));
         HIP_CHECK(hipMemsetAsync(d_.ub, 0, sizeof(unsigned long long) * (size_t)g.n_groups, st_));
         HIP_CHECK(hipMemsetAsync(d_.gdirty, 1, (size_t)g.n_groups, st_));
+        d_.cb_words = (g.rcap + 31) / 32;
+        HIP_CHECK(hipMemsetAsync(d_.colbits, 0, sizeof(uint32_t) * (size_t)n_loc_ * d_.cb_words, st_));
         push();
         HIP_CHECK(hipMalloc(&d_done_, sizeof(unsigned int)));
         HIP_CHECK(hipMemsetAsync(d_done_, 0, sizeof(unsigned int), st_));
