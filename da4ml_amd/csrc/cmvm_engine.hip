@@ -19,8 +19,10 @@
 //           one u32 per entry = col:8 | minus:12 | plus:12; wide layout: 16 bytes = u64 cell + u32 col.
 //   rowoff  [rcap] {offset, length} of every row's list (bump-allocated in creation order)
 //   rows    [rcap]         RowInfo interval + latency of every row
-//   collist [n_out][lcap]  u64     rows that have (had) digits in a column, ascending: row:24 | len:12 | off:28 -- the
-//                                  reference to the row's list travels with the id, so no consumer needs rowoff first
+//   collist [n_out][lcap]  u64     rows that have (had) digits in a column, ascending: row:24 | len:12 | off:28 (digit
+//                                  gather at the end; the column-sharded chain's flags)
+//   colbits [n_out][rcap/32]       bit r of column j: row r has digits in column j NOW; the partner rows of a greedy step are
+//                                  the OR of the substituted columns' bitmaps
 //   table   C slots (power of two), open addressing on (id0,id1):
 //             hkey[C] u64 (16 keys = one 128-byte line = one probe bucket), hrank[C] u32 (selection rank of the block's
 //             best key, 0 = none; the array the selection re-reads), hblk[C] one PAYLOAD LINE per slot:
@@ -175,7 +177,6 @@ struct ChainDev {
     uint8_t *gdirty;           // [n_groups] a block's best (rank, key) changed since the group was last verified
     // per-iteration hand-off select -> update
     int *mcol;
-    int *colin;        // [n_out] number of INPUT rows at the head of each column list (fixed after k_init_cells)
     uint16_t *cmap;    // [n_out] 1 + index of a column among the substituted columns of this step, 0 = not substituted
     uint32_t *colbits; // [n_out][cb_words] bit r of column j: row r has digits in column j NOW.  The partner rows of a step are the
                        // OR of the substituted columns' bitmaps -- no list reads, no de-duplication, no stale entries
@@ -235,6 +236,12 @@ constexpr int DPP_ROW_SHR1 = 0x111, DPP_ROW_SHR2 = 0x112, DPP_ROW_SHR4 = 0x114, 
     v = OP(v, dpp_u32<DPP_ROW_SHR8, 0xF>(ident, v));                    \
     v = OP(v, dpp_u32<DPP_ROW_BCAST15, 0xA>(ident, v));                 \
     v = OP(v, dpp_u32<DPP_ROW_BCAST31, 0xC>(ident, v));
+__device__ __forceinline__ uint32_t uadd32(uint32_t a, uint32_t b) { return a + b; }
+// inclusive prefix sum over the wave (the same DPP sequence leaves the running sums in every lane)
+__device__ __forceinline__ uint32_t wave_scan_add_u32(uint32_t v) {
+    DA_DPP_REDUCE32(v, 0u, uadd32)
+    return v;
+}
 __device__ __forceinline__ uint32_t umax32(uint32_t a, uint32_t b) { return a > b ? a : b; }
 __device__ __forceinline__ uint32_t smin32(uint32_t a, uint32_t b) { return (int)a < (int)b ? a : b; }
 __device__ __forceinline__ int wave_min_i32(int v) {
@@ -552,10 +559,7 @@ template <class Cell> __global__ void __launch_bounds__(256) k_init_cells(ChainD
             ch.collist[(size_t)j * ch.lcap + len + __popcll(nz & ((1ull << lane) - 1))] = ref_pack((uint32_t)i, (uint32_t)ch.n_out, (uint32_t)i * (uint32_t)ch.n_out);
         len += __popcll(nz);
     }
-    if (lane == 0) {
-        ch.collen[j] = len;
-        ch.colin[j] = len;
-    }
+    if (lane == 0) ch.collen[j] = len;
     if (j == 0)
         for (int i = lane; i < ch.n_in; i += WAVE) {
             ch.rows[i] = RowInfo{ch.qints[3 * i], ch.qints[3 * i + 1], ch.qints[3 * i + 2], ch.lats[i]};
@@ -640,10 +644,8 @@ template <class Cell, bool SHARDED = false> __global__ void __launch_bounds__(SE
     int *s_len = reinterpret_cast<int *>(s_cnt + 6 * Kpad);                           // [n_out + 1] list lengths -> offsets
     int *s_col = s_len + n_out + 1;                                                   // [n_out] matched columns
     int *s_bpos = s_col + n_out;                                                      // [n_out] 1 + position of a column in B's list, 0 = absent
-    int *s_cin = s_bpos + n_out;                                                      // [n_out] input rows at the head of a matched column's list
-    int *s_clen = s_cin + n_out;                                                      // [n_out] list length of every column (fetched while the arg-max runs)
-    int *s_cinall = s_clen + n_out;                                                   // [n_out] input rows at the head of every column's list
-    int *s_cm = s_cinall + n_out;                                                     // [n_out] 1 + index among the matched columns, 0 = not matched
+    int *s_clen = s_bpos + n_out;                                                     // [n_out] list length of every column (fetched while the arg-max runs)
+    int *s_cm = s_clen + n_out;                                                       // [n_out] 1 + index among the matched columns, 0 = not matched
     uint32_t *s_bits = reinterpret_cast<uint32_t *>(s_cm + n_out);                   // [claim_words] rows already claimed (if it fits)
     const int claim_words = g->claim_words;
     constexpr int NW = SEL_THREADS / WAVE;
@@ -685,7 +687,6 @@ template <class Cell, bool SHARDED = false> __global__ void __launch_bounds__(SE
     // critical path, so that no dependent load is left there
     for (int j = tid; j < n_out; j += SEL_THREADS) {
         s_clen[j] = ((const DA_GLOBAL int *)g->collen)[j];
-        s_cinall[j] = SHARDED ? 0 : ((const DA_GLOBAL int *)g->colin)[j];
         s_cm[j] = 0;
     }
     const int GPW = (n_groups + NW - 1) / NW;  // groups per wave, <= 4 * WAVE
@@ -972,7 +973,6 @@ template <class Cell, bool SHARDED = false> __global__ void __launch_bounds__(SE
                 if (!same && nbv == 0) atomicAnd(gen(&cb[B >> 5]), ~(1u << (B & 31)));
             }
             s_len[at] = s_clen[colA];  // the pre-append length: the new row itself is not a partner
-            s_cin[at] = s_cinall[colA];  // how many of them are input rows: those are made partners wholesale, only the tail is claimed
             s_col[at] = (int)colA;
             my_matches += popc32(O::plus(ma) | O::minus(ma));
         }
@@ -1009,7 +1009,6 @@ template <class Cell, bool SHARDED = false> __global__ void __launch_bounds__(SE
                 collen[j] = len + 1;
             } else
                 g->error = E_LIST_CAPACITY;
-            s_len[k] = len - s_cin[k];  // from here on: the length of the list's tail (rows created by substitutions)
         }
     }
     __syncthreads();
@@ -1055,12 +1054,9 @@ template <class Cell, bool SHARDED = false> __global__ void __launch_bounds__(SE
     total = s_len[m];
     }
     tp[5] = clock64();
-    // ---------------- (4) partner rows: every row that may share a substituted column, once, into the partner list -- by the
-    // first NW-6 waves; the last six waves store the six special pairs meanwhile.  A superset is harmless (a partner without
-    // digits in the substituted columns changes nothing), so ALL input rows are partners wholesale: they head every column
-    // list, and re-reading them m times was most of this phase.  Only the tails of the lists (rows created by
-    // substitutions) are read and de-duplicated.  A column-sharded chain leaves one flag per row instead of the list
-    // (exact: its lists are read whole).
+    // ---------------- (4) partner rows -- the rows that have digits in a substituted column -- into the partner list, by the
+    // first NW-6 waves; the last six waves store the six special pairs meanwhile.  A column-sharded chain leaves one flag per
+    // row instead (read from its column lists).
     constexpr int CLAIM_WAVES = NW - 6, CLAIM_THREADS = CLAIM_WAVES * WAVE;
     if (wid < CLAIM_WAVES) {
         if constexpr (SHARDED) {
@@ -1079,8 +1075,8 @@ template <class Cell, bool SHARDED = false> __global__ void __launch_bounds__(SE
         } else {
             // Partner rows = rows that have digits in a substituted column = OR of those columns' row bitmaps (A, B and the
             // new row masked out: their bits are being changed by this very kernel).  Word w of the OR covers rows 32 w ..;
-            // the set bits are counted, one LDS atomic per wave reserves the places, the row ids go to pl_ids; then, one
-            // thread per partner, the list reference is attached (a parallel gather from rowoff).
+            // the set bits are counted (DPP prefix sum), one LDS atomic per wave reserves the places, the row ids go to pl_ids;
+            // then, one thread per partner, the list reference is attached (a parallel gather from rowoff).
             const DA_GLOBAL uint32_t *cb = (const DA_GLOBAL uint32_t *)g->colbits;
             const int cbw = g->cb_words, nwords = (int)((Nw + 31) >> 5);
             DA_GLOBAL uint32_t *ids = (DA_GLOBAL uint32_t *)g->pl_ids;
@@ -1093,11 +1089,7 @@ template <class Cell, bool SHARDED = false> __global__ void __launch_bounds__(SE
                     if ((int)(B >> 5) == w) bits &= ~(1u << (B & 31));
                     if ((int)(Nw >> 5) == w) bits &= ~(1u << (Nw & 31));
                 }
-                int cnt = popc32(bits), inc = cnt;  // exclusive prefix inside the wave
-                for (int o = 1; o < WAVE; o <<= 1) {
-                    const int t = __shfl_up(inc, o);
-                    if (lane >= o) inc += t;
-                }
+                const int cnt = popc32(bits), inc = (int)wave_scan_add_u32((uint32_t)cnt);  // inclusive prefix inside the wave (DPP)
                 const int wave_total = __builtin_amdgcn_readlane(inc, WAVE - 1);
                 if (wave_total == 0) continue;
                 int base = 0;
@@ -1108,8 +1100,8 @@ template <class Cell, bool SHARDED = false> __global__ void __launch_bounds__(SE
                     bits &= bits - 1;
                 }
             }
-            // all claim waves have written their ids (named barrier over the claim waves only is not available: the six
-            // special-pair waves are elsewhere; so the references are attached after the block barrier below)
+            // the list references are attached after the block barrier below, one thread per partner: a parallel gather
+            // from rowoff (attaching them here, lane by lane inside the bit loop, serialises the look-ups: +3.6 us measured)
         }
     } else {
         const int sp = wid - CLAIM_WAVES;
@@ -1852,7 +1844,6 @@ size_t carve_chain(unsigned char *base, const ChainJob &job, const Geometry &g, 
     d.gtie = c.take<unsigned long long>(g.n_groups);
     d.gdirty = c.take<uint8_t>(g.n_groups);
     d.mcol = c.take<int>(n_out);
-    d.colin = c.take<int>(n_out);
     d.cmap = c.take<uint16_t>(n_out);
     d.colbits = c.take<uint32_t>(n_out * (size_t)((g.rcap + 31) / 32));
     d.pl_ids = c.take<uint32_t>(g.rcap);
@@ -2057,7 +2048,7 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
         size_t claim_bytes = ((size_t)geo[i].rcap + 31) / 32 * 4;
         if (claim_bytes > 64 * 1024) claim_bytes = 0;
         const size_t no = (size_t)jobs[i].n_out, cellb = geo[i].wide ? 8 : 4, entb = geo[i].wide ? 16 : 4;
-        size_t s = no * entb + 6 * (size_t)geo[i].Kpad * 4 + (7 * no + 1) * 4 + claim_bytes;
+        size_t s = no * entb + 6 * (size_t)geo[i].Kpad * 4 + (5 * no + 1) * 4 + claim_bytes;
         s = align_up(s, 16);
         sel_lds[w] = std::max(sel_lds[w], s);
         upd_lds[w] = std::max(upd_lds[w], align_up((size_t)UPD_WAVES * 4 * 3 * (size_t)geo[i].Kpad * 4 + 2 * no * cellb + no * 6, 16));
@@ -2463,7 +2454,7 @@ class HipShardEngine : public ShardEngine {
         else
             hipLaunchKernelGGL(k_init_cells<uint64_t>, colgrid, dim3(256), 0, st_, dd_);
         HIP_CHECK(hipGetLastError());
-        sel_lds_ = align_up((size_t)n_loc_ * (g.wide ? 16 : 4) + 6 * (size_t)g.Kpad * 4 + (7 * (size_t)n_loc_ + 1) * 4 + (size_t)d_.claim_words * 4, 16);
+        sel_lds_ = align_up((size_t)n_loc_ * (g.wide ? 16 : 4) + 6 * (size_t)g.Kpad * 4 + (5 * (size_t)n_loc_ + 1) * 4 + (size_t)d_.claim_words * 4, 16);
         if (sel_lds_ > 150 * 1024) throw std::runtime_error("selection kernel needs more than 150 KiB of LDS");
         if (!g.wide)
             HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_iter_select<uint32_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sel_lds_));
