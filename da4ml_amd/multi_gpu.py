@@ -29,7 +29,8 @@ def init(backend: str | None = None):
         torch.cuda.set_device(local)
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('MASTER_PORT', '29511')
+        if 'MASTER_PORT' not in os.environ:  # the ranks cannot agree on a free port by themselves: the launcher picks it
+            raise RuntimeError('WORLD_SIZE > 1 but MASTER_PORT is not set: start the ranks with torch.distributed.run or `python bench.py --gpus N`')
         dist.init_process_group(backend or ('nccl' if use_gpu else 'gloo'), rank=rank, world_size=world)
     return rank, world, local, device
 

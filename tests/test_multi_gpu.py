@@ -6,6 +6,8 @@ import subprocess
 import sys
 from pathlib import Path
 
+import pytest
+
 ROOT = Path(__file__).resolve().parent.parent
 
 WORKER = r'''
@@ -227,3 +229,15 @@ def test_column_sharded_chain_gloo_world2_and_3():
         for r in res:
             assert all(r['same']) and len(r['same']) == 8, r
             assert r['steps'] > 100 and r['steps'] == res[0]['steps']  # the ranks walked the same greedy steps
+
+
+def test_init_needs_a_port_from_the_launcher(monkeypatch):
+    """Ranks started without a rendezvous port must fail loudly instead of guessing one."""
+    from da4ml_amd import multi_gpu
+
+    monkeypatch.setenv('RANK', '0')
+    monkeypatch.setenv('WORLD_SIZE', '2')
+    monkeypatch.setenv('LOCAL_RANK', '0')
+    monkeypatch.delenv('MASTER_PORT', raising=False)
+    with pytest.raises(RuntimeError, match='MASTER_PORT'):
+        multi_gpu.init('gloo')
