@@ -1206,7 +1206,9 @@ __global__ void __launch_bounds__(UPD_THREADS, DA_UPD_OCC) __attribute__((amdgpu
     ChainDev *g = &chains[blockIdx.y];
     if (g->done) return;
     const int n_partners = g->n_partners;
-    if (n_partners == 0) return;
+    // the grid is sized for the partner counts of the first steps of a chain (thousands); later most blocks have nothing
+    // to do and leave before the hand-off is copied
+    if ((int)blockIdx.x * (UPD_WAVES * QN) >= n_partners) return;
     const Ctx c = make_ctx(g, 2 * g->iter - 1);
     const int m = g->m, nb = c.n_bits, Kpad = c.Kpad, n_out = c.n_out, K = c.K;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
