@@ -1780,7 +1780,8 @@ struct HipBackend::Impl {
     hipStream_t stream = nullptr;
     static constexpr int MAX_LANES = 8;
     hipStream_t lanes[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // greedy-loop streams of the chain groups
-    int n_lanes = 3;  // + the poll stream = 4 hardware queues
+    int n_lanes = 4;  // chain groups = greedy-loop streams.  Measured (C3 batch 64, loop ms): 2 -> 880, 3 -> 871, 4 -> 838, 5..8 -> 1470:
+                      // four hardware queues; the poll stream's rare copies share one of them at no visible cost
     int upd_total_blocks = 2560;  // k_iter_update blocks over all chains of a batch (4 waves x 4 groups each); measured (C3 batch 64,
                                   // solves/s): 1024: 45.3, 1536: 53.3, 2048: 53.8, 2560: 55.5, 4096: 47.5
     DeviceBuffer arena, desc_buf, io_buf;

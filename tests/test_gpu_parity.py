@@ -128,6 +128,33 @@ def test_capacity_retry(oracle):
     assert r['cost'] == want.cost and r['n_ops'] == [len(s.ops) for s in want.solutions]
 
 
+def test_capacity_retry_at_128x128_against_the_reference_record():
+    """the same at a size where the arenas matter: 128x128 int8 with arenas 50x / 20x too small must retry
+    and still deliver the digest of the record made by oracle/_ref/libref.so (tests/golden/large_chain_golden.json)"""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    rec = json.loads((Path(__file__).parent / 'golden' / 'large_chain_golden.json').read_text())['128x128_seed0_single_chain_ref']
+    code = (
+        "import sys; sys.path.insert(0, '.'); sys.path.insert(0, 'tests')\n"
+        "from cases import int_matrix\nfrom da4ml_amd import _binary as hip\nimport json, hashlib\n"
+        f"opts = json.loads({json.dumps(json.dumps(rec['opts']))})\n"
+        "p = hip.solve(int_matrix(0, 128, 128, -128, 128), **opts)\n"
+        "dump = json.loads(json.dumps(p, default=lambda o: o.to_dict()))\n"
+        "print(json.dumps({'cost': p.cost, 'n_ops': [len(s.ops) for s in p.solutions], 'retries': hip.timings()['retries'],\n"
+        "                  'sha256': hashlib.sha256(json.dumps(dump, separators=(',', ':')).encode()).hexdigest()}))\n"
+    )
+    env = dict(os.environ, DA4ML_HIP_TABLE_SCALE='0.02', DA4ML_HIP_ROW_SCALE='0.05')
+    out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, cwd=str(Path(__file__).resolve().parent.parent))
+    assert out.returncode == 0, out.stderr
+    r = json.loads(out.stdout.strip().splitlines()[-1])
+    assert r['retries'] >= 1
+    assert r['cost'] == rec['cost'] and r['n_ops'] == rec['n_ops'] and r['sha256'] == rec['sha256']
+
+
 def test_c3_256x256_seed0_against_oracle_record(hip):
     """BASELINE C3 matrices: digest of the full GPU result against the records of the 70-minute CPU oracle runs
     (tests/golden/large_chain_golden.json: 128x128 seed 0 and 256x256 seeds 0..; records named *_ref come from oracle/_ref/libref.so,

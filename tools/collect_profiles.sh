@@ -12,8 +12,8 @@ python bench.py --steps 2 --warmup 1 > $OUT/bench.json 2> $OUT/bench.err
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o c3 -- python bench.py --steps 1 --warmup 0 --cpu-seconds 0 --no-verify > $OUT/trace.log 2>&1
 cp $OUT/trace/c3_kernel_stats.csv $OUT/kernel_stats.csv 2>/dev/null
 rm -rf $OUT/trace   # large per-dispatch trace: the stats summary is what gets committed
-# 3. PMC passes (counters only, own runs) at the BENCHED batch of 64 = 3 chain groups of 21-22 chains per dispatch
-echo '{"batch": 64, "groups": 3, "chains_per_dispatch": 21.333333}' > $OUT/pmc_meta.json
+# 3. PMC passes (counters only, own runs) at the BENCHED batch of 64 = 4 chain groups of 16 chains per dispatch
+echo '{"batch": 64, "groups": 4, "chains_per_dispatch": 16.0}' > $OUT/pmc_meta.json
 if [ -n "${QUICK:-}" ]; then SETS=("FETCH_SIZE" "WRITE_SIZE"); else SETS=("FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS" "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum"); fi
 for SET in "${SETS[@]}"; do
   NAME=$(echo $SET | tr ' ' '_' | cut -c1-40)
