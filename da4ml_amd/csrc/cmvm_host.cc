@@ -288,7 +288,7 @@ static bool host_chain(const ChainJob &job, ChainOut &out) {
     return true;
 }
 
-StageResult finalize_chain(const ChainJob &job, const ChainOut &out) {
+StageResult finalize_chain(const ChainJob &job, const ChainOut &out, int inner_threads) {
     if (out.error != E_OK) throw std::runtime_error("CMVM chain failed on the device (error " + std::to_string(out.error) + ")");
     StageResult r;
     r.n_in = job.n_in;
@@ -313,58 +313,115 @@ StageResult finalize_chain(const ChainJob &job, const ChainOut &out) {
             throw std::runtime_error("device latency model diverged from the host libm at iteration " + std::to_string(t));
         r.ops.push_back(OpRec{a, b, (int64_t)sub, shift, qint_add(oa.q, ob.q, shift, false, sub), lat, cost});
     }
-    // one min-heap reduction per output column (cmvm_core.cc:103-210)
-    std::vector<Term> heap;
-    auto cmp = [](const Term &x, const Term &y) { return term_after(x, y); };
-    for (int j = 0; j < job.n_out; ++j) {
-        heap.clear();
-        for (uint32_t k = out.col_start[j]; k < out.col_start[j + 1]; ++k) {
-            uint64_t cell = out.dig_cell[k];
-            uint32_t plus = (uint32_t)cell, minus = (uint32_t)(cell >> 32), any = plus | minus;
-            int64_t row = out.dig_row[k];
-            while (any) {
-                int pos = __builtin_ctz(any);
-                any &= any - 1;
-                const OpRec &o = r.ops[row];
-                heap.push_back(Term{o.latency, (int64_t)((minus >> pos) & 1), magnitude_bits(o.q) + pos, o.q, row, pos});
+    // One min-heap reduction per output column (cmvm_core.cc:103-210).  The columns are independent: a tree op refers to
+    // pick / input ops (ids < n_fixed, final already) and to earlier ops of its own column only.  Chunks of columns are
+    // therefore reduced on `inner_threads` host threads with chunk-local ids (n_fixed + position in the chunk's op list;
+    // the order relations the heap looks at are the same as with the final ids) and concatenated in column order.
+    const int64_t n_fixed = (int64_t)r.ops.size();
+    struct Chunk {
+        std::vector<OpRec> ops;
+        std::vector<int64_t> idx, shift, neg;  // per column of the chunk; idx in chunk-local numbering
+    };
+    const int n_out = job.n_out;
+    const int n_chunks = inner_threads > 1 ? std::min(n_out, inner_threads * 4) : 1;
+    std::vector<Chunk> chunks((size_t)n_chunks);
+    auto reduce_chunk = [&](int c) {
+        Chunk &ck = chunks[c];
+        const int j0 = (int)((long long)n_out * c / n_chunks), j1 = (int)((long long)n_out * (c + 1) / n_chunks);
+        std::vector<Term> heap;
+        auto cmp = [](const Term &x, const Term &y) { return term_after(x, y); };
+        auto op_at = [&](int64_t id) -> const OpRec & { return id < n_fixed ? r.ops[id] : ck.ops[id - n_fixed]; };
+        for (int j = j0; j < j1; ++j) {
+            heap.clear();
+            for (uint32_t k = out.col_start[j]; k < out.col_start[j + 1]; ++k) {
+                uint64_t cell = out.dig_cell[k];
+                uint32_t plus = (uint32_t)cell, minus = (uint32_t)(cell >> 32), any = plus | minus;
+                int64_t row = out.dig_row[k];
+                while (any) {
+                    int pos = __builtin_ctz(any);
+                    any &= any - 1;
+                    const OpRec &o = op_at(row);
+                    heap.push_back(Term{o.latency, (int64_t)((minus >> pos) & 1), magnitude_bits(o.q) + pos, o.q, row, pos});
+                }
             }
+            if (heap.empty()) {
+                ck.idx.push_back(-1);
+                ck.shift.push_back(out.shift1[j]);
+                ck.neg.push_back(0);
+                continue;
+            }
+            if (heap.size() == 1) {
+                ck.idx.push_back(heap[0].id);
+                ck.shift.push_back((int64_t)out.shift1[j] + heap[0].shift);
+                ck.neg.push_back(heap[0].neg);
+                continue;
+            }
+            std::make_heap(heap.begin(), heap.end(), cmp);
+            while (heap.size() > 1) {
+                std::pop_heap(heap.begin(), heap.end(), cmp);
+                Term first = heap.back();
+                heap.pop_back();
+                std::pop_heap(heap.begin(), heap.end(), cmp);
+                Term second = heap.back();
+                heap.pop_back();
+                // the result is anchored on the non-negated operand when the first one is negative
+                const Term &base = first.neg ? second : first, &other = first.neg ? first : second;
+                int64_t sh = other.shift - base.shift;
+                bool sub_op = first.neg ? (second.neg == 0) : (second.neg != 0);
+                QInt q = qint_add(base.q, other.q, sh, base.neg != 0, other.neg != 0);
+                float dlat, cost;
+                cost_add(base.q, other.q, sh, sub_op, job.adder_size, job.carry_size, dlat, cost);
+                float lat = std::max(first.lat, second.lat) + dlat;
+                int64_t id = n_fixed + (int64_t)ck.ops.size();
+                ck.ops.push_back(OpRec{base.id, other.id, (int64_t)sub_op, sh, q, lat, cost});
+                heap.push_back(Term{lat, first.neg & second.neg, magnitude_bits(q) + base.shift, q, id, base.shift});
+                std::push_heap(heap.begin(), heap.end(), cmp);
+            }
+            ck.idx.push_back(n_fixed + (int64_t)ck.ops.size() - 1);
+            ck.neg.push_back(heap[0].neg);
+            ck.shift.push_back((int64_t)out.shift1[j] + heap[0].shift);
         }
-        if (heap.empty()) {
-            r.out_idxs.push_back(-1);
-            r.out_shifts.push_back(out.shift1[j]);
-            r.out_negs.push_back(0);
-            continue;
+    };
+    if (n_chunks == 1)
+        reduce_chunk(0);
+    else {
+        std::atomic<int> next{0};
+        std::exception_ptr err;
+        std::mutex err_mu;
+        auto work = [&] {
+            for (int c = next++; c < n_chunks; c = next++) {
+                try {
+                    reduce_chunk(c);
+                } catch (...) {
+                    std::lock_guard<std::mutex> lk(err_mu);
+                    if (!err) err = std::current_exception();
+                }
+            }
+        };
+        std::vector<std::thread> pool;
+        for (int t = 1; t < std::min(inner_threads, n_chunks); ++t) pool.emplace_back(work);
+        work();
+        for (auto &t : pool) t.join();
+        if (err) std::rethrow_exception(err);
+    }
+    size_t total = r.ops.size();
+    for (const Chunk &ck : chunks) total += ck.ops.size();
+    r.ops.reserve(total);
+    r.out_idxs.reserve(n_out);
+    r.out_shifts.reserve(n_out);
+    r.out_negs.reserve(n_out);
+    for (Chunk &ck : chunks) {
+        const int64_t off = (int64_t)r.ops.size() - n_fixed;  // chunk-local id -> final id
+        for (OpRec &o : ck.ops) {
+            if (o.id0 >= n_fixed) o.id0 += off;
+            if (o.id1 >= n_fixed) o.id1 += off;
+            r.ops.push_back(o);
         }
-        if (heap.size() == 1) {
-            r.out_idxs.push_back(heap[0].id);
-            r.out_shifts.push_back((int64_t)out.shift1[j] + heap[0].shift);
-            r.out_negs.push_back(heap[0].neg);
-            continue;
+        for (size_t k = 0; k < ck.idx.size(); ++k) {
+            r.out_idxs.push_back(ck.idx[k] >= n_fixed ? ck.idx[k] + off : ck.idx[k]);
+            r.out_shifts.push_back(ck.shift[k]);
+            r.out_negs.push_back(ck.neg[k]);
         }
-        std::make_heap(heap.begin(), heap.end(), cmp);
-        while (heap.size() > 1) {
-            std::pop_heap(heap.begin(), heap.end(), cmp);
-            Term first = heap.back();
-            heap.pop_back();
-            std::pop_heap(heap.begin(), heap.end(), cmp);
-            Term second = heap.back();
-            heap.pop_back();
-            // the result is anchored on the non-negated operand when the first one is negative
-            const Term &base = first.neg ? second : first, &other = first.neg ? first : second;
-            int64_t sh = other.shift - base.shift;
-            bool sub_op = first.neg ? (second.neg == 0) : (second.neg != 0);
-            QInt q = qint_add(base.q, other.q, sh, base.neg != 0, other.neg != 0);
-            float dlat, cost;
-            cost_add(base.q, other.q, sh, sub_op, job.adder_size, job.carry_size, dlat, cost);
-            float lat = std::max(first.lat, second.lat) + dlat;
-            int64_t id = (int64_t)r.ops.size();
-            r.ops.push_back(OpRec{base.id, other.id, (int64_t)sub_op, sh, q, lat, cost});
-            heap.push_back(Term{lat, first.neg & second.neg, magnitude_bits(q) + base.shift, q, id, base.shift});
-            std::push_heap(heap.begin(), heap.end(), cmp);
-        }
-        r.out_idxs.push_back((int64_t)r.ops.size() - 1);
-        r.out_negs.push_back(heap[0].neg);
-        r.out_shifts.push_back((int64_t)out.shift1[j] + heap[0].shift);
     }
     return r;
 }
@@ -638,7 +695,11 @@ std::vector<PipeResult> solve_batch_unique(Backend &be, const std::vector<Proble
                 throw std::runtime_error("Unknown method: " + (owners[k].what == 2 ? c.method1 : c.method0));
             }
         std::vector<StageResult> sols(jobs.size());
-        parallel_for(jobs.size(), [&](size_t k) { sols[k] = finalize_chain(jobs[k], outs[k]); });
+        // the chains are spread over the host threads first; what is left of the machine works on the columns of each
+        // chain (256 cores for the 64 chains of the benchmark: 4 threads per chain)
+        const size_t hw_threads = std::max(1u, std::thread::hardware_concurrency());
+        const int inner = (int)std::max<size_t>(1, std::min<size_t>(8, hw_threads / std::max<size_t>(1, std::min<size_t>(jobs.size(), 64))));
+        parallel_for(jobs.size(), [&](size_t k) { sols[k] = finalize_chain(jobs[k], outs[k], outs[k].dig_row.size() >= 4096 ? inner : 1); });
         if (std::getenv("DA4ML_HIP_VERBOSE"))
             std::fprintf(stderr, "[da4ml_hip] round of %zu chains: run_chains %.2f ms, adder trees %.2f ms\n", jobs.size(),
                          std::chrono::duration<double, std::milli>(t_fin - t_rc).count(),

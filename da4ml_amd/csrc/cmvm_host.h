@@ -108,7 +108,7 @@ void kernel_decompose(Backend &be, const float *kernel, int n_in, int n_out, int
                       std::vector<float> &m1);
 
 // cmvm_core.cc:89-225 from a finished chain
-StageResult finalize_chain(const ChainJob &job, const ChainOut &out);
+StageResult finalize_chain(const ChainJob &job, const ChainOut &out, int inner_threads = 1);  // inner_threads: host threads for the per-column trees
 
 // api.cc:147-250 for a batch of independent problems (one entry per matrix); problems progress together so
 // that every round submits all currently runnable chains to the backend at once.
