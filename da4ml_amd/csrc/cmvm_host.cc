@@ -698,8 +698,13 @@ std::vector<PipeResult> solve_batch_unique(Backend &be, const std::vector<Proble
         // the chains are spread over the host threads first; what is left of the machine works on the columns of each
         // chain (256 cores for the 64 chains of the benchmark: 4 threads per chain)
         const size_t hw_threads = std::max(1u, std::thread::hardware_concurrency());
-        const int inner = (int)std::max<size_t>(1, std::min<size_t>(8, hw_threads / std::max<size_t>(1, std::min<size_t>(jobs.size(), 64))));
-        parallel_for(jobs.size(), [&](size_t k) { sols[k] = finalize_chain(jobs[k], outs[k], outs[k].dig_row.size() >= 4096 ? inner : 1); });
+        int inner = (int)std::max<size_t>(1, std::min<size_t>(8, hw_threads / std::max<size_t>(1, std::min<size_t>(jobs.size(), 64))));
+        size_t inner_from = 4096;  // digits of a chain from which the extra threads pay
+        if (const char *e = std::getenv("DA4ML_HIP_TREE_THREADS")) {  // test hook: force the chunked reduction on small chains too
+            inner = std::max(1, std::atoi(e));
+            inner_from = 0;
+        }
+        parallel_for(jobs.size(), [&](size_t k) { sols[k] = finalize_chain(jobs[k], outs[k], outs[k].dig_row.size() >= inner_from ? inner : 1); });
         if (std::getenv("DA4ML_HIP_VERBOSE"))
             std::fprintf(stderr, "[da4ml_hip] round of %zu chains: run_chains %.2f ms, adder trees %.2f ms\n", jobs.size(),
                          std::chrono::duration<double, std::milli>(t_fin - t_rc).count(),

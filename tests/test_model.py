@@ -113,3 +113,15 @@ def test_default_search_record_64(model):
     dump = json.loads(json.dumps(p, default=lambda o: o.to_dict()))
     assert p.cost == rec['cost'] and [len(s.ops) for s in p.solutions] == rec['n_ops']
     assert hashlib.sha256(json.dumps(dump, separators=(',', ':')).encode()).hexdigest() == rec['sha256']
+
+
+def test_adder_trees_on_several_host_threads(model, oracle, monkeypatch):
+    """finalize_chain reduces chunks of output columns on several host threads with chunk-local op ids; the op list must not
+    depend on the number of threads / chunks (DA4ML_HIP_TREE_THREADS forces the chunked path on small chains)"""
+    cases = [(int_matrix(3, 24, 40, -128, 128), dict(method0='wmc', method1='wmc', decompose_dc=-1, search_all_decompose_dc=False)),
+             (int_matrix(4, 32, 5, -8, 8), dict()), (int_matrix(5, 7, 33, -128, 128), dict(adder_size=1, carry_size=-1))]  # fmt: skip
+    for k, opts in cases:
+        want = oracle.solve(k, **opts)
+        for threads in ('1', '2', '5', '64'):
+            monkeypatch.setenv('DA4ML_HIP_TREE_THREADS', threads)
+            assert model.solve(k, **opts) == want, (k.shape, opts, threads)
