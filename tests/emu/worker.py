@@ -1,0 +1,143 @@
+"""Worker of tests/test_emulated_device.py: runs in a process whose DA4ML_HIP_LIB points at tests/emu/libda4ml_emu.so, i.e.
+the product's Python layer, C ABI, host logic AND kernels, the latter executed thread by thread on the CPU.  Everything is
+compared with the oracle; one JSON line on stdout.  usage: worker.py <what> [args]"""
+
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent.parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / 'tests'))
+
+import numpy as np  # noqa: E402
+from cases import int_matrix, random_case  # noqa: E402
+
+from da4ml_amd import _binary as hip  # noqa: E402
+from oracle.oracle import Oracle  # noqa: E402
+
+SINGLE = dict(method0='wmc', method1='wmc', decompose_dc=-1, search_all_decompose_dc=False)
+
+
+def out(**kw):
+    print(json.dumps(kw), flush=True)
+
+
+def random_cases(lo, hi):
+    o = Oracle('port')
+    bad = []
+    for seed in range(lo, hi):
+        k, opts, _ = random_case(seed)
+        if hip.solve(k, **opts) != o.solve(k, **opts):
+            bad.append(seed)
+    out(bad=bad, n=hi - lo)
+
+
+def layouts():
+    """both entry layouts and their boundaries: narrow u32 entries (<= 256 columns, <= 12 digits) and the wide 16-byte ones"""
+    o = Oracle('port')
+    cases = {
+        'narrow_12_digits': (int_matrix(1, 6, 5, -2048, 2048), SINGLE),
+        'wide_13_digits': (int_matrix(2, 6, 5, -4096, 4096), SINGLE),
+        'wide_fractional': (int_matrix(3, 5, 6, -128, 128).astype(np.float32) / 64.0, SINGLE),
+        'columns_256': (int_matrix(4, 3, 256, -2, 2), SINGLE),
+        'columns_257': (int_matrix(5, 3, 257, -2, 2), SINGLE),
+        'one_row': (int_matrix(6, 1, 20, -128, 128), SINGLE),
+        'one_column': (int_matrix(7, 20, 1, -128, 128), SINGLE),
+        'zeros': (np.zeros((4, 4), np.float32), SINGLE),
+        'default_search': (int_matrix(8, 12, 12, -32, 32), {}),
+    }
+    bad = [name for name, (k, opts) in cases.items() if hip.solve(k, **opts) != o.solve(k, **opts)]
+    out(bad=bad, n=len(cases))
+
+
+def batch():
+    """many chains per launch, repeated problems, mixed shapes (both layouts in one batch)"""
+    o = Oracle('port')
+    ks = [int_matrix(s, 6 + s % 5, 4 + s % 7, -64, 64) for s in range(12)] + [int_matrix(3, 9, 7, -64, 64), int_matrix(40, 4, 5, -8192, 8192)]
+    got = hip.solve_many(ks, **SINGLE)
+    bad = [i for i, k in enumerate(ks) if got[i] != o.solve(k, **SINGLE)]
+    tm = hip.timings()
+    out(bad=bad, n=len(ks), chains=tm['chains'])
+
+
+def retry():
+    """arena heuristics far too small (environment set by the test): capacity error on the device, rerun with larger arenas"""
+    o = Oracle('port')
+    k = int_matrix(0, 20, 20, -128, 128)
+    p = hip.solve(k, **SINGLE)
+    out(equal=p == o.solve(k, **SINGLE), retries=hip.timings()['retries'])
+
+
+def shard_single():
+    """the column-sharded engine (k_cs_* kernels, k_iter_select<SHARDED>) with one rank: exchanges are no-ops"""
+    o = Oracle('port')
+    bad = []
+    for seed, shape in ((1, (10, 12)), (2, (7, 5)), (3, (4, 300))):
+        k = int_matrix(seed, *shape, -16, 16)
+        p, st = hip.solve_sharded(k, **SINGLE)
+        if p != o.solve(k, **SINGLE) or st['sharded_chains'] < 1:
+            bad.append(seed)
+    out(bad=bad)
+
+
+def shard_rank():
+    """one rank of a gloo job: the HIP shard engine of every rank runs on its own emulated device"""
+    import ctypes as C
+    import hashlib
+
+    import torch
+    import torch.distributed as dist
+
+    from da4ml_amd import multi_gpu as mg
+
+    rank, world, _, _ = mg.init('gloo')
+    FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_int64, C.c_int)
+
+    def allreduce(ctx, buf, count, on_device):  # the emulated device's memory is host memory
+        t = torch.from_numpy(np.ctypeslib.as_array((C.c_int32 * count).from_address(buf)))
+        dist.all_reduce(t)
+
+    cb = FN(allreduce)
+
+    def solver(kernel, allreduce=None, **kw):
+        return hip.solve_sharded(kernel, allreduce=cb, **kw)
+
+    digests = []
+    for seed, shape, opts in ((1, (10, 12), SINGLE), (2, (9, 7), {}), (3, (6, 5), dict(adder_size=1, carry_size=-1))):
+        k = int_matrix(seed, *shape, -16, 16)
+        p = mg.solve_column_sharded(k, sharded_solver=solver, **opts)
+        dump = json.dumps(json.loads(json.dumps(p, default=lambda x: x.to_dict())), separators=(',', ':'))
+        digests.append(hashlib.sha256(dump.encode()).hexdigest())
+    if rank == 0:
+        o = Oracle('port')
+        want = []
+        for seed, shape, opts in ((1, (10, 12), SINGLE), (2, (9, 7), {}), (3, (6, 5), dict(adder_size=1, carry_size=-1))):
+            p = o.solve(int_matrix(seed, *shape, -16, 16), **opts)
+            want.append(hashlib.sha256(json.dumps(json.loads(json.dumps(p, default=lambda x: x.to_dict())), separators=(',', ':')).encode()).hexdigest())
+        Path(os.environ['EMU_OUT']).write_text(json.dumps({'equal': digests == want}))
+    gathered = [None] * world
+    dist.all_gather_object(gathered, digests)
+    assert all(g == digests for g in gathered)
+    mg.shutdown()
+
+
+def dais():
+    """k_dais_run on the emulated device against the host executor"""
+    from dais_cases import random_program
+
+    bad = []
+    for seed in range(12):
+        prog, x = random_program(seed, n_samples=70)  # more than one wavefront of samples
+        if not np.array_equal(hip.dais_interp_run(prog, x, executor='device'), hip.dais_interp_run(prog, x, executor='host')):
+            bad.append(seed)
+    out(bad=bad)
+
+
+if __name__ == '__main__':
+    t0 = time.time()
+    what = sys.argv[1]
+    {'random': lambda: random_cases(int(sys.argv[2]), int(sys.argv[3])), 'layouts': layouts, 'batch': batch, 'retry': retry,
+     'shard_single': shard_single, 'shard_rank': shard_rank, 'dais': dais}[what]()  # fmt: skip
