@@ -41,7 +41,7 @@ struct Machine {
     Fiber *cur = nullptr;
     void (*tramp)(void *) = nullptr;
     void *closure = nullptr;
-    std::vector<unsigned char> lds;
+    unsigned char *lds = nullptr;  // dynamic LDS of the running launch: an allocation of exactly the requested size
 };
 thread_local Machine *g_m = nullptr;
 std::mutex g_launch_mutex;  // one emulated device: launches from different host threads take turns
@@ -171,7 +171,7 @@ void block_barrier() {
     yield_to_scheduler();
 }
 
-unsigned char *dyn_shared() { return g_m->lds.data(); }
+unsigned char *dyn_shared() { return g_m->lds; }
 
 void launch_impl(dim3 grid, dim3 block, size_t lds, void (*tramp)(void *), void *closure) {
     std::lock_guard<std::mutex> lk(g_launch_mutex);
@@ -188,7 +188,10 @@ void launch_impl(dim3 grid, dim3 block, size_t lds, void (*tramp)(void *), void 
         std::fprintf(stderr, "hipemu: unsupported block shape\n");
         std::abort();
     }
-    m->lds.assign(lds + 64, 0);
+    void *dyn = nullptr;  // exactly the requested size: a sanitizer build sees overruns of the LDS carve
+    if (posix_memalign(&dyn, 16, lds ? lds : 1) != 0) std::abort();
+    std::memset(dyn, 0, lds);
+    m->lds = static_cast<unsigned char *>(dyn);
     m->tramp = tramp;
     m->closure = closure;
     Machine *outer = g_m;
@@ -206,6 +209,8 @@ void launch_impl(dim3 grid, dim3 block, size_t lds, void (*tramp)(void *), void 
             }
     g_m = outer;
     g_ctx = outer_ctx;
+    m->lds = nullptr;
+    std::free(dyn);
 }
 
 }  // namespace hipemu

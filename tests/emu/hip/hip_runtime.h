@@ -217,7 +217,7 @@ inline hipError_t hipSetDevice(int) { return hipSuccess; }
 inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
 inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 inline hipError_t hipMemGetInfo(size_t *free_b, size_t *total_b) { *free_b = (size_t)3 << 30; *total_b = (size_t)4 << 30; return hipSuccess; }
-inline hipError_t hipMalloc(void **p, size_t n) { *p = std::aligned_alloc(256, (n + 255) / 256 * 256 + 256); return *p ? hipSuccess : 2; }
+inline hipError_t hipMalloc(void **p, size_t n) { return posix_memalign(p, 256, n ? n : 1) == 0 ? hipSuccess : 2; }  // exact size: a sanitizer build sees overruns
 template <class T> inline hipError_t hipMalloc(T **p, size_t n) { return hipMalloc((void **)p, n); }
 inline hipError_t hipFree(void *p) { std::free(p); return hipSuccess; }
 inline hipError_t hipHostMalloc(void **p, size_t n, unsigned = 0) { return hipMalloc(p, n); }

@@ -81,3 +81,19 @@ def test_column_sharded_engine_two_ranks_gloo(emu, tmp_path):
 
 def test_dais_device_executor(emu):
     assert emu('dais')['bad'] == []
+
+
+def test_kernels_under_address_sanitizer():
+    """the same library built with AddressSanitizer: no out-of-bounds access of static or dynamic LDS, of device allocations
+    or of per-thread arrays in any kernel on the layout, batch and sharded-engine cases"""
+    r = subprocess.run(['make', '-s', '-C', str(EMU_DIR), 'asan'], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    runtime = subprocess.run(['make', '-s', '-C', str(EMU_DIR), 'asan-runtime'], capture_output=True, text=True).stdout.strip()
+    if not Path(runtime).exists():
+        pytest.skip('no AddressSanitizer runtime in this toolchain')
+    base = dict(os.environ, DA4ML_HIP_LIB=str(EMU_DIR / 'build' / 'libda4ml_emu_asan.so'), DA4ML_HIP_UPD_BLOCKS='64', LD_PRELOAD=runtime,
+                ASAN_OPTIONS='detect_leaks=0:detect_stack_use_after_return=0:abort_on_error=1')  # fmt: skip
+    for what, extra in (('layouts', {}), ('batch', {}), ('shard_single', {'DA4ML_SHARD_FORCE': '1'})):
+        out = subprocess.run([sys.executable, str(EMU_DIR / 'worker.py'), what], env=dict(base, **extra), capture_output=True, text=True, cwd=str(ROOT), timeout=900)
+        assert out.returncode == 0 and 'AddressSanitizer' not in out.stderr, (what, out.stderr[-3000:])
+        assert json.loads(out.stdout.strip().splitlines()[-1])['bad'] == [], what
