@@ -17,6 +17,30 @@
 #include <mutex>
 #include <vector>
 
+// ThreadSanitizer build (make tsan): every GPU thread is a TSan fiber, the scheduler switches WITHOUT a synchronisation
+// edge, and the only happens-before edges are the ones the machine gives: launch boundaries, block barriers, and the
+// rendezvous of the lanes at a wave-level operation.  Two plain accesses of the same location from different threads
+// with none of these in between -- inside a block or across the blocks of a launch -- are reported as a data race.
+// This file itself is compiled WITHOUT instrumentation (-DHIPEMU_TSAN only): the scheduler's bookkeeping is not kernel data.
+#ifdef HIPEMU_TSAN
+extern "C" {
+// The runtime's interface for managed heaps is the one public way to make it forget the access history of a range that is
+// not malloc'ed: the section of the __shared__ statics is registered as such a heap and 're-allocated' at every block start.
+void __tsan_java_init(unsigned long heap_begin, unsigned long heap_size);
+void __tsan_java_alloc(unsigned long ptr, unsigned long size);
+void __tsan_java_free(unsigned long ptr, unsigned long size);
+void *__tsan_get_current_fiber(void);
+void *__tsan_create_fiber(unsigned flags);
+void __tsan_destroy_fiber(void *fiber);
+void __tsan_switch_to_fiber(void *fiber, unsigned flags);
+void __tsan_acquire(void *addr);
+void __tsan_release(void *addr);
+}
+#define TSAN_ONLY(x) x
+#else
+#define TSAN_ONLY(x)
+#endif
+
 namespace hipemu {
 
 thread_local ThreadCtx *g_ctx = nullptr;
@@ -30,6 +54,8 @@ struct Fiber {
     uint64_t val = 0;
     Snap *out = nullptr;
     ThreadCtx ctx;
+    void *tsan = nullptr, *tsan_pool[3] = {nullptr, nullptr, nullptr};
+    int stack_slot = 0;
 };
 constexpr size_t STACK_BYTES = 256 << 10;
 constexpr int MAX_THREADS = 1024;
@@ -42,6 +68,16 @@ struct Machine {
     void (*tramp)(void *) = nullptr;
     void *closure = nullptr;
     unsigned char *lds = nullptr;  // dynamic LDS of the running launch: an allocation of exactly the requested size
+    size_t lds_bytes = 0;
+    unsigned long block_counter = 0;  // blocks run so far, over all launches
+    void *sched_tsan = nullptr;
+    // addresses of the happens-before edges.  The barrier and wave objects of a block come from a pool and are never shared
+    // with another block of the launch: a shared object would order the blocks through their barriers
+    char launch_sync = 0, done_sync = 0;
+    static constexpr size_t SYNC_POOL = 1 << 20;
+    std::vector<char> sync_pool;
+    size_t sync_next = 0;
+    char *bar_sync = nullptr, *wave_sync[MAX_THREADS / WAVE] = {nullptr};
 };
 thread_local Machine *g_m = nullptr;
 std::mutex g_launch_mutex;  // one emulated device: launches from different host threads take turns
@@ -70,9 +106,38 @@ hipemu_switch:
 .size hipemu_switch,.-hipemu_switch
 )");
 
+#ifdef HIPEMU_TSAN
+// Drop the race detector's access history of a range (memory that changes hands WITHOUT a happens-before edge: the LDS of the
+// next block, the stack of the next thread).  The runtime's managed-heap interface is the one public way to do that for
+// memory that is not malloc'ed; the "heap" registered with it is the whole address space.
+constexpr size_t STACK_WINDOW = 8 << 10;   // the part of a fiber stack the kernels can reach (measured: < 2 KB); checked at every switch
+void forget(const void *p, size_t n) {
+    static bool registered = false;
+    if (!registered) {
+        __tsan_java_init(8ul, (1ul << 47) - 16);
+        registered = true;
+    }
+    unsigned long lo = ((unsigned long)p + 7) & ~7ul, hi = ((unsigned long)p + n) & ~7ul;
+    if (hi > lo) {
+        __tsan_java_free(lo, hi - lo);
+        __tsan_java_alloc(lo, hi - lo);
+    }
+}
+#endif
+
 void yield_to_scheduler() {
     Machine *m = g_m;
     Fiber *f = m->cur;
+#ifdef HIPEMU_TSAN
+    {
+        const uintptr_t top = (uintptr_t)(m->stacks + (size_t)(f->stack_slot + 1) * STACK_BYTES), here = (uintptr_t)__builtin_frame_address(0);
+        if (top - here > STACK_WINDOW - 1024) {
+            std::fprintf(stderr, "hipemu: a kernel thread uses more stack than the race detector's window\n");
+            std::abort();
+        }
+    }
+#endif
+    TSAN_ONLY(__tsan_switch_to_fiber(m->sched_tsan, 1);)
     hipemu_switch(&f->sp, m->sched_sp);
     g_ctx = &f->ctx;  // resumed
 }
@@ -81,15 +146,19 @@ extern "C" void hipemu_fiber_main() {
     Machine *m = g_m;
     Fiber *f = m->cur;
     g_ctx = &f->ctx;
+    TSAN_ONLY(__tsan_acquire(&m->launch_sync);)  // everything the host did before the launch
     m->tramp(m->closure);
+    TSAN_ONLY(__tsan_release(&m->done_sync);)
     f->state = DONE;
+    TSAN_ONLY(__tsan_switch_to_fiber(m->sched_tsan, 1);)
     hipemu_switch(&f->sp, m->sched_sp);
     std::abort();  // a finished fiber is never resumed
 }
 
-void prepare(Machine *m, int t) {
+void prepare(Machine *m, int t, int stack_slot) {
     Fiber &f = m->fibers[t];
-    uintptr_t top = (uintptr_t)(m->stacks + (size_t)(t + 1) * STACK_BYTES);
+    f.stack_slot = stack_slot;
+    uintptr_t top = (uintptr_t)(m->stacks + (size_t)(stack_slot + 1) * STACK_BYTES);
     top &= ~(uintptr_t)15;
     void **sp = (void **)top;
     *--sp = nullptr;                         // keeps the entry frame 16-byte aligned (as after a call)
@@ -97,15 +166,48 @@ void prepare(Machine *m, int t) {
     for (int r = 0; r < 6; ++r) *--sp = nullptr;  // rbp rbx r12 r13 r14 r15
     f.sp = sp;
     f.state = RUNNABLE;
+#ifdef HIPEMU_TSAN
+    // The detector sees the accesses of one of its fibers as program-ordered, whoever ran on it.  Thread t of consecutive
+    // blocks must therefore never share a detector fiber; three generations are kept and used in turn (creating and
+    // destroying one per GPU thread costs ~60 us each, which made the race-detecting build unusable).
+    void *&slot = f.tsan_pool[m->block_counter % 3];
+    if (!slot) slot = __tsan_create_fiber(0);
+    f.tsan = slot;
+    forget((const void *)(top - STACK_WINDOW), STACK_WINDOW);
+#endif
+}
+
+// word-by-word through volatile: no memcpy call, which a sanitizer runtime would intercept and attribute to the scheduler
+void deliver(Snap *to, const Snap &from) {
+    volatile uint64_t *d = reinterpret_cast<volatile uint64_t *>(to);
+    const uint64_t *s = reinterpret_cast<const uint64_t *>(&from);
+    for (size_t i = 0; i < sizeof(Snap) / sizeof(uint64_t); ++i) d[i] = s[i];
 }
 
 void run(Machine *m, Fiber &f) {
     m->cur = &f;
+    TSAN_ONLY(__tsan_switch_to_fiber(f.tsan, 1);)  // 1 = no synchronisation between the two fibers
     hipemu_switch(&m->sched_sp, f.sp);
     m->cur = nullptr;
 }
 
+extern "C" char __start_hipemu_lds[] __attribute__((weak)), __stop_hipemu_lds[] __attribute__((weak));  // the __shared__ statics
+
 void run_block(Machine *m, int n_threads) {
+#ifdef HIPEMU_TSAN
+    // Every block has its own LDS on the real machine: what earlier blocks did to these bytes is not a conflict.  The
+    // history of the static section and of the dynamic carve is dropped, then the block's threads are given everything the
+    // scheduler (= the host) has done so far -- and nothing any other GPU thread of this launch has done.
+    {
+        if (&__start_hipemu_lds[0] && &__stop_hipemu_lds[0] > &__start_hipemu_lds[0]) forget(__start_hipemu_lds, (size_t)(&__stop_hipemu_lds[0] - &__start_hipemu_lds[0]));
+        if (m->lds_bytes) forget(m->lds, m->lds_bytes);
+        __tsan_release(&m->launch_sync);
+        if (m->sync_pool.empty()) m->sync_pool.assign(Machine::SYNC_POOL, 0);
+        auto next = [&]() { return &m->sync_pool[m->sync_next++ % Machine::SYNC_POOL]; };
+        m->bar_sync = next();
+        for (int w = 0; w < MAX_THREADS / WAVE; ++w) m->wave_sync[w] = next();
+    }
+#endif
     const int n_waves = (n_threads + WAVE - 1) / WAVE;
     int live = n_threads;
     while (live > 0) {
@@ -137,7 +239,7 @@ void run_block(Machine *m, int n_threads) {
                     }
                 for (int t = l0; t < l1; ++t)
                     if (m->fibers[t].state == AT_WAVE_OP && m->fibers[t].site == site) {
-                        *m->fibers[t].out = s;
+                        deliver(m->fibers[t].out, s);
                         m->fibers[t].state = RUNNABLE;
                     }
             }
@@ -158,17 +260,23 @@ void run_block(Machine *m, int n_threads) {
 }  // namespace
 
 void wave_exchange(uint64_t my_val, const void *site, Snap &out) {
-    Fiber *f = g_m->cur;
+    Machine *m = g_m;
+    Fiber *f = m->cur;
     f->state = AT_WAVE_OP;
     f->site = site;
     f->val = my_val;
     f->out = &out;
+    TSAN_ONLY(char *ws = m->wave_sync[(f - m->fibers.data()) / WAVE]; __tsan_release(ws);)
     yield_to_scheduler();
+    TSAN_ONLY(__tsan_acquire(ws);)  // the lanes of a wavefront are in lockstep at a wave-level operation
 }
 
 void block_barrier() {
-    g_m->cur->state = AT_BARRIER;
+    Machine *m = g_m;
+    m->cur->state = AT_BARRIER;
+    TSAN_ONLY(__tsan_release(m->bar_sync);)
     yield_to_scheduler();
+    TSAN_ONLY(__tsan_acquire(m->bar_sync);)
 }
 
 unsigned char *dyn_shared() { return g_m->lds; }
@@ -188,25 +296,29 @@ void launch_impl(dim3 grid, dim3 block, size_t lds, void (*tramp)(void *), void 
         std::fprintf(stderr, "hipemu: unsupported block shape\n");
         std::abort();
     }
-    void *dyn = nullptr;  // exactly the requested size: a sanitizer build sees overruns of the LDS carve
+    void *dyn = nullptr;  // dynamic LDS, exactly the requested size: an address-sanitizer build sees overruns of the carve
     if (posix_memalign(&dyn, 16, lds ? lds : 1) != 0) std::abort();
-    std::memset(dyn, 0, lds);
     m->lds = static_cast<unsigned char *>(dyn);
+    m->lds_bytes = lds;
     m->tramp = tramp;
     m->closure = closure;
     Machine *outer = g_m;
     ThreadCtx *outer_ctx = g_ctx;
     g_m = m;
+    TSAN_ONLY(m->sched_tsan = __tsan_get_current_fiber();)
     for (unsigned bz = 0; bz < grid.z; ++bz)
         for (unsigned by = 0; by < grid.y; ++by)
             for (unsigned bx = 0; bx < grid.x; ++bx) {
                 for (int t = 0; t < n_threads; ++t) {
-                    prepare(m, t);
+                    prepare(m, t, t);
                     const unsigned ut = (unsigned)t;  // linear thread id: x fastest, wavefronts of 64 consecutive ids
                     m->fibers[t].ctx = ThreadCtx{dim3(ut % block.x, ut / block.x % block.y, ut / (block.x * block.y)), dim3(bx, by, bz), block, grid};
                 }
+                for (size_t i = 0; i < lds; ++i) static_cast<volatile unsigned char *>(dyn)[i] = 0;  // not memset: see deliver()
                 run_block(m, n_threads);
+                ++m->block_counter;
             }
+    TSAN_ONLY(__tsan_acquire(&m->done_sync);)  // a launch is complete when the host continues
     g_m = outer;
     g_ctx = outer_ctx;
     m->lds = nullptr;

@@ -20,7 +20,9 @@
 #define __device__
 #define __host__
 #define __constant__
-#define __shared__ static  // blocks run one at a time on one thread: function-local statics are the block's LDS variables
+// Blocks run one at a time on one thread: function-local statics are the block's LDS variables.  They live in a section of
+// their own so that a race-detecting build can declare them new memory at every block start (LDS is per block).
+#define __shared__ static __attribute__((section("hipemu_lds")))
 #define __forceinline__ inline __attribute__((always_inline))
 #define __launch_bounds__(...)
 #define HIP_SYMBOL(x) x
@@ -187,17 +189,32 @@ inline long long wall_clock64() { return (long long)__rdtsc(); }
 template <class A, class B> inline typename std::common_type<A, B>::type max(A a, B b) { return a > b ? a : b; }
 template <class A, class B> inline typename std::common_type<A, B>::type min(A a, B b) { return a < b ? a : b; }
 
-// atomics: kernels run one thread at a time
-template <class T, class U> inline T atomicAdd(T *p, U v) { T o = *p; *p = (T)(o + (T)v); return o; }
-template <class T, class U> inline T atomicSub(T *p, U v) { T o = *p; *p = (T)(o - (T)v); return o; }
-template <class T, class U> inline T atomicMax(T *p, U v) { T o = *p; if ((T)v > o) *p = (T)v; return o; }
-template <class T, class U> inline T atomicMin(T *p, U v) { T o = *p; if ((T)v < o) *p = (T)v; return o; }
-template <class T, class U> inline T atomicOr(T *p, U v) { T o = *p; *p = (T)(o | (T)v); return o; }
-template <class T, class U> inline T atomicAnd(T *p, U v) { T o = *p; *p = (T)(o & (T)v); return o; }
-template <class T, class U> inline T atomicExch(T *p, U v) { T o = *p; *p = (T)v; return o; }
-template <class T, class U, class V> inline T atomicCAS(T *p, U cmp, V v) { T o = *p; if (o == (T)cmp) *p = (T)v; return o; }
-#define __hip_atomic_load(p, order, scope) (*(p))
-#define __hip_atomic_store(p, v, order, scope) (*(p) = (v))
+// atomics: kernels run one thread at a time; real atomic builtins all the same, so that a ThreadSanitizer build of the
+// library (race detection, emu_runtime.cc) knows which accesses are atomic
+template <class T, class U> inline T atomicAdd(T *p, U v) { return __atomic_fetch_add(p, (T)v, __ATOMIC_RELAXED); }
+template <class T, class U> inline T atomicSub(T *p, U v) { return __atomic_fetch_sub(p, (T)v, __ATOMIC_RELAXED); }
+template <class T, class U> inline T atomicOr(T *p, U v) { return __atomic_fetch_or(p, (T)v, __ATOMIC_RELAXED); }
+template <class T, class U> inline T atomicAnd(T *p, U v) { return __atomic_fetch_and(p, (T)v, __ATOMIC_RELAXED); }
+template <class T, class U> inline T atomicExch(T *p, U v) { return __atomic_exchange_n(p, (T)v, __ATOMIC_RELAXED); }
+template <class T, class U> inline T atomicMax(T *p, U v) {
+    T o = __atomic_load_n(p, __ATOMIC_RELAXED);
+    while ((T)v > o && !__atomic_compare_exchange_n(p, &o, (T)v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {
+    }
+    return o;
+}
+template <class T, class U> inline T atomicMin(T *p, U v) {
+    T o = __atomic_load_n(p, __ATOMIC_RELAXED);
+    while ((T)v < o && !__atomic_compare_exchange_n(p, &o, (T)v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {
+    }
+    return o;
+}
+template <class T, class U, class V> inline T atomicCAS(T *p, U cmp, V v) {
+    T o = (T)cmp;
+    __atomic_compare_exchange_n(p, &o, (T)v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED);
+    return o;
+}
+#define __hip_atomic_load(p, order, scope) __atomic_load_n((p), __ATOMIC_RELAXED)
+#define __hip_atomic_store(p, v, order, scope) __atomic_store_n((p), (v), __ATOMIC_RELAXED)
 #define __hip_atomic_fetch_add(p, v, order, scope) atomicAdd((p), (v))
 
 // ------------------------------------------------------------------------------------------------ runtime API

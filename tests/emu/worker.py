@@ -124,6 +124,21 @@ def shard_rank():
     mg.shutdown()
 
 
+def race_cases():
+    """workload of the race-detector run (no oracle in this process: its OpenMP runtime is not instrumented); the digests are
+    compared by the caller.  Several partner rows per update block, two chains per launch, both entry layouts, an insert-heavy
+    default search"""
+    import hashlib
+
+    def digest(p):
+        return hashlib.sha256(json.dumps(json.loads(json.dumps(p, default=lambda x: x.to_dict())), separators=(',', ':')).encode()).hexdigest()
+
+    ks = [int_matrix(1, 28, 5, -128, 128), int_matrix(3, 5, 4, -4096, 4096)]
+    got = hip.solve_many(ks, **SINGLE)
+    tm = hip.timings()
+    out(digests=[digest(p) for p in got] + [digest(hip.solve(int_matrix(4, 8, 8, -32, 32)))], partners_per_step=tm['partners'] / max(tm['iterations'], 1))
+
+
 def dais():
     """k_dais_run on the emulated device against the host executor"""
     from dais_cases import random_program
@@ -140,4 +155,4 @@ if __name__ == '__main__':
     t0 = time.time()
     what = sys.argv[1]
     {'random': lambda: random_cases(int(sys.argv[2]), int(sys.argv[3])), 'layouts': layouts, 'batch': batch, 'retry': retry,
-     'shard_single': shard_single, 'shard_rank': shard_rank, 'dais': dais}[what]()  # fmt: skip
+     'shard_single': shard_single, 'shard_rank': shard_rank, 'dais': dais, 'race_cases': race_cases}[what]()  # fmt: skip

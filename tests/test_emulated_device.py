@@ -97,3 +97,51 @@ def test_kernels_under_address_sanitizer():
         out = subprocess.run([sys.executable, str(EMU_DIR / 'worker.py'), what], env=dict(base, **extra), capture_output=True, text=True, cwd=str(ROOT), timeout=900)
         assert out.returncode == 0 and 'AddressSanitizer' not in out.stderr, (what, out.stderr[-3000:])
         assert json.loads(out.stdout.strip().splitlines()[-1])['bad'] == [], what
+
+
+def _tsan_runtime():
+    r = subprocess.run(['make', '-s', '-C', str(EMU_DIR), 'tsan'], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    runtime = subprocess.run(['make', '-s', '-C', str(EMU_DIR), 'tsan-runtime'], capture_output=True, text=True).stdout.strip()
+    if not Path(runtime).exists():
+        pytest.skip('no ThreadSanitizer runtime in this toolchain')
+    return runtime
+
+
+def test_race_detector_sees_what_it_should():
+    """the race-detecting build of the emulated device (GPU threads as ThreadSanitizer fibers; happens-before only through launch
+    boundaries, block barriers and wave-level rendezvous) on kernels with known races and on their repaired versions"""
+    _tsan_runtime()
+    exe = EMU_DIR / 'build' / 'race_selftest'
+    for case in ('clean_barrier', 'clean_wave', 'clean_atomic', 'clean_launches', 'race_blocks', 'race_blocks_after_barrier', 'race_waves', 'race_lanes'):
+        out = subprocess.run([str(exe), case], env=dict(os.environ, TSAN_OPTIONS='halt_on_error=0 exitcode=0'), capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, (case, out.stderr[-2000:])
+        reports = out.stderr.count('WARNING: ThreadSanitizer: data race')
+        assert (reports >= 1) if case.startswith('race_') else (reports == 0), (case, reports, out.stderr[-3000:])
+
+
+def test_kernels_have_no_unexpected_data_race(oracle):
+    """the product under that detector: a batch of two chains (several partner rows per update block, both entry layouts) and a
+    default search.  The only races allowed are the two by-design patterns of the pair table listed, with their reasons, in
+    tests/emu/tsan_benign.supp; the results must still be the oracle's"""
+    import hashlib
+
+    import numpy as np  # noqa: F401
+    from cases import int_matrix
+
+    runtime = _tsan_runtime()
+    env = dict(os.environ, DA4ML_HIP_LIB=str(EMU_DIR / 'build' / 'libda4ml_emu_tsan.so'), DA4ML_HIP_UPD_BLOCKS='64', LD_PRELOAD=runtime,
+               TSAN_OPTIONS=f'halt_on_error=0 exitcode=0 history_size=2 suppressions={EMU_DIR / "tsan_benign.supp"}')  # fmt: skip
+    out = subprocess.run([sys.executable, str(EMU_DIR / 'worker.py'), 'race_cases'], env=env, capture_output=True, text=True, cwd=str(ROOT), timeout=1800)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert 'WARNING: ThreadSanitizer' not in out.stderr, out.stderr[:6000]
+    r = json.loads(out.stdout.strip().splitlines()[-1])
+    assert r['partners_per_step'] > 16  # more than one update block had work
+
+    def digest(p):
+        return hashlib.sha256(json.dumps(json.loads(json.dumps(p, default=lambda x: x.to_dict())), separators=(',', ':')).encode()).hexdigest()
+
+    single = dict(method0='wmc', method1='wmc', decompose_dc=-1, search_all_decompose_dc=False)
+    want = [digest(oracle.solve(int_matrix(1, 28, 5, -128, 128), **single)), digest(oracle.solve(int_matrix(3, 5, 4, -4096, 4096), **single)),
+            digest(oracle.solve(int_matrix(4, 8, 8, -32, 32)))]  # fmt: skip
+    assert r['digests'] == want
