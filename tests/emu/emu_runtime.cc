@@ -117,7 +117,7 @@ void forget(const void *p, size_t n) {
         __tsan_java_init(8ul, (1ul << 47) - 16);
         registered = true;
     }
-    unsigned long lo = ((unsigned long)p + 7) & ~7ul, hi = ((unsigned long)p + n) & ~7ul;
+    unsigned long lo = (unsigned long)p & ~7ul, hi = ((unsigned long)p + n + 7) & ~7ul;  // whole 8-byte cells (allocations are 16-byte granular)
     if (hi > lo) {
         __tsan_java_free(lo, hi - lo);
         __tsan_java_alloc(lo, hi - lo);

@@ -1,7 +1,7 @@
 // TEST INFRASTRUCTURE -- does the ThreadSanitizer build of the emulated device see what it is supposed to see?
 // Small kernels with and without the races the detector is meant for; built with -fsanitize=thread and run by
 // tests/test_emulated_device.py, which expects a report for every racy case and none for the clean ones.
-//   usage: race_selftest <case>     cases: clean_barrier clean_wave clean_atomic clean_launches race_blocks race_blocks_after_barrier race_waves race_lanes
+//   usage: race_selftest <case>     cases: clean_barrier clean_wave clean_atomic clean_lds_blocks clean_launches race_blocks race_blocks_after_barrier race_waves race_lanes
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -31,6 +31,17 @@ __global__ void k_lanes(int *p, int use_fence) {  // lane 0 writes, lane 1 reads
     if (use_fence) __builtin_amdgcn_wave_barrier();
     if (threadIdx.x == 1) p[0] = box;
 }
+__global__ void k_lds_per_block(int *p) {  // LDS is per block: the same static and dynamic bytes in every block, no conflict
+    __shared__ int acc;
+    int *dyn = reinterpret_cast<int *>(::hipemu::dyn_shared());
+    if (threadIdx.x == 0) acc = 0;
+    if (threadIdx.x < 7) dyn[threadIdx.x] = 0;
+    __syncthreads();
+    atomicAdd(&acc, 1);
+    atomicAdd(&dyn[threadIdx.x % 7], 1);
+    __syncthreads();
+    if (threadIdx.x == 0) p[blockIdx.x] = acc + dyn[0];
+}
 __global__ void k_write(int *p) { p[threadIdx.x] = (int)threadIdx.x; }
 __global__ void k_read(const int *p, int *q) { q[threadIdx.x] = p[(threadIdx.x + 1) % 128]; }
 
@@ -47,6 +58,7 @@ int main(int argc, char **argv) {
     else if (!std::strcmp(what, "clean_barrier")) hipLaunchKernelGGL(k_waves, dim3(1), dim3(128), 0, nullptr, p, 1);
     else if (!std::strcmp(what, "race_lanes")) hipLaunchKernelGGL(k_lanes, dim3(1), dim3(64), 0, nullptr, p, 0);
     else if (!std::strcmp(what, "clean_wave")) hipLaunchKernelGGL(k_lanes, dim3(1), dim3(64), 0, nullptr, p, 1);
+    else if (!std::strcmp(what, "clean_lds_blocks")) hipLaunchKernelGGL(k_lds_per_block, dim3(5), dim3(256), 28, nullptr, p);  // 28: not a whole number of 8-byte cells
     else if (!std::strcmp(what, "clean_launches")) {  // a kernel boundary orders everything
         hipLaunchKernelGGL(k_write, dim3(1), dim3(128), 0, nullptr, p);
         hipLaunchKernelGGL(k_read, dim3(1), dim3(128), 0, nullptr, p, q);

@@ -113,7 +113,7 @@ def test_race_detector_sees_what_it_should():
     boundaries, block barriers and wave-level rendezvous) on kernels with known races and on their repaired versions"""
     _tsan_runtime()
     exe = EMU_DIR / 'build' / 'race_selftest'
-    for case in ('clean_barrier', 'clean_wave', 'clean_atomic', 'clean_launches', 'race_blocks', 'race_blocks_after_barrier', 'race_waves', 'race_lanes'):
+    for case in ('clean_barrier', 'clean_wave', 'clean_atomic', 'clean_lds_blocks', 'clean_launches', 'race_blocks', 'race_blocks_after_barrier', 'race_waves', 'race_lanes'):
         out = subprocess.run([str(exe), case], env=dict(os.environ, TSAN_OPTIONS='halt_on_error=0 exitcode=0'), capture_output=True, text=True, timeout=300)
         assert out.returncode == 0, (case, out.stderr[-2000:])
         reports = out.stderr.count('WARNING: ThreadSanitizer: data race')
