@@ -1199,16 +1199,21 @@ __device__ __forceinline__ unsigned long long row_max_u64(unsigned long long v) 
 }
 
 template <class Cell>
-__global__ void __launch_bounds__(UPD_THREADS, DA_UPD_OCC) __attribute__((amdgpu_num_sgpr(DA_UPD_SGPRS))) k_iter_update(ChainDev *chains) {
+__global__ void __launch_bounds__(UPD_THREADS, DA_UPD_OCC) __attribute__((amdgpu_num_sgpr(DA_UPD_SGPRS))) k_iter_update(ChainDev *chains, int n_chains) {
     using F = RowFmt<Cell>;
     using Entry = typename F::Entry;
     constexpr int QCW = sizeof(Cell) == 4 ? 2 : 4;  // count words per lane: narrow layout Kpad / 2 <= 24 words, wide <= 60
-    ChainDev *g = &chains[blockIdx.y];
+    // Grid (chains padded to a multiple of 8, blocks per chain): the chain index is the FAST grid dimension.  Workgroups go to
+    // the XCDs round-robin by their linear id, so all blocks of chain c -- and block c of k_iter_select, which has the same
+    // linear id modulo 8 -- run on XCD c mod 8: the table lines, bounds and lists of a chain stay in ONE of the eight
+    // non-coherent L2s instead of being spread over all of them.
+    if ((int)blockIdx.x >= n_chains) return;
+    ChainDev *g = &chains[blockIdx.x];
     if (g->done) return;
     const int n_partners = g->n_partners;
     // the grid is sized for the partner counts of the first steps of a chain (thousands); later most blocks have nothing
     // to do and leave before the hand-off is copied
-    if ((int)blockIdx.x * (UPD_WAVES * QN) >= n_partners) return;
+    if ((int)blockIdx.y * (UPD_WAVES * QN) >= n_partners) return;
     const Ctx c = make_ctx(g, 2 * g->iter - 1);
     const int m = g->m, nb = c.n_bits, Kpad = c.Kpad, n_out = c.n_out, K = c.K;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1251,7 +1256,7 @@ __global__ void __launch_bounds__(UPD_THREADS, DA_UPD_OCC) __attribute__((amdgpu
 #define DA_UPD_CH 4  // measured on MI355X (C3 batch 64): 1 -> 52.7, 2 -> 53.8, 4 -> 54.5 solves/s
 #endif
     constexpr int CH = DA_UPD_CH;  // list chunks (16 entries each) fetched together; longer lists continue in the loop below
-    const int total_waves = (int)gridDim.x * UPD_WAVES, gw = (int)blockIdx.x * UPD_WAVES + wid;
+    const int total_waves = (int)gridDim.y * UPD_WAVES, gw = (int)blockIdx.y * UPD_WAVES + wid;
     unsigned long long ref_next = gw * QN + q < n_partners ? plist[gw * QN + q] : 0ull;
     for (int base = gw * QN; base < n_partners; base += total_waves * QN) {
         const int idx = base + q;
@@ -2120,9 +2125,9 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
             hipLaunchKernelGGL(k_iter_select<uint64_t>, dim3(gr.count), dim3(SEL_THREADS), sel_lds[1], gr.stream, base, im.d_done);
         if (se) HIP_CHECK(hipEventRecord(se[1], gr.stream));
         if (gr.w == 0)
-            hipLaunchKernelGGL(k_iter_update<uint32_t>, dim3(upd_blocks[0], gr.count), dim3(UPD_THREADS), upd_lds[0], gr.stream, base);
+            hipLaunchKernelGGL(k_iter_update<uint32_t>, dim3((gr.count + 7) & ~7, upd_blocks[0]), dim3(UPD_THREADS), upd_lds[0], gr.stream, base, gr.count);
         else
-            hipLaunchKernelGGL(k_iter_update<uint64_t>, dim3(upd_blocks[1], gr.count), dim3(UPD_THREADS), upd_lds[1], gr.stream, base);
+            hipLaunchKernelGGL(k_iter_update<uint64_t>, dim3((gr.count + 7) & ~7, upd_blocks[1]), dim3(UPD_THREADS), upd_lds[1], gr.stream, base, gr.count);
         if (se) HIP_CHECK(hipEventRecord(se[2], gr.stream));
     };
     // Windows of up to WINDOW_ITERS iterations x all groups are queued eagerly; one event-bracketed iteration per window
