@@ -5,7 +5,6 @@ compared with the oracle; one JSON line on stdout.  usage: worker.py <what> [arg
 import json
 import os
 import sys
-import time
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent.parent
@@ -152,7 +151,6 @@ def dais():
 
 
 if __name__ == '__main__':
-    t0 = time.time()
     what = sys.argv[1]
     {'random': lambda: random_cases(int(sys.argv[2]), int(sys.argv[3])), 'layouts': layouts, 'batch': batch, 'retry': retry,
      'shard_single': shard_single, 'shard_rank': shard_rank, 'dais': dais, 'race_cases': race_cases}[what]()  # fmt: skip
