@@ -1805,7 +1805,7 @@ HipBackend::HipBackend(int device) : impl_(new Impl) {
     for (int l = 1; l < Impl::MAX_LANES; ++l) HIP_CHECK(hipStreamCreateWithFlags(&impl_->lanes[l], hipStreamNonBlocking));
     if (const char *e = std::getenv("DA4ML_HIP_TABLE_SCALE")) impl_->table_scale = std::max(1e-4, std::atof(e));
     if (const char *e = std::getenv("DA4ML_HIP_ROW_SCALE")) row_scale_ = std::max(1e-4, std::atof(e));
-    if (const char *e = std::getenv("DA4ML_HIP_UPD_BLOCKS")) impl_->upd_total_blocks = std::max(64, std::atoi(e));
+    if (const char *e = std::getenv("DA4ML_HIP_UPD_BLOCKS")) impl_->upd_total_blocks = std::max(2, std::atoi(e));
     if (const char *e = std::getenv("DA4ML_HIP_LANES")) impl_->n_lanes = std::max(1, std::min((int)Impl::MAX_LANES, std::atoi(e)));
     HIP_CHECK(hipMalloc(&impl_->d_done, sizeof(unsigned int)));
     HIP_CHECK(hipHostMalloc(&impl_->h_done, 2 * sizeof(unsigned int), hipHostMallocDefault));

@@ -26,7 +26,7 @@ def emu():
     assert r.returncode == 0 and EMU_LIB.exists(), r.stdout[-2000:] + r.stderr[-2000:]
 
     def run(*args, env=None, timeout=900):
-        e = dict(os.environ, DA4ML_HIP_LIB=str(EMU_LIB), DA4ML_HIP_UPD_BLOCKS='64', **(env or {}))
+        e = dict(os.environ, DA4ML_HIP_LIB=str(EMU_LIB), DA4ML_HIP_UPD_BLOCKS='8', **(env or {}))
         out = subprocess.run([sys.executable, str(EMU_DIR / 'worker.py'), *map(str, args)], env=e, capture_output=True, text=True, cwd=str(ROOT), timeout=timeout)
         assert out.returncode == 0, out.stderr[-3000:]
         return json.loads(out.stdout.strip().splitlines()[-1])
@@ -71,7 +71,7 @@ def test_column_sharded_engine_two_ranks_gloo(emu, tmp_path):
     procs = []
     for rank in range(2):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE='2', LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
-                   DA4ML_HIP_LIB=str(EMU_LIB), DA4ML_HIP_UPD_BLOCKS='64', EMU_OUT=str(res))  # fmt: skip
+                   DA4ML_HIP_LIB=str(EMU_LIB), DA4ML_HIP_UPD_BLOCKS='8', EMU_OUT=str(res))  # fmt: skip
         procs.append(subprocess.Popen([sys.executable, str(EMU_DIR / 'worker.py'), 'shard_rank'], env=env, cwd=str(ROOT), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     for p in procs:
         _, err = p.communicate(timeout=600)
@@ -91,7 +91,7 @@ def test_kernels_under_address_sanitizer():
     runtime = subprocess.run(['make', '-s', '-C', str(EMU_DIR), 'asan-runtime'], capture_output=True, text=True).stdout.strip()
     if not Path(runtime).exists():
         pytest.skip('no AddressSanitizer runtime in this toolchain')
-    base = dict(os.environ, DA4ML_HIP_LIB=str(EMU_DIR / 'build' / 'libda4ml_emu_asan.so'), DA4ML_HIP_UPD_BLOCKS='64', LD_PRELOAD=runtime,
+    base = dict(os.environ, DA4ML_HIP_LIB=str(EMU_DIR / 'build' / 'libda4ml_emu_asan.so'), DA4ML_HIP_UPD_BLOCKS='8', LD_PRELOAD=runtime,
                 ASAN_OPTIONS='detect_leaks=0:detect_stack_use_after_return=0:abort_on_error=1')  # fmt: skip
     for what, extra in (('layouts', {}), ('batch', {}), ('shard_single', {'DA4ML_SHARD_FORCE': '1'})):
         out = subprocess.run([sys.executable, str(EMU_DIR / 'worker.py'), what], env=dict(base, **extra), capture_output=True, text=True, cwd=str(ROOT), timeout=900)
@@ -130,7 +130,7 @@ def test_kernels_have_no_unexpected_data_race(oracle):
     from cases import int_matrix
 
     runtime = _tsan_runtime()
-    env = dict(os.environ, DA4ML_HIP_LIB=str(EMU_DIR / 'build' / 'libda4ml_emu_tsan.so'), DA4ML_HIP_UPD_BLOCKS='64', LD_PRELOAD=runtime,
+    env = dict(os.environ, DA4ML_HIP_LIB=str(EMU_DIR / 'build' / 'libda4ml_emu_tsan.so'), DA4ML_HIP_UPD_BLOCKS='8', LD_PRELOAD=runtime,
                TSAN_OPTIONS=f'halt_on_error=0 exitcode=0 history_size=2 suppressions={EMU_DIR / "tsan_benign.supp"}')  # fmt: skip
     out = subprocess.run([sys.executable, str(EMU_DIR / 'worker.py'), 'race_cases'], env=env, capture_output=True, text=True, cwd=str(ROOT), timeout=1800)
     assert out.returncode == 0, out.stderr[-3000:]
