@@ -111,6 +111,14 @@ struct BlkHdr {
 // therefore keep their table / row / list pointers in the global address space (GLOBAL instructions, vmcnt only).
 #define DA_GLOBAL __attribute__((address_space(1)))
 template <class T> __device__ __forceinline__ T *gen(DA_GLOBAL T *p) { return (T *)p; }  // for the HIP atomic API
+// Wave-uniform values pinned into scalar registers at this point of the program.  The greedy-loop kernels read ~30 fields
+// of their chain descriptor; left alone, the compiler sinks each scalar load behind the early-exit branch that first needs
+// it and the prologue becomes a chain of 4-6 dependent scalar round trips to L2 (ISA reading, round 2).  Loading every
+// field first and pinning the values before the first branch makes it ONE round trip: an empty asm that "uses" the
+// register is a point the load cannot be moved past.
+#define DA_PIN_ASM(x) asm volatile("" : "+s"(x))
+template <class T> __device__ __forceinline__ void pin_one(T &v) { DA_PIN_ASM(v); }
+template <class... T> __device__ __forceinline__ void pin_sgpr(T &...v) { (pin_one(v), ...); }
 typedef float da_f4 __attribute__((ext_vector_type(4)));
 typedef int da_i4 __attribute__((ext_vector_type(4)));
 typedef unsigned int da_u2 __attribute__((ext_vector_type(2)));
@@ -1207,15 +1215,25 @@ __global__ void __launch_bounds__(UPD_THREADS, DA_UPD_OCC) __attribute__((amdgpu
     // the XCDs round-robin by their linear id, so all blocks of chain c -- and block c of k_iter_select, which has the same
     // linear id modulo 8 -- run on XCD c mod 8: the table lines, bounds and lists of a chain stay in ONE of the eight
     // non-coherent L2s instead of being spread over all of them.
-    if ((int)blockIdx.x >= n_chains) return;
-    ChainDev *g = &chains[blockIdx.x];
-    if (g->done) return;
-    const int n_partners = g->n_partners;
+    ChainDev *gq = &chains[(int)blockIdx.x < n_chains ? blockIdx.x : 0];  // clamped: the descriptor read below is unconditional
+    // ---- ONE scalar round trip: every descriptor field the block needs, pinned before the first branch (pin_sgpr)
+    int done = gq->done, n_partners = gq->n_partners, iter = gq->iter, m = gq->m, n_in = gq->n_in;
+    uint32_t A = gq->A, B = gq->B, Nw = gq->Nw;
+    Ctx c = make_ctx(gq, 2 * iter - 1);
+    const DA_GLOBAL int *mcol = (const DA_GLOBAL int *)gq->mcol;
+    const DA_GLOBAL Cell *mA = (const DA_GLOBAL Cell *)gq->mA, *mB = (const DA_GLOBAL Cell *)gq->mB;
+    const DA_GLOBAL uint16_t *cmap = (const DA_GLOBAL uint16_t *)gq->cmap;
+    const DA_GLOBAL Entry *rl = (const DA_GLOBAL Entry *)gq->rlist;
+    const DA_GLOBAL unsigned long long *plist = (const DA_GLOBAL unsigned long long *)gq->plist;
+    int grid_y = (int)gridDim.y;
+    pin_sgpr(done, n_partners, iter, m, n_in, A, B, Nw, grid_y, mcol, mA, mB, cmap, rl, plist);
+    pin_sgpr(c.n_out, c.n_bits, c.K, c.Kpad, c.method, c.gs_log2, c.pb_log2, c.cmask, c.windows, c.hkey, c.hrank, c.hblk, c.ub, c.gdirty, c.rows);
+    if ((int)blockIdx.x >= n_chains || done) return;
     // the grid is sized for the partner counts of the first steps of a chain (thousands); later most blocks have nothing
     // to do and leave before the hand-off is copied
     if ((int)blockIdx.y * (UPD_WAVES * QN) >= n_partners) return;
-    const Ctx c = make_ctx(g, 2 * g->iter - 1);
-    const int m = g->m, nb = c.n_bits, Kpad = c.Kpad, n_out = c.n_out, K = c.K;
+    ChainDev *g = gq;
+    const int nb = c.n_bits, Kpad = c.Kpad, n_out = c.n_out, K = c.K;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // LDS: consumed digits of A [n_out] and B [n_out] | per-wave, per-partner counters [UPD_WAVES][QN][3][Kpad] | the
     // substituted columns [n_out] | column -> 1 + index of the substituted column, 0 = not substituted [n_out]
@@ -1225,12 +1243,15 @@ __global__ void __launch_bounds__(UPD_THREADS, DA_UPD_OCC) __attribute__((amdgpu
     int *s_col = reinterpret_cast<int *>(s_cnt + (size_t)UPD_WAVES * QN * 3 * Kpad);
     uint16_t *s_cmap = reinterpret_cast<uint16_t *>(s_col + n_out);
     const int tid = threadIdx.x, lane = lane_id(), wid = wave_id();
+    const int q = lane >> 4, l = lane & (QG - 1), qsh = q * QG;
+    const int total_waves = grid_y * UPD_WAVES, gw = (int)blockIdx.y * UPD_WAVES + wid;
+    // ---- ONE vector round trip: the group's first partner reference and the new row's record leave together with the
+    // hand-off of k_iter_select (they used to wait behind the hand-off barrier: two more dependent round trips)
+    unsigned long long ref_next = gw * QN + q < n_partners ? plist[gw * QN + q] : 0ull;
+    const RowInfo rnew = load_row(c.rows, Nw);
     __shared__ unsigned int s_stat[2];
     if (tid < 2) s_stat[tid] = 0;
     {  // the hand-off of k_iter_select into LDS: one pass, one barrier (the column map arrives ready-made)
-        const DA_GLOBAL int *mcol = (const DA_GLOBAL int *)g->mcol;
-        const DA_GLOBAL Cell *mA = (const DA_GLOBAL Cell *)g->mA, *mB = (const DA_GLOBAL Cell *)g->mB;
-        const DA_GLOBAL uint16_t *cmap = (const DA_GLOBAL uint16_t *)g->cmap;
         for (int j = tid; j < n_out; j += UPD_THREADS) s_cmap[j] = cmap[j];
         for (int j = tid; j < m; j += UPD_THREADS) {
             s_col[j] = mcol[j];
@@ -1239,13 +1260,7 @@ __global__ void __launch_bounds__(UPD_THREADS, DA_UPD_OCC) __attribute__((amdgpu
         }
     }
     __syncthreads();
-    const uint32_t A = g->A, B = g->B, Nw = g->Nw;
     const bool same = A == B;
-    const int n_in = g->n_in;
-    const DA_GLOBAL Entry *rl = (const DA_GLOBAL Entry *)g->rlist;
-    const DA_GLOBAL unsigned long long *plist = (const DA_GLOBAL unsigned long long *)g->plist;
-    const RowInfo rnew = load_row(c.rows, Nw);
-    const int q = lane >> 4, l = lane & (QG - 1), qsh = q * QG;
     uint32_t *dA = s_cnt + ((size_t)wid * QN + q) * 3 * Kpad, *dB = dA + Kpad, *cN = dB + Kpad;  // this group's counters
     const int KW = Kpad / 2;  // 32-bit words of counts per block (two u16 counts each)
     unsigned int found = 0, inserts = 0;
@@ -1256,8 +1271,6 @@ __global__ void __launch_bounds__(UPD_THREADS, DA_UPD_OCC) __attribute__((amdgpu
 #define DA_UPD_CH 4  // measured on MI355X (C3 batch 64): 1 -> 52.7, 2 -> 53.8, 4 -> 54.5 solves/s
 #endif
     constexpr int CH = DA_UPD_CH;  // list chunks (16 entries each) fetched together; longer lists continue in the loop below
-    const int total_waves = (int)gridDim.y * UPD_WAVES, gw = (int)blockIdx.y * UPD_WAVES + wid;
-    unsigned long long ref_next = gw * QN + q < n_partners ? plist[gw * QN + q] : 0ull;
     for (int base = gw * QN; base < n_partners; base += total_waves * QN) {
         const int idx = base + q;
         const bool valid = idx < n_partners;
