@@ -80,8 +80,9 @@ constexpr int UPD_THREADS = 256;   // k_iter_update block
 constexpr int UPD_WAVES = UPD_THREADS / WAVE;
 constexpr int MAX_GROUPS = 4096;   // 16 waves x 64 lanes x 4 register-resident bounds in k_iter_select
 
-// Per-phase shader-clock timers of k_iter_update (tests/gpu_profile.py).  They cost SGPRs and VALU time, so they are
-// compiled in only with -DDA_PHASE_TIMERS (make PHASE_TIMERS=1).
+// Per-phase shader-clock timers of k_iter_select / k_iter_update (tests/gpu_profile.py).  They cost SGPRs, VALU time and --
+// every s_memtime is followed by a wait for all outstanding LDS and scalar operations -- latency on the dependent chain of
+// the select kernel (eight of them per launch), so they are compiled in only with -DDA_PHASE_TIMERS (make PHASE_TIMERS=1).
 #ifdef DA_PHASE_TIMERS
 #define UPD_TIMER_DECL long long up[5] = {0, 0, 0, 0, 0}, u0 = clock64(), u1;
 #define UPD_TIMER_MARK(i) \
@@ -91,10 +92,17 @@ constexpr int MAX_GROUPS = 4096;   // 16 waves x 64 lanes x 4 register-resident 
 #define UPD_TIMER_FLUSH \
     if (lane == 0)      \
         for (int q = 0; q < 5; ++q) atomicAdd(&g->st_phase[7 + q], (unsigned long long)up[q]);
+#define SEL_TIMER_DECL long long tp[8];
+#define SEL_TIMER_MARK(i) tp[i] = clock64();
+#define SEL_TIMER_FLUSH \
+    for (int q = 0; q < 7; ++q) g->st_phase[q] += (unsigned long long)(tp[q + 1] - tp[q]);
 #else
 #define UPD_TIMER_DECL
 #define UPD_TIMER_MARK(i)
 #define UPD_TIMER_FLUSH
+#define SEL_TIMER_DECL
+#define SEL_TIMER_MARK(i)
+#define SEL_TIMER_FLUSH
 #endif
 
 // header of a pair block's payload line (16 bytes, followed by the K u16 counts)
@@ -119,6 +127,16 @@ template <class T> __device__ __forceinline__ T *gen(DA_GLOBAL T *p) { return (T
 #define DA_PIN_ASM(x) asm volatile("" : "+s"(x))
 template <class T> __device__ __forceinline__ void pin_one(T &v) { DA_PIN_ASM(v); }
 template <class... T> __device__ __forceinline__ void pin_sgpr(T &...v) { (pin_one(v), ...); }
+// The same for per-lane values, and a compiler-level fence for memory operations.  "Load early, use late": a loaded value
+// that is first touched after pin_vgpr() / behind load_fence() is not waited for before that point, and loads in front of
+// the fence are not sunk behind it -- the loads of a phase leave together instead of one round trip after the other.
+#define DA_PIN_VASM(x) asm volatile("" : "+v"(x))
+template <class T> __device__ __forceinline__ void pin_vone(T &v) { DA_PIN_VASM(v); }
+template <class... T> __device__ __forceinline__ void pin_vgpr(T &...v) { (pin_vone(v), ...); }
+__device__ __forceinline__ void load_fence() {
+    asm volatile("" ::: "memory");         // the optimiser does not move memory operations across
+    __builtin_amdgcn_sched_barrier(0);      // nor does the instruction scheduler move anything (e.g. a wait + v_readfirstlane of
+}                                           // the first loaded value in front of the other loads)
 typedef float da_f4 __attribute__((ext_vector_type(4)));
 typedef int da_i4 __attribute__((ext_vector_type(4)));
 typedef unsigned int da_u2 __attribute__((ext_vector_type(2)));
@@ -126,6 +144,9 @@ typedef unsigned long long da_ul2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ RowInfo load_row(const DA_GLOBAL RowInfo *rows, size_t i) {
     const da_f4 v = *reinterpret_cast<const DA_GLOBAL da_f4 *>(rows + i);
     return RowInfo{v.x, v.y, v.z, v.w};
+}
+__device__ __forceinline__ RowInfo pick_row(bool first, const RowInfo &a, const RowInfo &b) {  // field by field: the records stay in registers
+    return RowInfo{first ? a.lo : b.lo, first ? a.hi : b.hi, first ? a.step : b.step, first ? a.lat : b.lat};
 }
 __device__ __forceinline__ void store_row(DA_GLOBAL RowInfo *rows, size_t i, const RowInfo &r) {
     *reinterpret_cast<DA_GLOBAL da_f4 *>(rows + i) = da_f4{r.lo, r.hi, r.step, r.lat};
@@ -323,7 +344,7 @@ struct Ctx {
     unsigned long long tomb;  // this launch's tombstone value
 };
 // launch_id: 2 * iteration for k_iter_select, 2 * iteration + 1 for k_iter_update (only the low two bits are used)
-__device__ __forceinline__ Ctx make_ctx(ChainDev *g, int launch_id) {
+__device__ __forceinline__ Ctx make_ctx_raw(ChainDev *g, int launch_id) {
     Ctx c;
     c.tomb = KEY_TOMB - (unsigned long long)(launch_id & 3);
     c.n_out = g->n_out;
@@ -334,7 +355,7 @@ __device__ __forceinline__ Ctx make_ctx(ChainDev *g, int launch_id) {
     c.gs_log2 = g->gs_log2;
     c.pb_log2 = g->pb_log2;
     c.cmask = g->cmask;
-    c.windows = g->C / WAVE ? g->C / WAVE : 1;
+    c.windows = g->C;  // raw here (nothing is computed between the descriptor loads: they leave as ONE batch); ctx_finish() scales it
     c.hkey = (DA_GLOBAL unsigned long long *)g->hkey;
     c.hrank = (DA_GLOBAL uint32_t *)g->hrank;
     c.hblk = (DA_GLOBAL unsigned char *)g->hblk;
@@ -342,6 +363,12 @@ __device__ __forceinline__ Ctx make_ctx(ChainDev *g, int launch_id) {
     c.gdirty = (DA_GLOBAL uint8_t *)g->gdirty;
     c.rows = (const DA_GLOBAL RowInfo *)g->rows;
     c.g = g;
+    return c;
+}
+__device__ __forceinline__ void ctx_finish(Ctx &c) { c.windows = c.windows / WAVE ? c.windows / WAVE : 1; }  // after the fields are pinned
+__device__ __forceinline__ Ctx make_ctx(ChainDev *g, int launch_id) {
+    Ctx c = make_ctx_raw(g, launch_id);
+    ctx_finish(c);
     return c;
 }
 // payload line of a slot: 16-byte header, then the counts
@@ -641,9 +668,31 @@ template <class Cell, bool SHARDED = false> __global__ void __launch_bounds__(SE
     using F = RowFmt<Cell>;
     using Entry = typename F::Entry;
     ChainDev *g = &chains[blockIdx.x];
-    const int was_done = g->done, had_error = g->error;  // read together with the rest of the descriptor: one round trip
-    const Ctx c = make_ctx(g, 2 * g->iter);
-    const int n_groups = g->n_groups, n_out = c.n_out, Kpad = c.Kpad, nb = c.n_bits, lcap = g->lcap;
+    // ---- ONE scalar round trip: every descriptor field the block needs, pinned before the first branch (pin_sgpr; left
+    // alone the compiler sinks each load behind the branch that first needs it -- ten dependent round trips in this kernel)
+    int was_done = g->done, had_error = g->error, iter = g->iter, n_groups = g->n_groups, lcap = g->lcap, claim_words = g->claim_words;
+    int n_rows0 = g->n_rows, rcap = g->rcap, cbw = g->cb_words, adder_size = g->adder_size, carry_size = g->carry_size;
+    uint32_t offN = g->rl_used, rl_cap = g->rl_cap, n_live0 = g->n_live, live_peak0 = g->live_peak;
+    Ctx c = make_ctx_raw(g, 2 * iter);
+    DA_GLOBAL int *collen = (DA_GLOBAL int *)g->collen;
+    DA_GLOBAL unsigned long long *gtie_arr = (DA_GLOBAL unsigned long long *)g->gtie;
+    DA_GLOBAL da_u2 *rowoff = (DA_GLOBAL da_u2 *)g->rowoff;
+    DA_GLOBAL Entry *rl = (DA_GLOBAL Entry *)g->rlist;
+    DA_GLOBAL Cell *mA = (DA_GLOBAL Cell *)g->mA, *mB = (DA_GLOBAL Cell *)g->mB;
+    DA_GLOBAL int *mcol = (DA_GLOBAL int *)g->mcol;
+    DA_GLOBAL unsigned long long *collist = (DA_GLOBAL unsigned long long *)g->collist;
+    DA_GLOBAL uint16_t *cmap = (DA_GLOBAL uint16_t *)g->cmap;
+    DA_GLOBAL uint32_t *colbits = (DA_GLOBAL uint32_t *)g->colbits;
+    DA_GLOBAL uint32_t *pl_ids = (DA_GLOBAL uint32_t *)g->pl_ids;
+    DA_GLOBAL unsigned long long *plist = (DA_GLOBAL unsigned long long *)g->plist;
+    DA_GLOBAL da_i4 *picks = (DA_GLOBAL da_i4 *)g->picks;
+    DA_GLOBAL int32_t *cs_slab = (DA_GLOBAL int32_t *)g->cs_slab, *cs_flags = (DA_GLOBAL int32_t *)g->cs_flags;
+    pin_sgpr(was_done, had_error, iter, n_groups, lcap, claim_words, n_rows0, rcap, cbw, adder_size, carry_size, offN, rl_cap, n_live0, live_peak0);
+    pin_sgpr(c.n_out, c.n_bits, c.K, c.Kpad, c.method, c.gs_log2, c.pb_log2, c.cmask, c.windows, c.hkey, c.hrank, c.hblk, c.ub, c.gdirty, c.rows);
+    pin_sgpr(collen, gtie_arr, rowoff, rl, mA, mB, mcol, collist, cmap, colbits, pl_ids, plist, picks);
+    if constexpr (SHARDED) pin_sgpr(cs_slab, cs_flags);
+    ctx_finish(c);
+    const int n_out = c.n_out, Kpad = c.Kpad, nb = c.n_bits;
     if (was_done) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // dynamic LDS carve: B's list | special-pair counters | per-matched-column scratch | column -> position in B | claim bitmap
@@ -655,7 +704,6 @@ template <class Cell, bool SHARDED = false> __global__ void __launch_bounds__(SE
     int *s_clen = s_bpos + n_out;                                                     // [n_out] list length of every column (fetched while the arg-max runs)
     int *s_cm = s_clen + n_out;                                                       // [n_out] 1 + index among the matched columns, 0 = not matched
     uint32_t *s_bits = reinterpret_cast<uint32_t *>(s_cm + n_out);                   // [claim_words] rows already claimed (if it fits)
-    const int claim_words = g->claim_words;
     constexpr int NW = SEL_THREADS / WAVE;
     __shared__ unsigned long long s_red_tie[NW], s_floor0, s_floor;
     __shared__ uint32_t s_red_rank[NW];
@@ -664,12 +712,15 @@ template <class Cell, bool SHARDED = false> __global__ void __launch_bounds__(SE
     __shared__ int s_np, s_part[NW];
     __shared__ unsigned int s_matches;
     __shared__ RowInfo s_new;
+    constexpr int IDS_LDS = 2048;
+    __shared__ uint32_t s_ids[IDS_LDS];  // the first partner row ids of the step (the rest, if any, goes through pl_ids in HBM)
+    __shared__ Log2Table s_log2;  // copy of c_log2 (fetched with the bounds; the latency model's look-up then stays off the memory path)
 
     const int tid = threadIdx.x, lane = lane_id(), wid = wave_id();
     const int gs = 1 << c.gs_log2;
 
-    long long tp[8];
-    tp[0] = clock64();
+    SEL_TIMER_DECL
+    SEL_TIMER_MARK(0)
     if (had_error != E_OK) {  // a capacity error poisons the chain: stop it (the host retries with a larger arena)
         if (tid == 0) {
             g->done = 1;
@@ -691,23 +742,43 @@ template <class Cell, bool SHARDED = false> __global__ void __launch_bounds__(SE
         s_matches = 0;
         s_floor0 = 0;
     }
-    // the list lengths of all columns: needed for the matched columns only, after the substitution -- fetched now, off the
-    // critical path, so that no dependent load is left there
-    for (int j = tid; j < n_out; j += SEL_THREADS) {
-        s_clen[j] = ((const DA_GLOBAL int *)g->collen)[j];
-        s_cm[j] = 0;
-    }
+    // ---- ONE vector round trip: the bounds and dirty flags of this lane's (up to four) groups and the list length of this
+    // thread's column leave together.  The loads are UNCONDITIONAL (index clamped to group / column 0) and every use comes
+    // after the last of them: behind an `in ? load : 0` the compiler waits for each load inside its own branch -- four
+    // serialised round trips for the bounds alone (ISA reading, round 2).
     const int GPW = (n_groups + NW - 1) / NW;  // groups per wave, <= 4 * WAVE
     unsigned long long ubr[4];
     int dr[4];  // 0 clean on entry, 1 dirty, 2 verified in this call, 3 absent
     {
-        unsigned long long cl = 0;
+        // the list lengths of all columns: needed for the matched columns only, after the substitution -- fetched now, off
+        // the critical path, so that no dependent load is left there
+        const int clen0 = collen[tid < n_out ? tid : 0];
+        const bool want_log2 = (adder_size >= 0 || carry_size >= 0) && tid < (int)(sizeof(Log2Table) / 4);
+        const uint32_t l2w = want_log2 ? reinterpret_cast<const uint32_t *>(&c_log2)[tid] : 0u;
+        bool in[4];
+        uint8_t dv[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int q = wid * GPW + lane + u * WAVE;
-            const bool in = lane + u * WAVE < GPW && q < n_groups;
-            ubr[u] = in ? c.ub[q] : 0ull;
-            dr[u] = in ? (c.gdirty[q] ? 1 : 0) : 3;
+            in[u] = lane + u * WAVE < GPW && q < n_groups;
+            const int qc = in[u] ? q : 0;
+            ubr[u] = c.ub[qc];
+            dv[u] = c.gdirty[qc];
+        }
+        if (tid < n_out) {
+            s_clen[tid] = clen0;
+            s_cm[tid] = 0;
+        }
+        if (want_log2) reinterpret_cast<uint32_t *>(&s_log2)[tid] = l2w;
+        for (int j = tid + SEL_THREADS; j < n_out; j += SEL_THREADS) {
+            s_clen[j] = collen[j];
+            s_cm[j] = 0;
+        }
+        unsigned long long cl = 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            ubr[u] = in[u] ? ubr[u] : 0ull;
+            dr[u] = in[u] ? (dv[u] ? 1 : 0) : 3;
             if (dr[u] == 0) cl = max(cl, ubr[u]);
         }
         __syncthreads();  // s_floor0 initialised
@@ -715,7 +786,7 @@ template <class Cell, bool SHARDED = false> __global__ void __launch_bounds__(SE
         if (lane == 0 && cl) atomicMax(&s_floor0, cl);
     }
     __syncthreads();
-    tp[1] = clock64();
+    SEL_TIMER_MARK(1)
     {
         const unsigned long long floor0 = s_floor0;
         if (tid == 0) s_floor = floor0;
@@ -723,17 +794,15 @@ template <class Cell, bool SHARDED = false> __global__ void __launch_bounds__(SE
         uint32_t wrank = 0;
         unsigned long long wtie = 0;
         unsigned int rescans = 0;
-        DA_GLOBAL unsigned long long *gtie_arr = (DA_GLOBAL unsigned long long *)g->gtie;
         // groups that were clean on entry and tie the floor: their stored tie word decides -- fetched now, in flight while
-        // the dirty groups are re-read
-        unsigned long long clean_tie = 0;
+        // the dirty groups are re-read (combined only after the loop: no wait for them here)
+        unsigned long long ctie[4] = {0, 0, 0, 0};
         bool clean_any = false;
         if (floor0) {
 #pragma unroll
             for (int u = 0; u < 4; ++u)
                 if (dr[u] == 0 && ubr[u] == floor0) {
-                    const unsigned long long t = gtie_arr[wid * GPW + lane + u * WAVE];
-                    clean_tie = t > clean_tie ? t : clean_tie;
+                    ctie[u] = gtie_arr[wid * GPW + lane + u * WAVE];
                     clean_any = true;
                 }
         }
@@ -787,6 +856,28 @@ template <class Cell, bool SHARDED = false> __global__ void __launch_bounds__(SE
                 }
                 grank[r] = wave_max_u32(grank[r]);
             }
+            // the slots that hold a group's top rank: key and best-key index of ALL of them (both groups) are fetched before
+            // the first is looked at.  Equal ranks are the rule late in a chain (rank = count x overlap, most counts are 2):
+            // fetched and consumed slot by slot, every tied slot was a round trip of its own -- up to sixteen in a row.
+            unsigned long long kk[2][8];
+            uint32_t bi[2][8];
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int o = lane + u * WAVE;
+                    kk[r][u] = 0;
+                    bi[r][u] = 0;
+                    if (grank[r] && o < gs && rk[r][u] == grank[r]) {
+                        kk[r][u] = c.hkey[base[r] + o];
+                        bi[r][u] = load_best_idx(c, base[r] + o);
+                    }
+                }
+            load_fence();
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int u = 0; u < 8; ++u) pin_vgpr(kk[r][u], bi[r][u]);  // nothing derived from a loaded value is computed (and waited for) above this line
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
                 if (grank[r]) {
@@ -794,8 +885,7 @@ template <class Cell, bool SHARDED = false> __global__ void __launch_bounds__(SE
                     for (int u = 0; u < 8; ++u) {
                         const int o = lane + u * WAVE;
                         if (o < gs && rk[r][u] == grank[r]) {
-                            const unsigned long long kk = c.hkey[base[r] + o];
-                            const unsigned long long tw = tie_word((uint32_t)kk, (uint32_t)(kk >> 32), (int)load_best_idx(c, base[r] + o));
+                            const unsigned long long tw = tie_word((uint32_t)kk[r][u], (uint32_t)(kk[r][u] >> 32), (int)bi[r][u]);
                             gt[r] = tw > gt[r] ? tw : gt[r];
                         }
                     }
@@ -833,8 +923,10 @@ template <class Cell, bool SHARDED = false> __global__ void __launch_bounds__(SE
             }
             lds_fence();
         }
+        pin_vgpr(ctie[0], ctie[1], ctie[2], ctie[3]);  // first use of the stored tie words: only now are their loads waited for
         if (floor0) {
-            const unsigned long long ct = wave_max_u64(clean_tie);
+            const unsigned long long c01 = ctie[0] > ctie[1] ? ctie[0] : ctie[1], c23 = ctie[2] > ctie[3] ? ctie[2] : ctie[3];
+            const unsigned long long ct = wave_max_u64(c01 > c23 ? c01 : c23);
             if (__any(clean_any)) {
                 const uint32_t r0 = (uint32_t)(floor0 >> 32);
                 if (r0 > wrank || (r0 == wrank && ct > wtie)) {
@@ -861,11 +953,11 @@ template <class Cell, bool SHARDED = false> __global__ void __launch_bounds__(SE
         }
         __syncthreads();
     }
-    tp[2] = clock64();
+    SEL_TIMER_MARK(2)
     const uint32_t best_rank = s_best_rank;
     const unsigned long long best_tie = s_best_tie;
-    const uint32_t Nw = (uint32_t)g->n_rows;
-    if (best_rank == 0 || (int)Nw >= g->rcap) {
+    const uint32_t Nw = (uint32_t)n_rows0;
+    if (best_rank == 0 || (int)Nw >= rcap) {
         if (tid == 0) {
             if (best_rank != 0) g->error = E_ROW_CAPACITY;
             g->done = 1;
@@ -879,28 +971,17 @@ template <class Cell, bool SHARDED = false> __global__ void __launch_bounds__(SE
     int shift, sub;
     key_decode(idx, nb, shift, sub);
     const bool same = A == B;
-    const int iter = g->iter;
 
-    // ---------------- (2) new row record + substitution.  Every thread fetches the list references of A and B (two
-    // broadcast loads) while thread 0 fetches the two row records and builds the new one.
-    DA_GLOBAL da_u2 *rowoff = (DA_GLOBAL da_u2 *)g->rowoff;
+    // ---------------- (2) new row record + substitution.  ONE round trip: every thread fetches the list references and the
+    // records of rows A and B (four broadcast loads; thread 0 builds the new row from the records, the special-pair waves
+    // need them for new blocks); then, one more: this thread's entry of A and of B.  Thread 0 builds the new row while
+    // those are in flight (it used to fetch the records after the references had arrived, then look up the latency model's
+    // table, then the live-block counters: five dependent round trips in wave 0 with fifteen waves waiting at the barrier).
+    const RowInfo ra = load_row(c.rows, A), rb = load_row(c.rows, B);
     const da_u2 refA = rowoff[A], refB = rowoff[B];
-    const uint32_t offN = g->rl_used;
-    if (tid == 0) {
-        RowInfo ra = load_row(c.rows, A), rb = load_row(c.rows, B), rn;
-        int derr = 0;
-        qint_add_pair(ra, rb, shift, sub, rn.lo, rn.hi, rn.step);
-        float dlat = adder_dlat(ra, rb, shift, sub, g->adder_size, g->carry_size, c_log2, derr);
-        rn.lat = (ra.lat < rb.lat ? rb.lat : ra.lat) + dlat;
-        if (derr) g->error = E_FLOAT_DOMAIN;
-        store_row((DA_GLOBAL RowInfo *)g->rows, Nw, rn);
-        s_new = rn;
-        reinterpret_cast<DA_GLOBAL da_i4 *>((DA_GLOBAL int4 *)g->picks)[iter] = da_i4{(int)A, (int)B, sub, shift};
-        if (g->n_live > g->live_peak) g->live_peak = g->n_live;
-    }
-    for (int k = tid; k < 6 * Kpad; k += SEL_THREADS) s_cnt[k] = 0;
+    load_fence();  // the four loads leave before anything that depends on one of them
     const int lenA = (int)refA.y, lenB = (int)refB.y;
-    if (offN + (uint32_t)lenA > g->rl_cap) {  // the new row has at most lenA entries (cannot happen with the exact bound; guarded)
+    if (offN + (uint32_t)lenA > rl_cap) {  // the new row has at most lenA entries (cannot happen with the exact bound; guarded)
         if (tid == 0) {
             g->error = E_LIST_CAPACITY;
             g->done = 1;
@@ -909,26 +990,45 @@ template <class Cell, bool SHARDED = false> __global__ void __launch_bounds__(SE
         }
         return;
     }
-    DA_GLOBAL Entry *rl = (DA_GLOBAL Entry *)g->rlist;
     DA_GLOBAL Entry *rlA = rl + refA.x, *rlB = rl + refB.x, *rlN = rl + offN;
-    DA_GLOBAL int *collen = (DA_GLOBAL int *)g->collen;
-    // this thread's entry of A (first chunk) and the list length of its column are fetched now, in flight together with B's
-    // list: pass 1 below then starts without a dependent load
-    const Entry eA0 = tid < lenA ? rlA[tid] : F::none();
+    // this thread's entry of A (first chunk) and of B: pass 1 below then starts without a dependent load
+    // (unconditional loads, index clamped to entry 0 of the arena: behind a branch the wait counters become ambiguous and
+    // the second load is only issued after the first has returned)
+    Entry eA0 = rl[tid < lenA ? refA.x + (uint32_t)tid : 0u], eB0 = rl[tid < lenB ? refB.x + (uint32_t)tid : 0u];
+    load_fence();
+    RowInfo rn = RowInfo{0.0f, 0.0f, 0.0f, 0.0f};
+    int derr = 0;
+    if (tid == 0) {  // arithmetic only, while the entries are in flight; the global stores follow once they have been consumed
+        qint_add_pair(ra, rb, shift, sub, rn.lo, rn.hi, rn.step);
+        float dlat = adder_dlat(ra, rb, shift, sub, adder_size, carry_size, s_log2, derr);
+        rn.lat = (ra.lat < rb.lat ? rb.lat : ra.lat) + dlat;
+        s_new = rn;
+    }
+    for (int k = tid; k < 6 * Kpad; k += SEL_THREADS) s_cnt[k] = 0;
+    if (tid >= lenA) eA0 = F::none();
+    if (same || tid >= lenB) eB0 = F::none();
+    pin_vgpr(eA0, eB0);  // both consumed (waited for) here, in front of thread 0's stores below
     if (!same) {  // B's list into LDS, addressable by column
         for (int j = tid; j < n_out; j += SEL_THREADS) s_bpos[j] = 0;
         __syncthreads();
-        for (int t = tid; t < lenB; t += SEL_THREADS) {
+        if (tid < lenB) {
+            s_bent[tid] = eB0;
+            s_bpos[F::col(eB0)] = tid + 1;
+        }
+        for (int t = tid + SEL_THREADS; t < lenB; t += SEL_THREADS) {
             const Entry e = rlB[t];
             s_bent[t] = e;
             s_bpos[F::col(e)] = t + 1;
         }
     }
+    if (tid == 0) {  // (a wait for a loaded value also waits for every store issued before it: these come after the last one)
+        if (derr) g->error = E_FLOAT_DOMAIN;
+        store_row((DA_GLOBAL RowInfo *)c.rows, Nw, rn);
+        picks[iter] = da_i4{(int)A, (int)B, sub, shift};
+        if (n_live0 > live_peak0) g->live_peak = n_live0;
+    }
     __syncthreads();
-    tp[3] = clock64();
-    DA_GLOBAL Cell *mA = (DA_GLOBAL Cell *)g->mA, *mB = (DA_GLOBAL Cell *)g->mB;
-    DA_GLOBAL int *mcol = (DA_GLOBAL int *)g->mcol;
-    DA_GLOBAL unsigned long long *collist = (DA_GLOBAL unsigned long long *)g->collist;
+    SEL_TIMER_MARK(3)
     uint32_t *cAA = s_cnt, *cAB = s_cnt + Kpad, *cBB = s_cnt + 2 * Kpad, *cAN = s_cnt + 3 * Kpad, *cBN = s_cnt + 4 * Kpad,
              *cNN = s_cnt + 5 * Kpad;
     unsigned int my_matches = 0;
@@ -975,7 +1075,7 @@ template <class Cell, bool SHARDED = false> __global__ void __launch_bounds__(SE
             mB[at] = mb;
             s_cm[colA] = at + 1;
             {  // row bitmaps of this column: the new row enters, a row whose cell just lost its last digit leaves
-                DA_GLOBAL uint32_t *cb = (DA_GLOBAL uint32_t *)g->colbits + (size_t)colA * g->cb_words;
+                DA_GLOBAL uint32_t *cb = colbits + (size_t)colA * cbw;
                 atomicOr(gen(&cb[Nw >> 5]), 1u << (Nw & 31));
                 if (na == 0) atomicAnd(gen(&cb[A >> 5]), ~(1u << (A & 31)));
                 if (!same && nbv == 0) atomicAnd(gen(&cb[B >> 5]), ~(1u << (B & 31)));
@@ -1006,7 +1106,7 @@ template <class Cell, bool SHARDED = false> __global__ void __launch_bounds__(SE
             if (nbv) for_pairs_self<Cell>(nbv, nb, [&](int k) { atomicAdd(&cBB[k], 1u); });
         }
     // the map column -> matched index for the update blocks (one coalesced copy; pass 1 has completed: its last barrier)
-    for (int j = tid; j < n_out; j += SEL_THREADS) ((DA_GLOBAL uint16_t *)g->cmap)[j] = (uint16_t)s_cm[j];
+    for (int j = tid; j < n_out; j += SEL_THREADS) cmap[j] = (uint16_t)s_cm[j];
     // the new row joins the lists of its columns
     {
         const unsigned long long refN = ref_pack(Nw, (uint32_t)m, offN);
@@ -1020,7 +1120,7 @@ template <class Cell, bool SHARDED = false> __global__ void __launch_bounds__(SE
         }
     }
     __syncthreads();
-    tp[4] = clock64();
+    SEL_TIMER_MARK(4)
     int total = 0;
     if constexpr (SHARDED) {  // only the column-sharded chain still walks the column lists
     // exclusive prefix sum of the list lengths of the matched columns (m <= n_out)
@@ -1061,7 +1161,7 @@ template <class Cell, bool SHARDED = false> __global__ void __launch_bounds__(SE
     }
     total = s_len[m];
     }
-    tp[5] = clock64();
+    SEL_TIMER_MARK(5)
     // ---------------- (4) partner rows -- the rows that have digits in a substituted column -- into the partner list, by the
     // first NW-6 waves; the last six waves store the six special pairs meanwhile.  A column-sharded chain leaves one flag per
     // row instead (read from its column lists).
@@ -1085,9 +1185,9 @@ template <class Cell, bool SHARDED = false> __global__ void __launch_bounds__(SE
             // new row masked out: their bits are being changed by this very kernel).  Word w of the OR covers rows 32 w ..;
             // the set bits are counted (DPP prefix sum), one LDS atomic per wave reserves the places, the row ids go to pl_ids;
             // then, one thread per partner, the list reference is attached (a parallel gather from rowoff).
-            const DA_GLOBAL uint32_t *cb = (const DA_GLOBAL uint32_t *)g->colbits;
-            const int cbw = g->cb_words, nwords = (int)((Nw + 31) >> 5);
-            DA_GLOBAL uint32_t *ids = (DA_GLOBAL uint32_t *)g->pl_ids;
+            const DA_GLOBAL uint32_t *cb = colbits;
+            const int nwords = (int)((Nw + 31) >> 5);
+            DA_GLOBAL uint32_t *ids = pl_ids;
             for (int wb = wid * WAVE; wb < nwords; wb += CLAIM_THREADS) {  // wave-uniform trip count
                 const int w = wb + lane;
                 uint32_t bits = 0;
@@ -1103,8 +1203,13 @@ template <class Cell, bool SHARDED = false> __global__ void __launch_bounds__(SE
                 int base = 0;
                 if (lane == 0) base = atomicAdd(&s_np, wave_total);
                 int at = __builtin_amdgcn_readfirstlane(base) + inc - cnt;
-                while (bits) {
-                    ids[at++] = (uint32_t)(w << 5) + (uint32_t)ctz32(bits);
+                while (bits) {  // ids stay in LDS (a store to HBM followed by a load after the barrier was two round trips)
+                    const uint32_t id = (uint32_t)(w << 5) + (uint32_t)ctz32(bits);
+                    if (at < IDS_LDS)
+                        s_ids[at] = id;
+                    else
+                        ids[at] = id;
+                    ++at;
                     bits &= bits - 1;
                 }
             }
@@ -1125,7 +1230,7 @@ template <class Cell, bool SHARDED = false> __global__ void __launch_bounds__(SE
         default: lo = Nw, hi = Nw; break;
         }
         if constexpr (SHARDED) {  // partial counts of the six special pairs: head of the exchange slab, [6][K]
-            DA_GLOBAL int32_t *spec = (DA_GLOBAL int32_t *)g->cs_slab + (size_t)sp * c.K;
+            DA_GLOBAL int32_t *spec = cs_slab + (size_t)sp * c.K;
             for (int k = lane; k < c.K; k += WAVE) spec[k] = active ? (int32_t)cnt[k] : 0;
         } else if (active) {
             unsigned long long key = pack_pair(lo, hi);
@@ -1133,41 +1238,47 @@ template <class Cell, bool SHARDED = false> __global__ void __launch_bounds__(SE
             if (slot >= 0)
                 table_update(c, slot, key, [&](int k, uint32_t) { return cnt[k]; });
             else if (wave_any_ge2(cnt, c.K)) {
-                RowInfo ra = load_row(c.rows, lo), rb = hi == Nw ? s_new : load_row(c.rows, hi);
-                if (lo == Nw) ra = s_new;
-                table_insert(c, lo, hi, ra, rb, [&](int k) { return cnt[k]; });
+                // the records of the two rows: A's and B's were fetched with the list references, the new row's is in LDS
+                const RowInfo sn = s_new;
+                const RowInfo xa = pick_row(lo == Nw, sn, pick_row(lo == A, ra, rb)), xb = pick_row(hi == Nw, sn, pick_row(hi == A, ra, rb));
+                table_insert(c, lo, hi, xa, xb, [&](int k) { return cnt[k]; });
             }
         }
     }
-    tp[6] = clock64();
+    SEL_TIMER_MARK(6)
     __syncthreads();
     if constexpr (!SHARDED) {  // partner ids -> partner list entries (row id, list length, list offset)
         const int np = s_np;
-        const DA_GLOBAL uint32_t *ids = (const DA_GLOBAL uint32_t *)g->pl_ids;
-        DA_GLOBAL unsigned long long *plist = (DA_GLOBAL unsigned long long *)g->plist;
-        for (int t = tid; t < np; t += SEL_THREADS) {
-            const uint32_t r = ids[t];
-            const da_u2 ro = rowoff[r];
-            plist[t] = ref_pack(r, ro.y, ro.x);
+        const DA_GLOBAL uint32_t *ids = pl_ids;
+        for (int t = tid; t < np; t += 2 * SEL_THREADS) {  // two partners per thread and pass, their look-ups in flight together
+            const int t2 = t + SEL_THREADS;
+            const bool has2 = t2 < np;
+            const uint32_t r1 = t < IDS_LDS ? s_ids[t] : ids[t];
+            const uint32_t r2 = !has2 ? r1 : t2 < IDS_LDS ? s_ids[t2] : ids[t2];
+            const da_u2 ro1 = rowoff[r1], ro2 = rowoff[r2];
+            load_fence();
+            plist[t] = ref_pack(r1, ro1.y, ro1.x);
+            if (has2) plist[t2] = ref_pack(r2, ro2.y, ro2.x);
         }
     }
-    tp[7] = clock64();
+    SEL_TIMER_MARK(7)
     if constexpr (SHARDED) {  // claim bitmap -> 8-bit flag fields, four rows per word (summed over the ranks without carry)
-        DA_GLOBAL int32_t *flags = (DA_GLOBAL int32_t *)g->cs_flags;
+        DA_GLOBAL int32_t *flags = cs_flags;
         for (int w = tid; w < (int)((Nw + 3) / 4); w += SEL_THREADS) {
             const uint32_t b = (s_bits[w >> 3] >> ((w & 7) * 4)) & 0xFu;
             flags[w] = (int32_t)((b & 1u) | ((b & 2u) << 7) | ((b & 4u) << 14) | ((b & 8u) << 21));
         }
     }
     if (tid == 0) {
-        for (int q = 0; q < 7; ++q) g->st_phase[q] += (unsigned long long)(tp[q + 1] - tp[q]);
+        SEL_TIMER_FLUSH
         rowoff[Nw] = da_u2{offN, (uint32_t)m};
         g->rl_used = offN + (uint32_t)m;
         g->m = m;
         g->n_partners = s_np;
-        g->st_matches += (unsigned long long)s_matches;
-        g->st_partners += (unsigned long long)s_np;
-        g->st_cells += (unsigned long long)s_np * (unsigned)m;
+        // statistics: atomics without a return value (a plain += is load -> add -> store: one more round trip at the very end)
+        atomicAdd(&g->st_matches, (unsigned long long)s_matches);
+        atomicAdd(&g->st_partners, (unsigned long long)s_np);
+        atomicAdd(&g->st_cells, (unsigned long long)s_np * (unsigned)m);
         g->A = A;
         g->B = B;
         g->Nw = Nw;
@@ -1219,7 +1330,7 @@ __global__ void __launch_bounds__(UPD_THREADS, DA_UPD_OCC) __attribute__((amdgpu
     // ---- ONE scalar round trip: every descriptor field the block needs, pinned before the first branch (pin_sgpr)
     int done = gq->done, n_partners = gq->n_partners, iter = gq->iter, m = gq->m, n_in = gq->n_in;
     uint32_t A = gq->A, B = gq->B, Nw = gq->Nw;
-    Ctx c = make_ctx(gq, 2 * iter - 1);
+    Ctx c = make_ctx_raw(gq, 2 * iter - 1);
     const DA_GLOBAL int *mcol = (const DA_GLOBAL int *)gq->mcol;
     const DA_GLOBAL Cell *mA = (const DA_GLOBAL Cell *)gq->mA, *mB = (const DA_GLOBAL Cell *)gq->mB;
     const DA_GLOBAL uint16_t *cmap = (const DA_GLOBAL uint16_t *)gq->cmap;
@@ -1228,6 +1339,7 @@ __global__ void __launch_bounds__(UPD_THREADS, DA_UPD_OCC) __attribute__((amdgpu
     int grid_y = (int)gridDim.y;
     pin_sgpr(done, n_partners, iter, m, n_in, A, B, Nw, grid_y, mcol, mA, mB, cmap, rl, plist);
     pin_sgpr(c.n_out, c.n_bits, c.K, c.Kpad, c.method, c.gs_log2, c.pb_log2, c.cmask, c.windows, c.hkey, c.hrank, c.hblk, c.ub, c.gdirty, c.rows);
+    ctx_finish(c);
     if ((int)blockIdx.x >= n_chains || done) return;
     // the grid is sized for the partner counts of the first steps of a chain (thousands); later most blocks have nothing
     // to do and leave before the hand-off is copied

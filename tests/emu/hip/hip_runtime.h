@@ -167,6 +167,7 @@ __attribute__((noinline)) inline void __builtin_amdgcn_wave_barrier() {  // the 
 }
 inline void __builtin_amdgcn_s_waitcnt(int) {}
 inline void __builtin_amdgcn_s_sleep(int) {}
+inline void __builtin_amdgcn_sched_barrier(int) {}  // instruction-scheduling fence: no meaning on the host
 inline void __builtin_amdgcn_s_setprio(int) {}
 inline void __syncthreads() { hipemu::block_barrier(); }
 inline void __threadfence() {}
