@@ -707,11 +707,10 @@ template <class Cell, bool SHARDED = false> __global__ void __launch_bounds__(SE
     constexpr int NW = SEL_THREADS / WAVE;
     __shared__ unsigned long long s_red_tie[NW], s_floor0, s_floor;
     __shared__ uint32_t s_red_rank[NW];
-    __shared__ uint32_t s_best_rank;
-    __shared__ unsigned long long s_best_tie;
     __shared__ int s_np, s_part[NW];
     __shared__ unsigned int s_matches;
-    __shared__ RowInfo s_new;
+    __shared__ RowInfo s_new, s_ra, s_rb;
+    __shared__ da_u2 s_refA, s_refB;
     constexpr int IDS_LDS = 2048;
     __shared__ uint32_t s_ids[IDS_LDS];  // the first partner row ids of the step (the rest, if any, goes through pl_ids in HBM)
     __shared__ Log2Table s_log2;  // copy of c_log2 (fetched with the bounds; the latency model's look-up then stays off the memory path)
@@ -736,8 +735,6 @@ template <class Cell, bool SHARDED = false> __global__ void __launch_bounds__(SE
     // four) groups in registers, loaded coalesced from global memory, and the wave re-reads its highest dirty group
     // while that group's (possibly stale) bound can still beat or tie the rising floor.
     if (tid == 0) {
-        s_best_rank = 0;
-        s_best_tie = 0;
         s_np = 0;
         s_matches = 0;
         s_floor0 = 0;
@@ -747,7 +744,7 @@ template <class Cell, bool SHARDED = false> __global__ void __launch_bounds__(SE
     // after the last of them: behind an `in ? load : 0` the compiler waits for each load inside its own branch -- four
     // serialised round trips for the bounds alone (ISA reading, round 2).
     const int GPW = (n_groups + NW - 1) / NW;  // groups per wave, <= 4 * WAVE
-    unsigned long long ubr[4];
+    unsigned long long ubr[4], gtr[4];
     int dr[4];  // 0 clean on entry, 1 dirty, 2 verified in this call, 3 absent
     {
         // the list lengths of all columns: needed for the matched columns only, after the substitution -- fetched now, off
@@ -764,15 +761,18 @@ template <class Cell, bool SHARDED = false> __global__ void __launch_bounds__(SE
             const int qc = in[u] ? q : 0;
             ubr[u] = c.ub[qc];
             dv[u] = c.gdirty[qc];
+            gtr[u] = gtie_arr[qc];  // the stored tie word (exact while the group is clean): with the bounds, not a round trip later
         }
         if (tid < n_out) {
             s_clen[tid] = clen0;
             s_cm[tid] = 0;
+            s_bpos[tid] = 0;
         }
         if (want_log2) reinterpret_cast<uint32_t *>(&s_log2)[tid] = l2w;
         for (int j = tid + SEL_THREADS; j < n_out; j += SEL_THREADS) {
             s_clen[j] = collen[j];
             s_cm[j] = 0;
+            s_bpos[j] = 0;
         }
         unsigned long long cl = 0;
 #pragma unroll
@@ -787,6 +787,10 @@ template <class Cell, bool SHARDED = false> __global__ void __launch_bounds__(SE
     }
     __syncthreads();
     SEL_TIMER_MARK(1)
+    uint32_t best_rank, cand_rank;
+    unsigned long long best_tie, cand_tie;
+    RowInfo cand_ra, cand_rb;
+    da_u2 cand_refA, cand_refB;
     {
         const unsigned long long floor0 = s_floor0;
         if (tid == 0) s_floor = floor0;
@@ -794,15 +798,14 @@ template <class Cell, bool SHARDED = false> __global__ void __launch_bounds__(SE
         uint32_t wrank = 0;
         unsigned long long wtie = 0;
         unsigned int rescans = 0;
-        // groups that were clean on entry and tie the floor: their stored tie word decides -- fetched now, in flight while
-        // the dirty groups are re-read (combined only after the loop: no wait for them here)
-        unsigned long long ctie[4] = {0, 0, 0, 0};
+        // groups that were clean on entry and tie the floor: their stored tie word (fetched with the bounds) decides
+        unsigned long long clean_tie = 0;
         bool clean_any = false;
         if (floor0) {
 #pragma unroll
             for (int u = 0; u < 4; ++u)
                 if (dr[u] == 0 && ubr[u] == floor0) {
-                    ctie[u] = gtie_arr[wid * GPW + lane + u * WAVE];
+                    clean_tie = gtr[u] > clean_tie ? gtr[u] : clean_tie;
                     clean_any = true;
                 }
         }
@@ -923,10 +926,8 @@ template <class Cell, bool SHARDED = false> __global__ void __launch_bounds__(SE
             }
             lds_fence();
         }
-        pin_vgpr(ctie[0], ctie[1], ctie[2], ctie[3]);  // first use of the stored tie words: only now are their loads waited for
         if (floor0) {
-            const unsigned long long c01 = ctie[0] > ctie[1] ? ctie[0] : ctie[1], c23 = ctie[2] > ctie[3] ? ctie[2] : ctie[3];
-            const unsigned long long ct = wave_max_u64(c01 > c23 ? c01 : c23);
+            const unsigned long long ct = wave_max_u64(clean_tie);
             if (__any(clean_any)) {
                 const uint32_t r0 = (uint32_t)(floor0 >> 32);
                 if (r0 > wrank || (r0 == wrank && ct > wtie)) {
@@ -935,27 +936,31 @@ template <class Cell, bool SHARDED = false> __global__ void __launch_bounds__(SE
                 }
             }
         }
+        // Every wave fetches the list references and records of ITS candidate pair now (four broadcast loads, in flight
+        // across the reduction): the winner's are then already here -- one dependent round trip less than fetching them once
+        // the block knows the winner.
+        const uint32_t cA = wrank ? (uint32_t)((wtie >> 7) & 0xFFFFFFu) : 0u, cB = wrank ? (uint32_t)(wtie >> 31) : 0u;
+        cand_ra = load_row(c.rows, cA);
+        cand_rb = load_row(c.rows, cB);
+        cand_refA = rowoff[cA];
+        cand_refB = rowoff[cB];
+        cand_rank = wrank;
+        cand_tie = wtie;
         if (lane == 0) {
             s_red_rank[wid] = wrank;
             s_red_tie[wid] = wtie;
             if (rescans) atomicAdd(&g->st_rescans, (unsigned long long)rescans);
         }
         __syncthreads();
-        if (wid == 0) {  // the waves' results, one per lane: highest rank, then highest tie word among its holders
+        {  // the waves' results, one per lane: highest rank, then highest tie word among its holders.  Every wave reduces
+           // them itself (a dozen DPP steps): no broadcast through LDS, no second barrier.
             const uint32_t r = lane < NW ? s_red_rank[lane] : 0u;
             const unsigned long long t = lane < NW ? s_red_tie[lane] : 0ull;
-            const uint32_t br = wave_max_u32(r);
-            const unsigned long long bt = wave_max_u64(r == br ? t : 0ull);
-            if (lane == 0) {
-                s_best_rank = br;
-                s_best_tie = bt;
-            }
+            best_rank = wave_max_u32(r);
+            best_tie = wave_max_u64(r == best_rank ? t : 0ull);
         }
-        __syncthreads();
     }
     SEL_TIMER_MARK(2)
-    const uint32_t best_rank = s_best_rank;
-    const unsigned long long best_tie = s_best_tie;
     const uint32_t Nw = (uint32_t)n_rows0;
     if (best_rank == 0 || (int)Nw >= rcap) {
         if (tid == 0) {
@@ -972,14 +977,21 @@ template <class Cell, bool SHARDED = false> __global__ void __launch_bounds__(SE
     key_decode(idx, nb, shift, sub);
     const bool same = A == B;
 
-    // ---------------- (2) new row record + substitution.  ONE round trip: every thread fetches the list references and the
-    // records of rows A and B (four broadcast loads; thread 0 builds the new row from the records, the special-pair waves
-    // need them for new blocks); then, one more: this thread's entry of A and of B.  Thread 0 builds the new row while
-    // those are in flight (it used to fetch the records after the references had arrived, then look up the latency model's
-    // table, then the live-block counters: five dependent round trips in wave 0 with fifteen waves waiting at the barrier).
-    const RowInfo ra = load_row(c.rows, A), rb = load_row(c.rows, B);
-    const da_u2 refA = rowoff[A], refB = rowoff[B];
-    load_fence();  // the four loads leave before anything that depends on one of them
+    // ---------------- (2) new row record + substitution.  The list references and the records of rows A and B arrive from the
+    // wave that held the winner (fetched before the reduction, see above; thread 0 builds the new row from the records, the
+    // special-pair waves need them for new blocks); ONE round trip follows: this thread's entry of A and of B.  Thread 0
+    // builds the new row while those are in flight (it used to fetch the records after the references had arrived, then look
+    // up the latency model's table, then the live-block counters: five dependent round trips in wave 0 with fifteen waves
+    // waiting at the barrier).
+    if (cand_rank == best_rank && cand_tie == best_tie && lane == 0) {  // exactly one wave holds the winner (tie words are unique)
+        s_ra = cand_ra;
+        s_rb = cand_rb;
+        s_refA = cand_refA;
+        s_refB = cand_refB;
+    }
+    __syncthreads();
+    const RowInfo ra = s_ra, rb = s_rb;
+    const da_u2 refA = s_refA, refB = s_refB;
     const int lenA = (int)refA.y, lenB = (int)refB.y;
     if (offN + (uint32_t)lenA > rl_cap) {  // the new row has at most lenA entries (cannot happen with the exact bound; guarded)
         if (tid == 0) {
@@ -1008,9 +1020,7 @@ template <class Cell, bool SHARDED = false> __global__ void __launch_bounds__(SE
     if (tid >= lenA) eA0 = F::none();
     if (same || tid >= lenB) eB0 = F::none();
     pin_vgpr(eA0, eB0);  // both consumed (waited for) here, in front of thread 0's stores below
-    if (!same) {  // B's list into LDS, addressable by column
-        for (int j = tid; j < n_out; j += SEL_THREADS) s_bpos[j] = 0;
-        __syncthreads();
+    if (!same) {  // B's list into LDS, addressable by column (s_bpos was zeroed at the start, several barriers ago)
         if (tid < lenB) {
             s_bent[tid] = eB0;
             s_bpos[F::col(eB0)] = tid + 1;
