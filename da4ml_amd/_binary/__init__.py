@@ -38,7 +38,7 @@ def lib():
     if _lib is not None:
         return _lib
     csrc = Path(__file__).resolve().parent.parent / 'csrc'
-    sources = [p for p in csrc.glob('*') if p.suffix in ('.hip', '.cc', '.h')] + [_LIB_PATH.parent.parent / 'include' / 'da4ml_hip.h']
+    sources = [p for p in csrc.glob('*') if p.suffix in ('.hip', '.cc', '.h') or p.name == 'Makefile'] + [_LIB_PATH.parent.parent / 'include' / 'da4ml_hip.h']
     def _stale():
         return not _LIB_PATH.exists() or any(p.exists() and p.stat().st_mtime > _LIB_PATH.stat().st_mtime for p in sources)
 
