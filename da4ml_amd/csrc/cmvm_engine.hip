@@ -79,6 +79,9 @@ constexpr int SEL_THREADS = 1024;  // k_iter_select block (16 waves)
 constexpr int UPD_THREADS = 256;   // k_iter_update block
 constexpr int UPD_WAVES = UPD_THREADS / WAVE;
 constexpr int MAX_GROUPS = 4096;   // 16 waves x 64 lanes x 4 register-resident bounds in k_iter_select
+#ifndef DA_IDS_LDS
+#define DA_IDS_LDS 2048  // partner row ids of a step staged in LDS by k_iter_select (tests/emu builds with 16: its problems are small, both paths run)
+#endif
 
 // Per-phase shader-clock timers of k_iter_select / k_iter_update (tests/gpu_profile.py).  They cost SGPRs, VALU time and --
 // every s_memtime is followed by a wait for all outstanding LDS and scalar operations -- latency on the dependent chain of
@@ -711,7 +714,7 @@ template <class Cell, bool SHARDED = false> __global__ void __launch_bounds__(SE
     __shared__ unsigned int s_matches;
     __shared__ RowInfo s_new, s_ra, s_rb;
     __shared__ da_u2 s_refA, s_refB;
-    constexpr int IDS_LDS = 2048;
+    constexpr int IDS_LDS = DA_IDS_LDS;
     __shared__ uint32_t s_ids[IDS_LDS];  // the first partner row ids of the step (the rest, if any, goes through pl_ids in HBM)
     __shared__ Log2Table s_log2;  // copy of c_log2 (fetched with the bounds; the latency model's look-up then stays off the memory path)
 

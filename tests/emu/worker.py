@@ -62,6 +62,20 @@ def batch():
     out(bad=bad, n=len(ks), chains=tm['chains'])
 
 
+def big_table():
+    """a pair table of 2 M slots (environment set by the test) for small problems: 4096 groups of 512 slots, i.e. the geometry
+    of a 256x256 chain -- every lane of k_iter_select holds four group bounds and re-reads eight slots per group, which the
+    tables of small problems (4 groups of 256 slots) never reach"""
+    o = Oracle('port')
+    ks = [int_matrix(11, 14, 9, -128, 128), int_matrix(12, 9, 14, -4096, 4096)]
+    got = hip.solve_many(ks, **SINGLE)
+    bad = [i for i, k in enumerate(ks) if got[i] != o.solve(k, **SINGLE)]
+    k = int_matrix(13, 10, 10, -32, 32)
+    if hip.solve(k, method0='mc-dc', method1='wmc-pdc', adder_size=1, carry_size=-1) != o.solve(k, method0='mc-dc', method1='wmc-pdc', adder_size=1, carry_size=-1):
+        bad.append(2)
+    out(bad=bad)
+
+
 def retry():
     """arena heuristics far too small (environment set by the test): capacity error on the device, rerun with larger arenas"""
     o = Oracle('port')
@@ -152,5 +166,5 @@ def dais():
 
 if __name__ == '__main__':
     what = sys.argv[1]
-    {'random': lambda: random_cases(int(sys.argv[2]), int(sys.argv[3])), 'layouts': layouts, 'batch': batch, 'retry': retry,
+    {'random': lambda: random_cases(int(sys.argv[2]), int(sys.argv[3])), 'layouts': layouts, 'batch': batch, 'retry': retry, 'big_table': big_table,
      'shard_single': shard_single, 'shard_rank': shard_rank, 'dais': dais, 'race_cases': race_cases}[what]()  # fmt: skip

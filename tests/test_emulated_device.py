@@ -56,6 +56,12 @@ def test_capacity_retry(emu):
     assert r['equal'] and r['retries'] >= 1
 
 
+def test_table_geometry_of_a_large_chain(emu):
+    """DA4ML_HIP_TABLE_SCALE inflates the pair table of small problems to 2 M slots = 4096 groups of 512: all four bound
+    registers of every lane and all eight slots per lane and group of the arg-max are in use, as in a 256x256 chain"""
+    assert emu('big_table', env=dict(DA4ML_HIP_TABLE_SCALE='6000'))['bad'] == []
+
+
 def test_column_sharded_engine_single_rank(emu):
     """HipShardEngine (k_cs_init_counts, k_cs_init_table, k_iter_select<SHARDED>, k_cs_union, k_cs_partial, k_cs_apply)"""
     assert emu('shard_single', env=dict(DA4ML_SHARD_FORCE='1'))['bad'] == []
@@ -85,7 +91,7 @@ def test_dais_device_executor(emu):
 
 def test_kernels_under_address_sanitizer():
     """the same library built with AddressSanitizer: no out-of-bounds access of static or dynamic LDS, of device allocations
-    or of per-thread arrays in any kernel on the layout, batch and sharded-engine cases"""
+    or of per-thread arrays in any kernel on the layout, batch, sharded-engine and large-table cases"""
     r = subprocess.run(['make', '-s', '-C', str(EMU_DIR), 'asan'], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     runtime = subprocess.run(['make', '-s', '-C', str(EMU_DIR), 'asan-runtime'], capture_output=True, text=True).stdout.strip()
@@ -93,7 +99,7 @@ def test_kernels_under_address_sanitizer():
         pytest.skip('no AddressSanitizer runtime in this toolchain')
     base = dict(os.environ, DA4ML_HIP_LIB=str(EMU_DIR / 'build' / 'libda4ml_emu_asan.so'), DA4ML_HIP_UPD_BLOCKS='8', LD_PRELOAD=runtime,
                 ASAN_OPTIONS='detect_leaks=0:detect_stack_use_after_return=0:abort_on_error=1')  # fmt: skip
-    for what, extra in (('layouts', {}), ('batch', {}), ('shard_single', {'DA4ML_SHARD_FORCE': '1'})):
+    for what, extra in (('layouts', {}), ('batch', {}), ('shard_single', {'DA4ML_SHARD_FORCE': '1'}), ('big_table', {'DA4ML_HIP_TABLE_SCALE': '6000'})):
         out = subprocess.run([sys.executable, str(EMU_DIR / 'worker.py'), what], env=dict(base, **extra), capture_output=True, text=True, cwd=str(ROOT), timeout=900)
         assert out.returncode == 0 and 'AddressSanitizer' not in out.stderr, (what, out.stderr[-3000:])
         assert json.loads(out.stdout.strip().splitlines()[-1])['bad'] == [], what
