@@ -2498,7 +2498,7 @@ namespace {
 class HipShardEngine : public ShardEngine {
   public:
     HipShardEngine(hipStream_t st, int device, const ChainJob &job, int c0, int c1, double table_scale, double row_scale)
-        : st_(st), device_(device), job_(job), c0_(c0), n_loc_(c1 - c0) {
+        : st_(st), device_(device), job_(job), n_loc_(c1 - c0) {
         HIP_CHECK(hipSetDevice(device_));
         const size_t e = (size_t)job.n_in * job.n_out;
         // inputs + centred matrix of the WHOLE matrix (centring and digit width are global properties)
@@ -2724,7 +2724,7 @@ class HipShardEngine : public ShardEngine {
     hipStream_t st_;
     int device_;
     ChainJob job_;
-    int c0_, n_loc_;
+    int n_loc_;  // columns of this rank (the first of them is d_.col0)
     ChainDev d_;
     ChainDev *dd_ = nullptr;
     Geometry geo_;
