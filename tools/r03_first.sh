@@ -2,7 +2,8 @@
 # FIRST gpurun call of round 3.  The last GPU-measured kernels are those of revision 70c8f1a (profiles/r02_*); everything after
 # it -- the round-trip cuts of k_iter_update / k_iter_select made by ISA reading, the kernel-argument preload -- was verified on
 # the emulated device only (tests/emu: oracle parity, ASan, race detector), never timed.  This script settles them:
-#   HERE first (no GPU):   tools/ab_ref.sh measured=70c8f1a nopreload=WORKTREE:"KERNARG="
+#   HERE first (no GPU):   tools/ab_ref.sh measured=70c8f1a nopreload=WORKTREE:"KERNARG=" timers=WORKTREE:"PHASE_TIMERS=1"
+#                          (timers: per-phase shader-clock cycles of both kernels, printed at the end; it is slower by design)
 #   then:                  gpurun --timeout 1500 -- 'bash tools/r03_first.sh'
 # 1. the whole GPU parity suite on the working tree; 2. alternating timings (64-chain C3 batch and one chain alone) of the
 # working tree and of every library in ab_libs/; 3. QUICK profile collection of the working tree -> gpurun_out/profiles_r03/
@@ -16,6 +17,7 @@ for rep in 1 2 3; do
     echo "[$n #$rep] $a | single: $b"
   done
 done | tee gpurun_out/ab/summary.txt
+for n in timers; do [ -f gpurun_out/ab/$n.perf1.log ] && { echo "--- phase cycles ($n): batch 64, then one chain"; sed -n 3,4p gpurun_out/ab/$n.perf1.log; sed -n 3,4p gpurun_out/ab/$n.single1.log; }; done
 unset DA4ML_HIP_LIB
 QUICK=1 bash tools/collect_profiles.sh r03 2>&1 | tail -3
 tail -c 600 gpurun_out/profiles_r03/bench.json
