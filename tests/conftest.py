@@ -12,6 +12,18 @@ def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with `pytest -m gpu` on the GPU box)')
 
 
+def pytest_collection_modifyitems(config, items):
+    """A GPU test that hangs (a kernel that never ends blocks the process inside the HIP runtime) must end the session instead
+    of holding the GPU box until somebody else's limit fires: 15 minutes per test, enforced from a watchdog thread
+    (pytest-timeout's signal method cannot interrupt a blocked C call).  The longest GPU test takes seconds; the first one may
+    include the in-tree rebuild of the library and the first `import torch` on a fresh box."""
+    if not config.pluginmanager.hasplugin('timeout'):
+        return
+    for item in items:
+        if item.get_closest_marker('gpu') and not item.get_closest_marker('timeout'):
+            item.add_marker(pytest.mark.timeout(900, method='thread'))
+
+
 @pytest.fixture(scope='session')
 def oracle():
     """CPU restatement of the reference (oracle/cmvm_oracle.cc) -- the checker, never the thing under test."""
