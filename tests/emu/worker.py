@@ -76,6 +76,20 @@ def big_table():
     out(bad=bad)
 
 
+def record(name, fname):
+    """a committed large record (tests/golden/large_*_golden.json: 128x128 / 256x256 chains and default searches, made by the
+    oracle or by oracle/_ref/libref.so in up to 141 minutes of CPU) reproduced by the kernels on the emulated device"""
+    import hashlib
+    import re
+
+    rec = json.loads((ROOT / 'tests' / 'golden' / fname).read_text())[name]
+    n, seed = (int(v) for v in re.match(r'(\d+)x\1_seed(\d+)_', name).groups())
+    p = hip.solve(int_matrix(seed, n, n, -128, 128), **rec['opts'])
+    dump = json.loads(json.dumps(p, default=lambda o: o.to_dict()))
+    sha = hashlib.sha256(json.dumps(dump, separators=(',', ':')).encode()).hexdigest()
+    out(equal=p.cost == rec['cost'] and [len(s.ops) for s in p.solutions] == rec['n_ops'] and sha == rec['sha256'], cost=p.cost)
+
+
 def retry():
     """arena heuristics far too small (environment set by the test): capacity error on the device, rerun with larger arenas"""
     o = Oracle('port')
@@ -166,5 +180,5 @@ def dais():
 
 if __name__ == '__main__':
     what = sys.argv[1]
-    {'random': lambda: random_cases(int(sys.argv[2]), int(sys.argv[3])), 'layouts': layouts, 'batch': batch, 'retry': retry, 'big_table': big_table,
+    {'random': lambda: random_cases(int(sys.argv[2]), int(sys.argv[3])), 'layouts': layouts, 'batch': batch, 'retry': retry, 'big_table': big_table, 'record': lambda: record(sys.argv[2], sys.argv[3]),
      'shard_single': shard_single, 'shard_rank': shard_rank, 'dais': dais, 'race_cases': race_cases}[what]()  # fmt: skip

@@ -62,6 +62,15 @@ def test_table_geometry_of_a_large_chain(emu):
     assert emu('big_table', env=dict(DA4ML_HIP_TABLE_SCALE='6000'))['bad'] == []
 
 
+@pytest.mark.skipif(not os.environ.get('DA4ML_EMU_SLOW'), reason='minutes to half an hour per record: set DA4ML_EMU_SLOW=1 (run before every hand-over of kernel changes that no GPU has seen)')
+@pytest.mark.parametrize('name,fname', [('128x128_seed0_single_chain_ref', 'large_chain_golden.json'), ('64x64_seed0_default', 'large_default_golden.json'),
+                                        ('256x256_seed0_single_chain', 'large_chain_golden.json')])  # fmt: skip
+def test_large_records_on_the_emulated_device(emu, name, fname):
+    """the benchmark's own chain (256x256 int8, seed 0: 19 810 greedy steps, 2 M-slot table, thousands of partner rows per
+    step) and the 128x128 record of the reference build through the kernels on the emulated device: 3 / 4 / 21 minutes"""
+    assert emu('record', name, fname, timeout=7200)['equal']
+
+
 def test_column_sharded_engine_single_rank(emu):
     """HipShardEngine (k_cs_init_counts, k_cs_init_table, k_iter_select<SHARDED>, k_cs_union, k_cs_partial, k_cs_apply)"""
     assert emu('shard_single', env=dict(DA4ML_SHARD_FORCE='1'))['bad'] == []
