@@ -3,6 +3,8 @@
 // device the calls fail with DA_ERR_NO_DEVICE / NULL and a message.
 
 #include <cstdlib>
+#include <chrono>
+#include <cstdio>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -152,8 +154,11 @@ int da_solve_batch(int count, const float *const *kernels, const int64_t *n_in, 
             p.opt.search_all = search_all_decompose_dc != 0;
         }
         std::vector<da::ChainStats> stats;
+        const auto t0 = std::chrono::steady_clock::now();
         std::vector<da::PipeResult> res = da::solve_batch(backend(), probs, &stats);
         for (int i = 0; i < count; ++i) results[i] = new da_result{std::move(res[i]), i < (int)stats.size() ? stats[i] : da::ChainStats{}};
+        if (std::getenv("DA4ML_HIP_VERBOSE"))
+            std::fprintf(stderr, "[da4ml_hip] da_solve_batch(%d): %.2f ms\n", count, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
         return DA_OK;
     } catch (const std::exception &e) {
         return fail(e);

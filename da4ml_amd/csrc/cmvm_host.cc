@@ -110,14 +110,15 @@ void stage1_prepare(Stage1 &s, const float *kernel, int n_in, int n_out) {
     s.W = n_out + 1;
     s.centered.assign(kernel, kernel + (size_t)n_in * n_out);
     center_matrix(s.centered, n_in, n_out, s.s0, s.s1);
-    s.aug.assign((size_t)n_in * s.W, 0.0f);
-    for (int i = 0; i < n_in; ++i)
-        std::copy_n(&s.centered[(size_t)i * n_out], n_out, &s.aug[(size_t)i * s.W + 1]);
 }
 
+// column distances of the matrix augmented with a zero column (only decompositions with dc != -1 need them).  Called from one
+// thread per Stage1 object: before the candidates of a problem are split on several threads, or from kernel_decompose().
 void stage1_distances(Backend &be, Stage1 &s) {
     if (s.have_dist) return;
     size_t W = (size_t)s.W;
+    s.aug.assign((size_t)s.n_in * W, 0.0f);
+    for (int i = 0; i < s.n_in; ++i) std::copy_n(&s.centered[(size_t)i * s.n_out], s.n_out, &s.aug[(size_t)i * W + 1]);
     std::vector<int32_t> ai(s.aug.size());
     for (size_t k = 0; k < ai.size(); ++k) ai[k] = (int32_t)s.aug[k];
     std::vector<int64_t> d0(W * W), d1(W * W);
@@ -504,12 +505,29 @@ bool same_problem(const Problem &a, const Problem &b) {
 }
 uint64_t problem_hash(const Problem &p) {
     uint64_t h = 1469598103934665603ull;
-    auto mix = [&](const void *data, size_t n) {  // 4 bytes per step (every hashed array is a multiple of 4 bytes)
+    // (every hashed array is a multiple of 4 bytes.)  Four independent accumulators over 32-byte strides: the multiply chain of
+    // a single one made hashing the 64 matrices of a batch 5 ms of serial host time; the value only routes the de-duplication,
+    // equal hashes are settled by same_problem()
+    auto mix = [&](const void *data, size_t n) {
         const unsigned char *b = static_cast<const unsigned char *>(data);
-        for (size_t i = 0; i + 4 <= n; i += 4) {
+        uint64_t a[4] = {h, h ^ 0x9E3779B97F4A7C15ull, h ^ 0xC2B2AE3D27D4EB4Full, h ^ 0x165667B19E3779F9ull};
+        size_t i = 0;
+        for (; i + 32 <= n; i += 32)
+            for (int q = 0; q < 4; ++q) {
+                uint64_t w;
+                std::memcpy(&w, b + i + 8 * q, 8);
+                a[q] = (a[q] ^ w) * 1099511628211ull;
+                a[q] ^= a[q] >> 29;
+            }
+        for (; i + 4 <= n; i += 4) {
             uint32_t w;
             std::memcpy(&w, b + i, 4);
-            h = (h ^ w) * 1099511628211ull;
+            a[0] = (a[0] ^ w) * 1099511628211ull;
+            a[0] ^= a[0] >> 29;
+        }
+        h = a[0];
+        for (int q = 1; q < 4; ++q) {
+            h = (h ^ a[q]) * 1099511628211ull;
             h ^= h >> 29;
         }
     };
@@ -563,8 +581,15 @@ std::vector<PipeResult> solve_batch(Backend &be, const std::vector<Problem> &pro
 
 namespace {
 std::vector<PipeResult> solve_batch_unique(Backend &be, const std::vector<Problem> &problems, std::vector<ChainStats> *stats) {
+    const bool verbose = std::getenv("DA4ML_HIP_VERBOSE") != nullptr;
+    auto lap = [verbose, last = std::chrono::steady_clock::now()](const char *what) mutable {
+        auto now = std::chrono::steady_clock::now();
+        if (verbose) std::fprintf(stderr, "[da4ml_hip] host: %-24s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - last).count());
+        last = now;
+    };
     std::vector<ProblemState> ps(problems.size());
     std::vector<Candidate> cands;
+    std::vector<size_t> fresh;  // problems whose matrix is seen for the first time
     for (size_t i = 0; i < problems.size(); ++i) {
         const Problem &p = problems[i];
         ProblemState &s = ps[i];
@@ -581,7 +606,7 @@ std::vector<PipeResult> solve_batch_unique(Backend &be, const std::vector<Proble
         }
         if (!s.s1p) {
             s.s1p = std::make_shared<Stage1>();
-            stage1_prepare(*s.s1p, p.kernel, p.n_in, p.n_out);
+            fresh.push_back(i);  // centred below, all new matrices on the host threads together
         }
         int log2_n = (int)std::ceil(std::log2((float)p.n_in));
         std::vector<std::pair<int, int>> tries;  // (hard_dc, decompose_dc)
@@ -606,6 +631,8 @@ std::vector<PipeResult> solve_batch_unique(Backend &be, const std::vector<Proble
         }
     }
 
+    parallel_for(fresh.size(), [&](size_t k) { stage1_prepare(*ps[fresh[k]].s1p, problems[fresh[k]].kernel, problems[fresh[k]].n_in, problems[fresh[k]].n_out); });
+    lap("problem set-up");
     auto prepare_stage0 = [&](Candidate &c) {
         ProblemState &s = ps[c.problem];
         if (c.decompose_dc < 0 && c.hard_dc >= 0) c.method0 = c.method1 = (c.method0 != "dummy") ? "wmc-dc" : "dummy";
@@ -670,6 +697,7 @@ std::vector<PipeResult> solve_batch_unique(Backend &be, const std::vector<Proble
             }
         }
         if (jobs.empty()) break;
+        lap("stage 1 + job list");
         std::vector<ChainOut> outs(jobs.size());
         auto t_rc = std::chrono::steady_clock::now();
         {  // chains without a greedy loop are finished on the host; the others go to the backend together
@@ -709,6 +737,7 @@ std::vector<PipeResult> solve_batch_unique(Backend &be, const std::vector<Proble
             std::fprintf(stderr, "[da4ml_hip] round of %zu chains: run_chains %.2f ms, adder trees %.2f ms\n", jobs.size(),
                          std::chrono::duration<double, std::milli>(t_fin - t_rc).count(),
                          std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_fin).count());
+        lap("chains + adder trees");
         for (size_t k = 0; k < jobs.size(); ++k) {
             Candidate &c = cands[owners[k].cand];
             ProblemState &s = ps[c.problem];
@@ -756,6 +785,7 @@ std::vector<PipeResult> solve_batch_unique(Backend &be, const std::vector<Proble
         }
     }
 
+    lap("candidate bookkeeping");
     std::vector<PipeResult> results(problems.size());
     for (size_t i = 0; i < problems.size(); ++i) {
         ProblemState &s = ps[i];
@@ -776,6 +806,7 @@ std::vector<PipeResult> solve_batch_unique(Backend &be, const std::vector<Proble
         results[i].stages.push_back(std::move(w.sol0));
         results[i].stages.push_back(std::move(w.sol1));
     }
+    lap("winner selection");
     return results;
 }
 
