@@ -90,6 +90,18 @@ def record(name, fname):
     out(equal=p.cost == rec['cost'] and [len(s.ops) for s in p.solutions] == rec['n_ops'] and sha == rec['sha256'], cost=p.cost)
 
 
+def fork_after_use():
+    """the host thread pool of the library (parked threads, cmvm_host.cc) does not exist in a forked child: the child must start
+    its own instead of waiting for threads that were never copied"""
+    ks = [int_matrix(s, 16, 16, -128, 128) for s in range(8)]
+    a = hip.solve_many(ks, **SINGLE)
+    pid = os.fork()
+    if pid == 0:
+        os._exit(0 if hip.solve_many(ks, **SINGLE) == a else 3)
+    _, st = os.waitpid(pid, 0)
+    out(child=os.WEXITSTATUS(st), parent=hip.solve_many(ks, **SINGLE) == a)
+
+
 def retry():
     """arena heuristics far too small (environment set by the test): capacity error on the device, rerun with larger arenas"""
     o = Oracle('port')
@@ -180,5 +192,5 @@ def dais():
 
 if __name__ == '__main__':
     what = sys.argv[1]
-    {'random': lambda: random_cases(int(sys.argv[2]), int(sys.argv[3])), 'layouts': layouts, 'batch': batch, 'retry': retry, 'big_table': big_table, 'record': lambda: record(sys.argv[2], sys.argv[3]),
+    {'random': lambda: random_cases(int(sys.argv[2]), int(sys.argv[3])), 'layouts': layouts, 'batch': batch, 'retry': retry, 'big_table': big_table, 'fork': fork_after_use, 'record': lambda: record(sys.argv[2], sys.argv[3]),
      'shard_single': shard_single, 'shard_rank': shard_rank, 'dais': dais, 'race_cases': race_cases}[what]()  # fmt: skip

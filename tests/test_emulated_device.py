@@ -51,6 +51,10 @@ def test_batched_chains(emu):
     assert r['bad'] == [] and r['chains'] >= 13
 
 
+def test_fork_after_use(emu):
+    assert emu('fork', timeout=120) == {'child': 0, 'parent': True}
+
+
 def test_capacity_retry(emu):
     r = emu('retry', env=dict(DA4ML_HIP_TABLE_SCALE='0.02', DA4ML_HIP_ROW_SCALE='0.05'))
     assert r['equal'] and r['retries'] >= 1
