@@ -456,8 +456,11 @@ class HostPool {
     }
     // false: the pool is in use (a nested or concurrent loop) -- the caller runs the loop on threads of its own
     template <class Fn> bool run(size_t n, Fn &&fn) {
-        std::unique_lock<std::mutex> busy(run_mu_, std::try_to_lock);
-        if (!busy.owns_lock()) return false;
+        if (busy_.test_and_set(std::memory_order_acquire)) return false;
+        struct Release {
+            std::atomic_flag &f;
+            ~Release() { f.clear(std::memory_order_release); }
+        } release{busy_};
         std::exception_ptr err;
         std::mutex err_mu;
         std::atomic<size_t> next{0};
@@ -517,7 +520,8 @@ class HostPool {
             if (--pending_ == 0) cv_done_.notify_one();
         }
     }
-    std::mutex mu_, run_mu_;
+    std::mutex mu_;
+    std::atomic_flag busy_ = ATOMIC_FLAG_INIT;
     std::condition_variable cv_work_, cv_done_;
     std::vector<std::thread> threads_;
     std::function<void()> *body_ = nullptr;
