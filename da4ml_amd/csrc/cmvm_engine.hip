@@ -573,6 +573,25 @@ __global__ void __launch_bounds__(256) k_prepare(ChainDev *chains) {
 // ------------------------------------------------------------------------------------------------ k_init_cells
 // grid (ceil(n_out / 4), n_chains): one wave per column builds the entries of that column in the (dense) lists of the
 // input rows and the column's row list.
+// grid (blocks, chains): the state every chain starts from -- claim stamps, ranks, group bounds and row bitmaps zero, keys
+// EMPTY (all ones), every group dirty.  16-byte stores; every array starts on a 256-byte boundary of the arena and is followed
+// by padding up to the next one (Carver), so the last, partial 16 bytes of an array may be written whole.
+__device__ __forceinline__ void fill16(void *p, size_t bytes, uint32_t v, size_t t0, size_t stride) {
+    da_i4 *q = reinterpret_cast<da_i4 *>(p);
+    const da_i4 w = da_i4{(int)v, (int)v, (int)v, (int)v};
+    for (size_t i = t0, n = (bytes + 15) / 16; i < n; i += stride) q[i] = w;
+}
+__global__ void __launch_bounds__(256) k_init_state(ChainDev *chains) {
+    const ChainDev &ch = chains[blockIdx.y];
+    const size_t t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+    fill16(ch.stamp, sizeof(uint32_t) * (size_t)ch.rcap, 0u, t0, stride);
+    fill16(ch.hkey, sizeof(unsigned long long) * (size_t)ch.C, 0xFFFFFFFFu, t0, stride);
+    fill16(ch.hrank, sizeof(uint32_t) * (size_t)ch.C, 0u, t0, stride);
+    fill16(ch.ub, sizeof(unsigned long long) * (size_t)ch.n_groups, 0u, t0, stride);
+    fill16(ch.gdirty, (size_t)ch.n_groups, 0x01010101u, t0, stride);
+    fill16(ch.colbits, sizeof(uint32_t) * (size_t)ch.n_out * ch.cb_words, 0u, t0, stride);
+}
+
 template <class Cell> __global__ void __launch_bounds__(256) k_init_cells(ChainDev *chains) {
     using O = CellOps<Cell>;
     using F = RowFmt<Cell>;
@@ -2153,17 +2172,13 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
         d.claim_words = (g.rcap + 31) / 32 * 4 <= 64 * 1024 ? (g.rcap + 31) / 32 : 0;
         d.iter = 0;
         d.done = (jobs[i].method == M_DUMMY || jobs[i].method < 0) ? 1 : 0;
-        // zero-initialised state: stamp, hrank, ub; hkey = EMPTY (all ones)
-        HIP_CHECK(hipMemsetAsync(d.stamp, 0, sizeof(uint32_t) * (size_t)g.rcap, st));
-        HIP_CHECK(hipMemsetAsync(d.hkey, 0xFF, sizeof(unsigned long long) * (size_t)g.C, st));
-        HIP_CHECK(hipMemsetAsync(d.hrank, 0, sizeof(uint32_t) * (size_t)g.C, st));
-        HIP_CHECK(hipMemsetAsync(d.ub, 0, sizeof(unsigned long long) * (size_t)g.n_groups, st));
-        HIP_CHECK(hipMemsetAsync(d.gdirty, 1, (size_t)g.n_groups, st));
         d.cb_words = (g.rcap + 31) / 32;
-        HIP_CHECK(hipMemsetAsync(d.colbits, 0, sizeof(uint32_t) * (size_t)jobs[i].n_out * d.cb_words, st));
     }
     HIP_CHECK(hipMemcpyAsync(d_desc, desc.data(), sizeof(ChainDev) * (size_t)n, hipMemcpyHostToDevice, st));
     HIP_CHECK(hipMemsetAsync(im.d_done, 0, sizeof(unsigned int), st));
+    // initial state of all chains in ONE launch (was six hipMemsetAsync per chain: 384 calls and 384 small kernels per batch)
+    hipLaunchKernelGGL(k_init_state, dim3(128, n), dim3(256), 0, st, d_desc);
+    HIP_CHECK(hipGetLastError());
 
     // ---- 3. launch per cell width (descriptors are grouped so that one launch covers a contiguous range)
     std::vector<int> order(n);
