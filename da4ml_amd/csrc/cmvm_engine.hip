@@ -235,6 +235,7 @@ struct ChainDev {
     unsigned long long *pk_cell;   // ... and their cells
     float *pk_lat;                 // [n_rows] latency of every row
     int pk_cap;
+    uint32_t pk_total;             // digits packed by k_pack (= fin_start[n_out])
     // column-sharded chains (cmvm_shard.h): the matrix handed to k_prepare has pn_out columns of which this chain holds
     // [col0, col0 + n_out); exchange buffers of the greedy step.  Ordinary chains: pn_out == n_out, col0 == 0.
     int pn_out, col0;
@@ -1804,6 +1805,7 @@ __global__ void __launch_bounds__(256) k_pack(ChainDev *chains) {
         }
         if (lane == 0) {
             ch.fin_start[n_out] = run;
+            ch.pk_total = run;
             s_total = run;
         }
     }
@@ -1821,6 +1823,26 @@ __global__ void __launch_bounds__(256) k_pack(ChainDev *chains) {
         }
     }
     for (int r = tid; r < ch.n_rows; r += blockDim.x) ch.pk_lat[r] = ch.rows[r].lat;
+}
+
+// ------------------------------------------------------------------------------------------------ k_gather
+// grid (blocks, pieces): the result arrays of all chains of a batch (seven per chain, scattered over the arena) copied into ONE
+// contiguous buffer, which then leaves in a single device-to-host copy (448 small copies per 64-chain batch before: each a DMA
+// operation of its own, ~10 us apiece on one stream).  Sources start on 256-byte boundaries, destinations on 64-byte ones.
+struct GatherPiece {
+    const void *src;
+    unsigned long long dst_off, bytes;
+};
+__global__ void __launch_bounds__(256) k_gather(const GatherPiece *pieces, unsigned char *dst) {
+    const GatherPiece pc = pieces[blockIdx.y];
+    const size_t t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+    const size_t n16 = (size_t)pc.bytes / 16;
+    const da_i4 *s16 = reinterpret_cast<const da_i4 *>(pc.src);
+    da_i4 *d16 = reinterpret_cast<da_i4 *>(dst + pc.dst_off);
+    for (size_t i = t0; i < n16; i += stride) d16[i] = s16[i];
+    const unsigned char *s1 = reinterpret_cast<const unsigned char *>(pc.src);
+    unsigned char *d1 = dst + pc.dst_off;
+    for (size_t i = n16 * 16 + t0; i < (size_t)pc.bytes; i += stride) d1[i] = s1[i];
 }
 
 // ------------------------------------------------------------------------------------------------ k_col_dist
@@ -1946,7 +1968,7 @@ struct HipBackend::Impl {
                       // four hardware queues; the poll stream's rare copies share one of them at no visible cost
     int upd_total_blocks = 2560;  // k_iter_update blocks over all chains of a batch (4 waves x 4 groups each); measured (C3 batch 64,
                                   // solves/s): 1024: 45.3, 1536: 53.3, 2048: 53.8, 2560: 55.5, 4096: 47.5
-    DeviceBuffer arena, desc_buf, io_buf;
+    DeviceBuffer arena, desc_buf, io_buf, gather_buf, piece_buf;  // gather_buf: the results of a batch, contiguous, before they leave
     unsigned int *d_done = nullptr;
     unsigned int *h_done = nullptr;  // pinned, two words: done counters of alternating poll windows
     hipStream_t poll_stream = nullptr;
@@ -2409,74 +2431,67 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
         --retry_depth_;
         return;
     }
-    size_t down_bytes = 0;
-    // Results through ONE pinned staging buffer (copies into pageable memory are staged and block, ~80 us each, and there
-    // are seven per chain): first the column offsets (= sizes of the digit arrays), the shifts and the picks, then exactly
-    // the digits.
-    std::vector<size_t> st_off(n), s0_off(n), s1_off(n), pk_off(n), lat_off(n), row_off(n), cell_off(n);
-    size_t pin_bytes = 0;
-    for (int s = 0; s < n; ++s) {
-        const ChainJob &j = jobs[order[s]];
-        st_off[s] = pin_bytes;
-        pin_bytes += align_up(((size_t)j.n_out + 1) * 4, 64);
-        s0_off[s] = pin_bytes;
-        pin_bytes += align_up((size_t)j.n_in, 64);
-        s1_off[s] = pin_bytes;
-        pin_bytes += align_up((size_t)j.n_out, 64);
-        pk_off[s] = pin_bytes;
-        pin_bytes += align_up((size_t)fin[s].iter * sizeof(int4), 64);
-    }
-    unsigned char *pin = static_cast<unsigned char *>(im.pinned.get(pin_bytes));
-    for (int s = 0; s < n; ++s) {
-        const ChainDev &d = fin[s];
-        const ChainJob &j = jobs[order[s]];
-        HIP_CHECK(hipMemcpyAsync(pin + st_off[s], d.fin_start, ((size_t)j.n_out + 1) * 4, hipMemcpyDeviceToHost, st));
-        HIP_CHECK(hipMemcpyAsync(pin + s0_off[s], d.shift0, j.n_in, hipMemcpyDeviceToHost, st));
-        HIP_CHECK(hipMemcpyAsync(pin + s1_off[s], d.shift1, j.n_out, hipMemcpyDeviceToHost, st));
-        if (d.iter) HIP_CHECK(hipMemcpyAsync(pin + pk_off[s], d.picks, (size_t)d.iter * sizeof(int4), hipMemcpyDeviceToHost, st));
-        down_bytes += (size_t)d.iter * 16;
-    }
-    HIP_CHECK(hipStreamSynchronize(st));
-    std::vector<uint32_t> totals(n);
-    size_t pin2 = 0;
-    for (int s = 0; s < n; ++s) {
-        const ChainJob &j = jobs[order[s]];
-        ChainOut &o = outs[order[s]];
-        const uint32_t *cs = reinterpret_cast<const uint32_t *>(pin + st_off[s]);
-        o.col_start.assign(cs, cs + j.n_out + 1);
-        totals[s] = cs[j.n_out];
-        o.shift0.assign(reinterpret_cast<const int8_t *>(pin + s0_off[s]), reinterpret_cast<const int8_t *>(pin + s0_off[s]) + j.n_in);
-        o.shift1.assign(reinterpret_cast<const int8_t *>(pin + s1_off[s]), reinterpret_cast<const int8_t *>(pin + s1_off[s]) + j.n_out);
-        const int32_t *pk = reinterpret_cast<const int32_t *>(pin + pk_off[s]);
-        o.picks.assign(pk, pk + (size_t)fin[s].iter * 4);
-        lat_off[s] = pin2;
-        pin2 += align_up((size_t)fin[s].n_rows * 4, 64);
-        row_off[s] = pin2;
-        pin2 += align_up((size_t)totals[s] * 4, 64);
-        cell_off[s] = pin2;
-        pin2 += align_up((size_t)totals[s] * 8, 64);
-    }
-    pin = static_cast<unsigned char *>(im.pinned.get(pin2));  // (the first area has been consumed above)
+    // Results: the seven arrays of every chain (column offsets, shifts, picks, row latencies, surviving digits) are gathered
+    // into one contiguous device buffer by k_gather and leave in ONE copy into pinned memory (they used to leave one by one:
+    // 448 copies per 64-chain batch in two synchronised phases).
+    struct ResultOffsets {
+        size_t st, s0, s1, pk, lat, row, cell;
+        uint32_t total;
+    };
+    std::vector<ResultOffsets> roff(n);
+    std::vector<GatherPiece> pieces;
+    pieces.reserve((size_t)n * 7);
+    size_t gather_bytes = 0;
+    auto piece = [&](const void *src, size_t bytes) {
+        const size_t at = gather_bytes;
+        if (bytes) pieces.push_back(GatherPiece{src, (unsigned long long)at, (unsigned long long)bytes});
+        gather_bytes += align_up(bytes, 64);
+        return at;
+    };
     for (int s = 0; s < n; ++s) {
         const ChainDev &d = fin[s];
-        HIP_CHECK(hipMemcpyAsync(pin + lat_off[s], d.pk_lat, (size_t)d.n_rows * 4, hipMemcpyDeviceToHost, st));
-        if (totals[s]) {
-            HIP_CHECK(hipMemcpyAsync(pin + row_off[s], d.pk_row, (size_t)totals[s] * 4, hipMemcpyDeviceToHost, st));
-            HIP_CHECK(hipMemcpyAsync(pin + cell_off[s], d.pk_cell, (size_t)totals[s] * 8, hipMemcpyDeviceToHost, st));
+        const ChainJob &j = jobs[order[s]];
+        ResultOffsets &ro = roff[s];
+        ro.total = d.error == E_OK ? d.pk_total : 0u;  // a failed chain delivers no digits (finalize_chain raises for it)
+        ro.st = piece(d.fin_start, ((size_t)j.n_out + 1) * 4);
+        ro.s0 = piece(d.shift0, (size_t)j.n_in);
+        ro.s1 = piece(d.shift1, (size_t)j.n_out);
+        ro.pk = piece(d.picks, (size_t)d.iter * sizeof(int4));
+        ro.lat = piece(d.pk_lat, (size_t)d.n_rows * 4);
+        ro.row = piece(d.pk_row, (size_t)ro.total * 4);
+        ro.cell = piece(d.pk_cell, (size_t)ro.total * 8);
+    }
+    unsigned char *pin = static_cast<unsigned char *>(im.pinned.get(std::max<size_t>(gather_bytes, 64)));
+    {
+        unsigned char *gbuf = static_cast<unsigned char *>(im.gather_buf.get(std::max<size_t>(gather_bytes, 64)));
+        GatherPiece *d_pieces = static_cast<GatherPiece *>(im.piece_buf.get(std::max<size_t>(pieces.size(), 1) * sizeof(GatherPiece)));
+        HIP_CHECK(hipMemcpyAsync(d_pieces, pieces.data(), pieces.size() * sizeof(GatherPiece), hipMemcpyHostToDevice, st));
+        for (size_t first = 0; first < pieces.size(); first += 32768) {  // grid.y is a 16-bit quantity
+            const unsigned cnt = (unsigned)std::min<size_t>(32768, pieces.size() - first);
+            hipLaunchKernelGGL(k_gather, dim3(16, cnt), dim3(256), 0, st, d_pieces + first, gbuf);
         }
-        down_bytes += (size_t)totals[s] * 12;
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipMemcpyAsync(pin, gbuf, gather_bytes, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
     }
-    HIP_CHECK(hipStreamSynchronize(st));
     for (int s = 0; s < n; ++s) {
         const ChainDev &d = fin[s];
+        const ChainJob &j = jobs[order[s]];
+        const ResultOffsets &ro = roff[s];
         int i = order[s];
         ChainOut &o = outs[i];
-        const float *lat = reinterpret_cast<const float *>(pin + lat_off[s]);
+        const uint32_t *cs = reinterpret_cast<const uint32_t *>(pin + ro.st);
+        o.col_start.assign(cs, cs + j.n_out + 1);
+        o.shift0.assign(reinterpret_cast<const int8_t *>(pin + ro.s0), reinterpret_cast<const int8_t *>(pin + ro.s0) + j.n_in);
+        o.shift1.assign(reinterpret_cast<const int8_t *>(pin + ro.s1), reinterpret_cast<const int8_t *>(pin + ro.s1) + j.n_out);
+        const int32_t *pk = reinterpret_cast<const int32_t *>(pin + ro.pk);
+        o.picks.assign(pk, pk + (size_t)d.iter * 4);
+        const float *lat = reinterpret_cast<const float *>(pin + ro.lat);
         o.row_lat.assign(lat, lat + d.n_rows);
-        const uint32_t *pr = reinterpret_cast<const uint32_t *>(pin + row_off[s]);
-        const unsigned long long *pc = reinterpret_cast<const unsigned long long *>(pin + cell_off[s]);
-        o.dig_row.assign(pr, pr + totals[s]);
-        o.dig_cell.assign(pc, pc + totals[s]);
+        const uint32_t *pr = reinterpret_cast<const uint32_t *>(pin + ro.row);
+        const unsigned long long *pc = reinterpret_cast<const unsigned long long *>(pin + ro.cell);
+        o.dig_row.assign(pr, pr + ro.total);
+        o.dig_cell.assign(pc, pc + ro.total);
         o.stats.iterations = d.iter;
         o.stats.digits0 = d.prep_digits;
         o.stats.table_peak = d.live_peak;
@@ -2500,7 +2515,6 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
     im.timings.chains += n;
     im.timings.arena_bytes = std::max(im.timings.arena_bytes, (double)arena_bytes);
     im.timings.total_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
-    (void)down_bytes;
     (void)max_n_in;
 }
 
