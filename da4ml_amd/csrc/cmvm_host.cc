@@ -301,7 +301,16 @@ StageResult finalize_chain(const ChainJob &job, const ChainOut &out, int inner_t
     r.carry_size = job.carry_size;
     r.inp_shifts.assign(out.shift0.begin(), out.shift0.end());
     size_t n_iter = out.picks.size() / 4;
-    r.ops.reserve(job.n_in + n_iter * 2);
+    // a column with t terms (digits) emits exactly t - 1 tree ops: the size of the op list is known before anything is built
+    const int n_out = job.n_out;
+    std::vector<int64_t> first_op((size_t)n_out + 1, 0);  // tree ops of the columns before j
+    for (int j = 0; j < n_out; ++j) {
+        int64_t terms = 0;
+        for (uint32_t k = out.col_start[j]; k < out.col_start[j + 1]; ++k)
+            terms += __builtin_popcountll(((uint64_t)(uint32_t)out.dig_cell[k]) | (out.dig_cell[k] >> 32));
+        first_op[j + 1] = first_op[j] + (terms > 1 ? terms - 1 : 0);
+    }
+    r.ops.reserve((size_t)job.n_in + n_iter + (size_t)first_op[n_out]);
     for (int i = 0; i < job.n_in; ++i) r.ops.push_back(OpRec{i, -1, -1, 0, job.qints[i], job.lats[i], 0.0f});
     // op records of the greedy picks, with the host libm (state_opr.cc:211-225)
     for (size_t t = 0; t < n_iter; ++t) {
@@ -318,23 +327,21 @@ StageResult finalize_chain(const ChainJob &job, const ChainOut &out, int inner_t
         r.ops.push_back(OpRec{a, b, (int64_t)sub, shift, qint_add(oa.q, ob.q, shift, false, sub), lat, cost});
     }
     // One min-heap reduction per output column (cmvm_core.cc:103-210).  The columns are independent: a tree op refers to
-    // pick / input ops (ids < n_fixed, final already) and to earlier ops of its own column only.  Chunks of columns are
-    // therefore reduced on `inner_threads` host threads with chunk-local ids (n_fixed + position in the chunk's op list;
-    // the order relations the heap looks at are the same as with the final ids) and concatenated in column order.
+    // pick / input ops (ids < n_fixed, final already) and to earlier ops of its own column only.  The ids of every column are
+    // known before any tree is built (prefix sum of the term counts above; the reference numbers the ops column after column,
+    // cmvm_core.cc:101,199-203): the op list is sized once and chunks of columns are reduced on `inner_threads` host
+    // threads straight into their final places -- no per-thread lists, no renumbering, no concatenation (the allocator
+    // traffic of 256 threads growing megabyte vectors was most of this function's wall time).
     const int64_t n_fixed = (int64_t)r.ops.size();
-    struct Chunk {
-        std::vector<OpRec> ops;
-        std::vector<int64_t> idx, shift, neg;  // per column of the chunk; idx in chunk-local numbering
-    };
-    const int n_out = job.n_out;
+    r.ops.resize((size_t)(n_fixed + first_op[n_out]));
+    r.out_idxs.assign((size_t)n_out, -1);
+    r.out_shifts.assign((size_t)n_out, 0);
+    r.out_negs.assign((size_t)n_out, 0);
     const int n_chunks = inner_threads > 1 ? std::min(n_out, inner_threads * 4) : 1;
-    std::vector<Chunk> chunks((size_t)n_chunks);
     auto reduce_chunk = [&](int c) {
-        Chunk &ck = chunks[c];
         const int j0 = (int)((long long)n_out * c / n_chunks), j1 = (int)((long long)n_out * (c + 1) / n_chunks);
         std::vector<Term> heap;
         auto cmp = [](const Term &x, const Term &y) { return term_after(x, y); };
-        auto op_at = [&](int64_t id) -> const OpRec & { return id < n_fixed ? r.ops[id] : ck.ops[id - n_fixed]; };
         for (int j = j0; j < j1; ++j) {
             heap.clear();
             for (uint32_t k = out.col_start[j]; k < out.col_start[j + 1]; ++k) {
@@ -344,22 +351,21 @@ StageResult finalize_chain(const ChainJob &job, const ChainOut &out, int inner_t
                 while (any) {
                     int pos = __builtin_ctz(any);
                     any &= any - 1;
-                    const OpRec &o = op_at(row);
+                    const OpRec &o = r.ops[row];
                     heap.push_back(Term{o.latency, (int64_t)((minus >> pos) & 1), magnitude_bits(o.q) + pos, o.q, row, pos});
                 }
             }
             if (heap.empty()) {
-                ck.idx.push_back(-1);
-                ck.shift.push_back(out.shift1[j]);
-                ck.neg.push_back(0);
+                r.out_shifts[j] = out.shift1[j];  // out_idxs -1, not negated
                 continue;
             }
             if (heap.size() == 1) {
-                ck.idx.push_back(heap[0].id);
-                ck.shift.push_back((int64_t)out.shift1[j] + heap[0].shift);
-                ck.neg.push_back(heap[0].neg);
+                r.out_idxs[j] = heap[0].id;
+                r.out_shifts[j] = (int64_t)out.shift1[j] + heap[0].shift;
+                r.out_negs[j] = heap[0].neg;
                 continue;
             }
+            int64_t id = n_fixed + first_op[j];  // this column's ops: [id, n_fixed + first_op[j + 1])
             std::make_heap(heap.begin(), heap.end(), cmp);
             while (heap.size() > 1) {
                 std::pop_heap(heap.begin(), heap.end(), cmp);
@@ -376,14 +382,15 @@ StageResult finalize_chain(const ChainJob &job, const ChainOut &out, int inner_t
                 float dlat, cost;
                 cost_add(base.q, other.q, sh, sub_op, job.adder_size, job.carry_size, dlat, cost);
                 float lat = std::max(first.lat, second.lat) + dlat;
-                int64_t id = n_fixed + (int64_t)ck.ops.size();
-                ck.ops.push_back(OpRec{base.id, other.id, (int64_t)sub_op, sh, q, lat, cost});
+                r.ops[id] = OpRec{base.id, other.id, (int64_t)sub_op, sh, q, lat, cost};
                 heap.push_back(Term{lat, first.neg & second.neg, magnitude_bits(q) + base.shift, q, id, base.shift});
                 std::push_heap(heap.begin(), heap.end(), cmp);
+                ++id;
             }
-            ck.idx.push_back(n_fixed + (int64_t)ck.ops.size() - 1);
-            ck.neg.push_back(heap[0].neg);
-            ck.shift.push_back((int64_t)out.shift1[j] + heap[0].shift);
+            if (id != n_fixed + first_op[j + 1]) throw std::runtime_error("adder tree of a column emitted an unexpected number of ops (internal error)");
+            r.out_idxs[j] = id - 1;
+            r.out_negs[j] = heap[0].neg;
+            r.out_shifts[j] = (int64_t)out.shift1[j] + heap[0].shift;
         }
     };
     if (n_chunks == 1)
@@ -407,25 +414,6 @@ StageResult finalize_chain(const ChainJob &job, const ChainOut &out, int inner_t
         work();
         for (auto &t : pool) t.join();
         if (err) std::rethrow_exception(err);
-    }
-    size_t total = r.ops.size();
-    for (const Chunk &ck : chunks) total += ck.ops.size();
-    r.ops.reserve(total);
-    r.out_idxs.reserve(n_out);
-    r.out_shifts.reserve(n_out);
-    r.out_negs.reserve(n_out);
-    for (Chunk &ck : chunks) {
-        const int64_t off = (int64_t)r.ops.size() - n_fixed;  // chunk-local id -> final id
-        for (OpRec &o : ck.ops) {
-            if (o.id0 >= n_fixed) o.id0 += off;
-            if (o.id1 >= n_fixed) o.id1 += off;
-            r.ops.push_back(o);
-        }
-        for (size_t k = 0; k < ck.idx.size(); ++k) {
-            r.out_idxs.push_back(ck.idx[k] >= n_fixed ? ck.idx[k] + off : ck.idx[k]);
-            r.out_shifts.push_back(ck.shift[k]);
-            r.out_negs.push_back(ck.neg[k]);
-        }
     }
     return r;
 }
