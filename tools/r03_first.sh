@@ -2,7 +2,9 @@
 # FIRST gpurun call of round 3.  The last GPU-measured kernels are those of revision 70c8f1a (profiles/r02_*); everything after
 # it -- the round-trip cuts of k_iter_update / k_iter_select made by ISA reading, the kernel-argument preload -- was verified on
 # the emulated device only (tests/emu: oracle parity, ASan, race detector), never timed.  This script settles them:
-#   HERE first (no GPU):   tools/ab_ref.sh measured=70c8f1a nopreload=WORKTREE:"KERNARG=" timers=WORKTREE:"PHASE_TIMERS=1"
+#   HERE first (no GPU):   tools/ab_ref.sh measured=70c8f1a kernels=a9a2b25 nopreload=WORKTREE:"KERNARG=" timers=WORKTREE:"PHASE_TIMERS=1"
+#                          (measured -> kernels: the round-trip cuts + the preload; kernels -> HEAD: the host-path changes --
+#                          thread pool, parallel centring, k_init_state, k_gather, in-place adder trees)
 #                          (timers: per-phase shader-clock cycles of both kernels, printed at the end; it is slower by design)
 #   then:                  gpurun --timeout 1500 -- 'bash tools/r03_first.sh'
 # 1. the whole GPU parity suite on the working tree; 2. alternating timings (64-chain C3 batch and one chain alone) of the
