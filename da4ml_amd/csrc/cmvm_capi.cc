@@ -258,7 +258,11 @@ int da_result_stats(const da_result *r, int64_t *s) {
     std::memcpy(s, v, sizeof v);
     return DA_OK;
 }
-void da_free(da_result *r) { delete r; }
+void da_free(da_result *r) {
+    if (!r) return;
+    for (da::StageResult &st : r->pipe.stages) da::recycle_op_list(std::move(st.ops));  // kept for the next call (cmvm_host.h)
+    delete r;
+}
 
 int da_timings(double *t, int reset) {
     std::lock_guard<std::mutex> lk(g_mutex);

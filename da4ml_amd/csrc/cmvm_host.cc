@@ -292,6 +292,55 @@ static bool host_chain(const ChainJob &job, ChainOut &out) {
     return true;
 }
 
+namespace {
+struct OpListStash {
+    std::mutex mu;
+    std::vector<std::vector<OpRec>> lists;
+    size_t bytes = 0;
+    static constexpr size_t MAX_BYTES = (size_t)1 << 30, MAX_LISTS = 1024, MIN_KEEP = 4096;  // ops; smaller lists are not worth keeping
+};
+OpListStash &op_list_stash() {
+    static OpListStash *s = new OpListStash();  // leaked: results may be released during interpreter shutdown
+    return *s;
+}
+}  // namespace
+
+std::vector<OpRec> take_op_list(size_t capacity) {
+    OpListStash &st = op_list_stash();
+    {
+        std::lock_guard<std::mutex> lk(st.mu);
+        int best = -1;
+        for (int k = (int)st.lists.size() - 1; k >= 0; --k)  // the smallest one that is large enough
+            if (st.lists[k].capacity() >= capacity && (best < 0 || st.lists[k].capacity() < st.lists[best].capacity())) best = k;
+        if (best >= 0) {
+            std::vector<OpRec> v = std::move(st.lists[best]);
+            st.lists[best] = std::move(st.lists.back());
+            st.lists.pop_back();
+            st.bytes -= v.capacity() * sizeof(OpRec);
+            v.clear();
+            return v;
+        }
+    }
+    std::vector<OpRec> v;
+    v.reserve(capacity);
+    return v;
+}
+
+void recycle_op_list(std::vector<OpRec> &&ops) {
+    if (ops.capacity() < OpListStash::MIN_KEEP) return;
+    OpListStash &st = op_list_stash();
+    std::vector<OpRec> drop;  // released outside the lock
+    std::lock_guard<std::mutex> lk(st.mu);
+    const size_t b = ops.capacity() * sizeof(OpRec);
+    if (st.bytes + b > OpListStash::MAX_BYTES || st.lists.size() >= OpListStash::MAX_LISTS) {
+        drop = std::move(ops);
+        return;
+    }
+    ops.clear();
+    st.bytes += b;
+    st.lists.push_back(std::move(ops));
+}
+
 StageResult finalize_chain(const ChainJob &job, const ChainOut &out, int inner_threads) {
     if (out.error != E_OK) throw std::runtime_error("CMVM chain failed on the device (error " + std::to_string(out.error) + ")");
     StageResult r;
@@ -310,7 +359,7 @@ StageResult finalize_chain(const ChainJob &job, const ChainOut &out, int inner_t
             terms += __builtin_popcountll(((uint64_t)(uint32_t)out.dig_cell[k]) | (out.dig_cell[k] >> 32));
         first_op[j + 1] = first_op[j] + (terms > 1 ? terms - 1 : 0);
     }
-    r.ops.reserve((size_t)job.n_in + n_iter + (size_t)first_op[n_out]);
+    r.ops = take_op_list((size_t)job.n_in + n_iter + (size_t)first_op[n_out]);
     for (int i = 0; i < job.n_in; ++i) r.ops.push_back(OpRec{i, -1, -1, 0, job.qints[i], job.lats[i], 0.0f});
     // op records of the greedy picks, with the host libm (state_opr.cc:211-225)
     for (size_t t = 0; t < n_iter; ++t) {
@@ -892,6 +941,10 @@ std::vector<PipeResult> solve_batch_unique(Backend &be, const std::vector<Proble
         Candidate &w = cands[s.cand[best]];
         results[i].stages.push_back(std::move(w.sol0));
         results[i].stages.push_back(std::move(w.sol1));
+    }
+    for (Candidate &c : cands) {  // the op lists of the candidates that lost (the winners' were moved out: nothing left to keep)
+        recycle_op_list(std::move(c.sol0.ops));
+        recycle_op_list(std::move(c.sol1.ops));
     }
     lap("winner selection");
     return results;

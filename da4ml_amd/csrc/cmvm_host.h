@@ -108,6 +108,11 @@ void kernel_decompose(Backend &be, const float *kernel, int n_in, int n_out, int
                       std::vector<float> &m1);
 
 // cmvm_core.cc:89-225 from a finished chain
+// Op lists are megabytes (65 k ops x 56 bytes for a 256x256 chain) and a batch holds 64 of them: handed to the allocator, each
+// is an mmap on creation, ~900 page faults on first touch and a munmap (with a TLB shoot-down on every core the process has
+// run on) on release -- per result and per call.  Released lists are kept here instead (bounded) and handed to the next call.
+std::vector<OpRec> take_op_list(size_t capacity);  // empty vector with at least this capacity (recycled if one fits)
+void recycle_op_list(std::vector<OpRec> &&ops);    // called by da_free / when a result is dropped
 StageResult finalize_chain(const ChainJob &job, const ChainOut &out, int inner_threads = 1);  // inner_threads: host threads for the per-column trees
 
 // api.cc:147-250 for a batch of independent problems (one entry per matrix); problems progress together so
