@@ -341,7 +341,9 @@ void recycle_op_list(std::vector<OpRec> &&ops) {
     st.lists.push_back(std::move(ops));
 }
 
-StageResult finalize_chain(const ChainJob &job, const ChainOut &out, int inner_threads) {
+// Part 1 (one thread per chain): input and greedy-pick op records, sizes and ids of the per-column adder trees.
+// Part 2 (any thread, any order, disjoint column ranges): the trees, written straight into their final places.
+StageResult finalize_prepare(const ChainJob &job, const ChainOut &out, std::vector<int64_t> &first_op) {
     if (out.error != E_OK) throw std::runtime_error("CMVM chain failed on the device (error " + std::to_string(out.error) + ")");
     StageResult r;
     r.n_in = job.n_in;
@@ -352,7 +354,7 @@ StageResult finalize_chain(const ChainJob &job, const ChainOut &out, int inner_t
     size_t n_iter = out.picks.size() / 4;
     // a column with t terms (digits) emits exactly t - 1 tree ops: the size of the op list is known before anything is built
     const int n_out = job.n_out;
-    std::vector<int64_t> first_op((size_t)n_out + 1, 0);  // tree ops of the columns before j
+    first_op.assign((size_t)n_out + 1, 0);  // tree ops of the columns before j
     for (int j = 0; j < n_out; ++j) {
         int64_t terms = 0;
         for (uint32_t k = out.col_start[j]; k < out.col_start[j + 1]; ++k)
@@ -375,20 +377,22 @@ StageResult finalize_chain(const ChainJob &job, const ChainOut &out, int inner_t
             throw std::runtime_error("device latency model diverged from the host libm at iteration " + std::to_string(t));
         r.ops.push_back(OpRec{a, b, (int64_t)sub, shift, qint_add(oa.q, ob.q, shift, false, sub), lat, cost});
     }
-    // One min-heap reduction per output column (cmvm_core.cc:103-210).  The columns are independent: a tree op refers to
-    // pick / input ops (ids < n_fixed, final already) and to earlier ops of its own column only.  The ids of every column are
-    // known before any tree is built (prefix sum of the term counts above; the reference numbers the ops column after column,
-    // cmvm_core.cc:101,199-203): the op list is sized once and chunks of columns are reduced on `inner_threads` host
-    // threads straight into their final places -- no per-thread lists, no renumbering, no concatenation (the allocator
-    // traffic of 256 threads growing megabyte vectors was most of this function's wall time).
+    // One min-heap reduction per output column follows (finalize_columns, cmvm_core.cc:103-210).  The columns are independent:
+    // a tree op refers to pick / input ops (final already) and to earlier ops of its own column only, and the ids of every
+    // column are known before any tree is built (prefix sum of the term counts above; the reference numbers the ops column
+    // after column, cmvm_core.cc:101,199-203): the op list is sized once here and column ranges are reduced on any thread
+    // straight into their final places -- no per-thread lists, no renumbering, no concatenation.
     const int64_t n_fixed = (int64_t)r.ops.size();
     r.ops.resize((size_t)(n_fixed + first_op[n_out]));
     r.out_idxs.assign((size_t)n_out, -1);
     r.out_shifts.assign((size_t)n_out, 0);
     r.out_negs.assign((size_t)n_out, 0);
-    const int n_chunks = inner_threads > 1 ? std::min(n_out, inner_threads * 4) : 1;
-    auto reduce_chunk = [&](int c) {
-        const int j0 = (int)((long long)n_out * c / n_chunks), j1 = (int)((long long)n_out * (c + 1) / n_chunks);
+    return r;
+}
+
+void finalize_columns(const ChainJob &job, const ChainOut &out, StageResult &r, const std::vector<int64_t> &first_op, int j0, int j1) {
+    const int64_t n_fixed = (int64_t)r.ops.size() - first_op[job.n_out];
+    {
         std::vector<Term> heap;
         auto cmp = [](const Term &x, const Term &y) { return term_after(x, y); };
         for (int j = j0; j < j1; ++j) {
@@ -441,9 +445,19 @@ StageResult finalize_chain(const ChainJob &job, const ChainOut &out, int inner_t
             r.out_negs[j] = heap[0].neg;
             r.out_shifts[j] = (int64_t)out.shift1[j] + heap[0].shift;
         }
+    }
+}
+
+StageResult finalize_chain(const ChainJob &job, const ChainOut &out, int inner_threads) {
+    std::vector<int64_t> first_op;
+    StageResult r = finalize_prepare(job, out, first_op);
+    const int n_out = job.n_out;
+    const int n_chunks = inner_threads > 1 ? std::min(n_out, inner_threads * 4) : 1;
+    auto reduce_chunk = [&](int c) {
+        finalize_columns(job, out, r, first_op, (int)((long long)n_out * c / n_chunks), (int)((long long)n_out * (c + 1) / n_chunks));
     };
-    if (n_chunks == 1)
-        reduce_chunk(0);
+    if (n_chunks <= 1)
+        finalize_columns(job, out, r, first_op, 0, n_out);
     else {
         std::atomic<int> next{0};
         std::exception_ptr err;
@@ -537,7 +551,7 @@ class HostPool {
     }
     HostPool() {
         unsigned hw = std::thread::hardware_concurrency();
-        const int n = (int)std::max(1u, std::min(hw ? hw : 1u, 64u)) - 1;
+        const int n = (int)std::max(1u, std::min(hw ? hw : 1u, 256u)) - 1;  // all cores of the GPU box's host (256) for the tree pieces
         for (int t = 0; t < n; ++t) threads_.emplace_back([this, t] { worker(t); });
         for (auto &t : threads_) t.detach();
     }
@@ -859,16 +873,31 @@ std::vector<PipeResult> solve_batch_unique(Backend &be, const std::vector<Proble
                 throw std::runtime_error("Unknown method: " + (owners[k].what == 2 ? c.method1 : c.method0));
             }
         std::vector<StageResult> sols(jobs.size());
-        // the chains are spread over the host threads first; what is left of the machine works on the columns of each
-        // chain (256 cores for the 64 chains of the benchmark: 4 threads per chain)
-        const size_t hw_threads = std::max(1u, std::thread::hardware_concurrency());
-        int inner = (int)std::max<size_t>(1, std::min<size_t>(8, hw_threads / std::max<size_t>(1, std::min<size_t>(jobs.size(), 64))));
-        size_t inner_from = 4096;  // digits of a chain from which the extra threads pay
-        if (const char *e = std::getenv("DA4ML_HIP_TREE_THREADS")) {  // test hook: force the chunked reduction on small chains too
-            inner = std::max(1, std::atoi(e));
-            inner_from = 0;
+        // Adder trees in two loops over the host threads: (1) per chain, the op records of the inputs and the greedy picks
+        // (sequential inside a chain) and the tree sizes; (2) per (chain, range of columns), the trees -- 1024 pieces for the
+        // 64 chains of the benchmark, balanced over all threads of the pool with no thread created on the way
+        std::vector<std::vector<int64_t>> first_op(jobs.size());
+        parallel_for(jobs.size(), [&](size_t k) { sols[k] = finalize_prepare(jobs[k], outs[k], first_op[k]); });
+        size_t chunk_from = 4096;  // digits of a chain from which its columns are split into ranges
+        int chunks_per_chain = 16;
+        if (const char *e = std::getenv("DA4ML_HIP_TREE_THREADS")) {  // test hook: split small chains too, 4 ranges per "thread"
+            chunks_per_chain = std::max(1, std::atoi(e)) * 4;
+            chunk_from = 0;
         }
-        parallel_for(jobs.size(), [&](size_t k) { sols[k] = finalize_chain(jobs[k], outs[k], outs[k].dig_row.size() >= inner_from ? inner : 1); });
+        struct Piece {
+            int chain, j0, j1;
+        };
+        std::vector<Piece> pieces;
+        for (size_t k = 0; k < jobs.size(); ++k) {
+            const int n_out = jobs[k].n_out;
+            const int parts = outs[k].dig_row.size() >= chunk_from ? std::max(1, std::min(n_out, chunks_per_chain)) : 1;
+            for (int c = 0; c < parts; ++c)
+                pieces.push_back(Piece{(int)k, (int)((long long)n_out * c / parts), (int)((long long)n_out * (c + 1) / parts)});
+        }
+        parallel_for(pieces.size(), [&](size_t i) {
+            const Piece &pc = pieces[i];
+            finalize_columns(jobs[pc.chain], outs[pc.chain], sols[pc.chain], first_op[pc.chain], pc.j0, pc.j1);
+        });
         if (std::getenv("DA4ML_HIP_VERBOSE"))
             std::fprintf(stderr, "[da4ml_hip] round of %zu chains: run_chains %.2f ms, adder trees %.2f ms\n", jobs.size(),
                          std::chrono::duration<double, std::milli>(t_fin - t_rc).count(),

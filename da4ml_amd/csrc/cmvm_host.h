@@ -113,7 +113,9 @@ void kernel_decompose(Backend &be, const float *kernel, int n_in, int n_out, int
 // run on) on release -- per result and per call.  Released lists are kept here instead (bounded) and handed to the next call.
 std::vector<OpRec> take_op_list(size_t capacity);  // empty vector with at least this capacity (recycled if one fits)
 void recycle_op_list(std::vector<OpRec> &&ops);    // called by da_free / when a result is dropped
-StageResult finalize_chain(const ChainJob &job, const ChainOut &out, int inner_threads = 1);  // inner_threads: host threads for the per-column trees
+StageResult finalize_prepare(const ChainJob &job, const ChainOut &out, std::vector<int64_t> &first_op);  // inputs + greedy picks, tree sizes
+void finalize_columns(const ChainJob &job, const ChainOut &out, StageResult &r, const std::vector<int64_t> &first_op, int j0, int j1);  // trees of columns [j0, j1)
+StageResult finalize_chain(const ChainJob &job, const ChainOut &out, int inner_threads = 1);  // both, on inner_threads threads of its own  // inner_threads: host threads for the per-column trees
 
 // api.cc:147-250 for a batch of independent problems (one entry per matrix); problems progress together so
 // that every round submits all currently runnable chains to the backend at once.
