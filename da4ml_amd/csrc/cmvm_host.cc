@@ -534,6 +534,7 @@ class HostPool {
             ++epoch_;
         }
         cv_work_.notify_all();
+        if (helpers > NARROW) cv_wide_.notify_all();  // the threads beyond the first 63 are woken for wide loops only
         body();  // the calling thread works too
         {
             std::unique_lock<std::mutex> lk(mu_);
@@ -551,7 +552,8 @@ class HostPool {
     }
     HostPool() {
         unsigned hw = std::thread::hardware_concurrency();
-        const int n = (int)std::max(1u, std::min(hw ? hw : 1u, 256u)) - 1;  // all cores of the GPU box's host (256) for the tree pieces
+        int n = (int)std::max(1u, std::min(hw ? hw : 1u, 256u)) - 1;  // all cores of the GPU box's host (256) for the tree pieces
+        if (const char *e = std::getenv("DA4ML_HOST_THREADS")) n = std::max(1, std::min(1024, std::atoi(e))) - 1;  // test hook
         for (int t = 0; t < n; ++t) threads_.emplace_back([this, t] { worker(t); });
         for (auto &t : threads_) t.detach();
     }
@@ -561,7 +563,7 @@ class HostPool {
             std::function<void()> *body = nullptr;
             {
                 std::unique_lock<std::mutex> lk(mu_);
-                cv_work_.wait(lk, [&] { return epoch_ != seen; });
+                (index < NARROW ? cv_work_ : cv_wide_).wait(lk, [&] { return epoch_ != seen; });
                 seen = epoch_;
                 if (index < wanted_) body = body_;
             }
@@ -573,7 +575,8 @@ class HostPool {
     }
     std::mutex mu_;
     std::atomic_flag busy_ = ATOMIC_FLAG_INIT;
-    std::condition_variable cv_work_, cv_done_;
+    static constexpr int NARROW = 63;
+    std::condition_variable cv_work_, cv_wide_, cv_done_;
     std::vector<std::thread> threads_;
     std::function<void()> *body_ = nullptr;
     uint64_t epoch_ = 0;

@@ -51,6 +51,13 @@ def test_batched_chains(emu):
     assert r['bad'] == [] and r['chains'] >= 13
 
 
+def test_wide_host_pool(emu):
+    """the host thread pool as on the 256-core GPU box: 200 threads, of which those beyond the first 63 are woken for wide loops
+    only (here: 14 chains x 8 column ranges of the adder trees)"""
+    r = emu('batch', env=dict(DA4ML_HOST_THREADS='200', DA4ML_HIP_TREE_THREADS='2'))
+    assert r['bad'] == [] and r['chains'] >= 13
+
+
 def test_fork_after_use(emu):
     assert emu('fork', timeout=120) == {'child': 0, 'parent': True}
 
