@@ -102,6 +102,8 @@ int da_stage_copy(const da_result *r, int stage, int64_t *inp_shifts, int64_t *o
 /* stats[0..7] = greedy iterations, initial digits, -, selection rounds, peak pair blocks, re-read table slots,
  * partner rows updated, substituted digits -- summed over the chains run for this problem */
 int da_result_stats(const da_result *r, int64_t *stats);
+/* Releases a result handle (NULL is ignored).  The op lists of the result are kept by the library for the next solve
+ * (at most 1 GiB in total) instead of being returned to the allocator. */
 void da_free(da_result *r);
 
 /* ---- DAIS program executor (host) -------------------------------------------------------------------------- */
