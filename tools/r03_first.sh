@@ -21,5 +21,7 @@ for rep in 1 2 3; do
 done | tee gpurun_out/ab/summary.txt
 for n in timers; do [ -f gpurun_out/ab/$n.perf1.log ] && { echo "--- phase cycles ($n): batch 64, then one chain"; sed -n 3,4p gpurun_out/ab/$n.perf1.log; sed -n 3,4p gpurun_out/ab/$n.single1.log; }; done
 unset DA4ML_HIP_LIB
+# host phases of one 64-chain call of HEAD (upload, init, loop, download, set-up, adder trees): where the non-loop time goes
+DA4ML_HIP_VERBOSE=1 timeout 90 python tests/gpu_profile.py 256 64 2>&1 | grep "da4ml_hip" | tail -24 | tee gpurun_out/ab/host_phases.txt
 QUICK=1 bash tools/collect_profiles.sh r03 2>&1 | tail -3
 tail -c 600 gpurun_out/profiles_r03/bench.json
