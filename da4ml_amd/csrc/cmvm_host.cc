@@ -249,6 +249,21 @@ inline int64_t magnitude_bits(const QInt &q) { return (int64_t)std::log2(std::ma
 // column in row order.  Returns false when the chain has to run on the device.
 static bool host_chain(const ChainJob &job, ChainOut &out) {
     const int n_in = job.n_in, n_out = job.n_out;
+    if (job.method != M_DUMMY && job.method >= 0) {
+        // quick way out for the ordinary chain: a column with two non-zero entries in live rows holds at least two digits, so
+        // the chain has a greedy loop and belongs to the device (found within the first rows of a dense matrix; the full
+        // examination below copies and centres the matrix)
+        std::vector<uint8_t> seen((size_t)n_out, 0);
+        for (int i = 0; i < n_in; ++i) {
+            if (job.qints[i].lo == 0.0f && job.qints[i].hi == 0.0f) continue;
+            const float *row = job.kernel + (size_t)i * n_out;
+            for (int j = 0; j < n_out; ++j)
+                if (row[j] != 0.0f) {
+                    if (seen[j]) return false;
+                    seen[j] = 1;
+                }
+        }
+    }
     std::vector<float> a(job.kernel, job.kernel + (size_t)n_in * n_out);
     std::vector<int8_t> s0, s1;
     center_matrix(a, n_in, n_out, s0, s1);
