@@ -56,3 +56,27 @@ TEST_CMVM_GRID = [
     for d in (0, -1, -2)
     for s in (False, True)
 ]
+
+
+METHODS = ('mc', 'mc-dc', 'mc-pdc', 'wmc', 'wmc-dc', 'wmc-pdc')
+COST_MODELS = ((-1, -1), (1, -1), (4, 8))
+
+
+def _method_grid():
+    """(name, int_matrix arguments, options): every selector x hard_dc x cost model at 32x32 and 64x64 int8 with the default
+    decomposition choice (search off: the `decompose_dc--` retry runs), and every selector as ONE 64x64 chain."""
+    grid = []
+    for n, seed in ((32, 5), (64, 6)):
+        for m in METHODS:
+            for h in (-1, 0, 2):
+                for a, c in COST_MODELS:
+                    opts = dict(method0=m, method1='auto', hard_dc=h, decompose_dc=-2, adder_size=a, carry_size=c, search_all_decompose_dc=False)
+                    grid.append((f'{n}x{n} {m} hard_dc={h} adder={a} carry={c}', (seed, n, n, -128, 128), opts))
+    for m in METHODS:
+        for a, c in COST_MODELS:
+            opts = dict(method0=m, method1=m, hard_dc=-1, decompose_dc=-1, adder_size=a, carry_size=c, search_all_decompose_dc=False)
+            grid.append((f'64x64 single chain {m} adder={a} carry={c}', (7, 64, 64, -128, 128), opts))
+    return grid
+
+
+METHOD_GRID = _method_grid()

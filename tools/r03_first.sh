@@ -11,7 +11,7 @@
 # working tree and of every library in ab_libs/; 3. QUICK profile collection of the working tree -> gpurun_out/profiles_r03/
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out/ab; rm -f gpurun_out/ab/*
 timeout 700 python -m pytest tests -m gpu -x -q 2>&1 | tail -5 | tee gpurun_out/ab/parity_head.log
-for rep in 1 2 3; do
+for rep in 1 2; do
   for lib in HEAD ab_libs/lib_*.so; do
     if [ "$lib" = HEAD ]; then unset DA4ML_HIP_LIB; n=head; else export DA4ML_HIP_LIB=$lib; n=$(basename $lib .so); n=${n#lib_}; fi
     a=$(timeout 90 python tests/gpu_profile.py 256 64 2>&1 | tee gpurun_out/ab/$n.perf$rep.log | sed -n '1p;6p' | tr '\n' ' ')
