@@ -128,7 +128,21 @@ template <class T> __device__ __forceinline__ T *gen(DA_GLOBAL T *p) { return (T
 // it and the prologue becomes a chain of 4-6 dependent scalar round trips to L2 (ISA reading, round 2).  Loading every
 // field first and pinning the values before the first branch makes it ONE round trip: an empty asm that "uses" the
 // register is a point the load cannot be moved past.
-#define DA_PIN_ASM(x) asm volatile("" : "+s"(x))
+// (inside the persistent kernel the descriptor is re-read in every task, behind stores and fences: those loads are vector
+// loads of a uniform address, and the explicit v_readfirstlane is what moves the value into a scalar register; on a value that
+// already lives in one it folds away)
+template <class T> __device__ __forceinline__ T da_uniform(T v) {
+    static_assert(sizeof(T) == 4 || sizeof(T) == 8, "pinned descriptor fields are 32- or 64-bit values");
+    if constexpr (sizeof(T) == 4) {
+        const int r = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v));
+        return __builtin_bit_cast(T, r);
+    } else {
+        const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+        const unsigned int lo = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)u), hi = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)(u >> 32));
+        return __builtin_bit_cast(T, ((unsigned long long)hi << 32) | lo);
+    }
+}
+#define DA_PIN_ASM(x) do { x = da_uniform(x); asm volatile("" : "+s"(x)); } while (0)
 template <class T> __device__ __forceinline__ void pin_one(T &v) { DA_PIN_ASM(v); }
 template <class... T> __device__ __forceinline__ void pin_sgpr(T &...v) { (pin_one(v), ...); }
 // The same for per-lane values, and a compiler-level fence for memory operations.  "Load early, use late": a loaded value
@@ -687,11 +701,13 @@ template <class Cell> __global__ void __launch_bounds__(256) k_init_pairs(ChainD
 // SHARDED (column-sharded chain, cmvm_shard.h): the chain holds a slice of the columns and a replica of the pair table.
 // The arg-max and the substitution are the same; the counts of the pairs among {A, B, new} are only PARTIAL here and go to
 // the head of the exchange slab instead of the table, and instead of a partner list the kernel leaves one flag per row.
-template <class Cell, bool SHARDED = false> __global__ void __launch_bounds__(SEL_THREADS) k_iter_select(ChainDev *chains, unsigned int *n_done) {
+// select_body: one greedy step's selection + substitution of chain `g` by a 1024-thread workgroup; returns 1 when the chain
+// is (or just became) finished, 0 after an ordinary step (hand-off for the update written).  Called by the k_iter_select
+// wrapper (one launch per step: the column-sharded chain and the DA4ML_HIP_ENGINE=launch path) and by the persistent k_greedy.
+template <class Cell, bool SHARDED = false> __device__ __forceinline__ int select_body(ChainDev *g, unsigned int *n_done) {
     using O = CellOps<Cell>;
     using F = RowFmt<Cell>;
     using Entry = typename F::Entry;
-    ChainDev *g = &chains[blockIdx.x];
     // ---- ONE scalar round trip: every descriptor field the block needs, pinned before the first branch (pin_sgpr; left
     // alone the compiler sinks each load behind the branch that first needs it -- ten dependent round trips in this kernel)
     int was_done = g->done, had_error = g->error, iter = g->iter, n_groups = g->n_groups, lcap = g->lcap, claim_words = g->claim_words;
@@ -717,7 +733,7 @@ template <class Cell, bool SHARDED = false> __global__ void __launch_bounds__(SE
     if constexpr (SHARDED) pin_sgpr(cs_slab, cs_flags);
     ctx_finish(c);
     const int n_out = c.n_out, Kpad = c.Kpad, nb = c.n_bits;
-    if (was_done) return;
+    if (was_done) return 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // dynamic LDS carve: B's list | special-pair counters | per-matched-column scratch | column -> position in B | claim bitmap
     Entry *s_bent = reinterpret_cast<Entry *>(smem);                                  // [n_out] entries of row B (updated in place)
@@ -750,7 +766,7 @@ template <class Cell, bool SHARDED = false> __global__ void __launch_bounds__(SE
             g->n_partners = 0;
             atomicAdd(n_done, 1u);
         }
-        return;
+        return 1;
     }
 
     // ---------------- (1) selection.  A group is CLEAN when no block in it changed its best (rank, key) since the
@@ -993,7 +1009,7 @@ template <class Cell, bool SHARDED = false> __global__ void __launch_bounds__(SE
             g->n_partners = 0;
             atomicAdd(n_done, 1u);
         }
-        return;
+        return 1;
     }
     const uint32_t A = (uint32_t)((best_tie >> 7) & 0xFFFFFFu), B = (uint32_t)(best_tie >> 31);
     const int idx = (int)(best_tie & 0x7F);
@@ -1024,7 +1040,7 @@ template <class Cell, bool SHARDED = false> __global__ void __launch_bounds__(SE
             g->n_partners = 0;
             atomicAdd(n_done, 1u);
         }
-        return;
+        return 1;
     }
     DA_GLOBAL Entry *rlA = rl + refA.x, *rlB = rl + refB.x, *rlN = rl + offN;
     // this thread's entry of A (first chunk) and of B: pass 1 below then starts without a dependent load
@@ -1319,6 +1335,10 @@ template <class Cell, bool SHARDED = false> __global__ void __launch_bounds__(SE
         g->n_rows = (int)Nw + 1;
         g->iter = iter + 1;
     }
+    return 0;
+}
+template <class Cell, bool SHARDED = false> __global__ void __launch_bounds__(SEL_THREADS) k_iter_select(ChainDev *chains, unsigned int *n_done) {
+    (void)select_body<Cell, SHARDED>(&chains[blockIdx.x], n_done);
 }
 
 #ifndef DA_UPD_OCC
@@ -1351,8 +1371,12 @@ __device__ __forceinline__ unsigned long long row_max_u64(unsigned long long v) 
     return v;
 }
 
-template <class Cell>
-__global__ void __launch_bounds__(UPD_THREADS, DA_UPD_OCC) __attribute__((amdgpu_num_sgpr(DA_UPD_SGPRS))) k_iter_update(ChainDev *chains, int n_chains) {
+// update_body: the partner rows [block_y * NWV * QN + ..., stride grid_y * NWV * QN) of chain `gq`'s current step, by a
+// workgroup of NWV wavefronts.  k_iter_update (256-thread blocks, grid = chains x blocks) and the persistent k_greedy (1024-thread
+// workgroups, one "chunk" of a step per call) both run it.
+template <class Cell, int NWV>
+__device__ __forceinline__ void update_body(ChainDev *gq, bool in_range, int block_y, int grid_y) {
+    constexpr int NTHR = NWV * WAVE;
     using F = RowFmt<Cell>;
     using Entry = typename F::Entry;
     constexpr int QCW = sizeof(Cell) == 4 ? 2 : 4;  // count words per lane: narrow layout Kpad / 2 <= 24 words, wide <= 60
@@ -1360,7 +1384,6 @@ __global__ void __launch_bounds__(UPD_THREADS, DA_UPD_OCC) __attribute__((amdgpu
     // the XCDs round-robin by their linear id, so all blocks of chain c -- and block c of k_iter_select, which has the same
     // linear id modulo 8 -- run on XCD c mod 8: the table lines, bounds and lists of a chain stay in ONE of the eight
     // non-coherent L2s instead of being spread over all of them.
-    ChainDev *gq = &chains[(int)blockIdx.x < n_chains ? blockIdx.x : 0];  // clamped: the descriptor read below is unconditional
     // ---- ONE scalar round trip: every descriptor field the block needs, pinned before the first branch (pin_sgpr)
     int done = gq->done, n_partners = gq->n_partners, iter = gq->iter, m = gq->m, n_in = gq->n_in;
     uint32_t A = gq->A, B = gq->B, Nw = gq->Nw;
@@ -1370,27 +1393,26 @@ __global__ void __launch_bounds__(UPD_THREADS, DA_UPD_OCC) __attribute__((amdgpu
     const DA_GLOBAL uint16_t *cmap = (const DA_GLOBAL uint16_t *)gq->cmap;
     const DA_GLOBAL Entry *rl = (const DA_GLOBAL Entry *)gq->rlist;
     const DA_GLOBAL unsigned long long *plist = (const DA_GLOBAL unsigned long long *)gq->plist;
-    int grid_y = (int)gridDim.y;
     pin_sgpr(done, n_partners, iter, m, n_in, A, B, Nw, grid_y, mcol, mA, mB, cmap, rl, plist);
     pin_sgpr(c.n_out, c.n_bits, c.K, c.Kpad, c.method, c.gs_log2, c.pb_log2, c.cmask, c.windows, c.hkey, c.hrank, c.hblk, c.ub, c.gdirty, c.rows);
     ctx_finish(c);
-    if ((int)blockIdx.x >= n_chains || done) return;
+    if (!in_range || done) return;
     // the grid is sized for the partner counts of the first steps of a chain (thousands); later most blocks have nothing
     // to do and leave before the hand-off is copied
-    if ((int)blockIdx.y * (UPD_WAVES * QN) >= n_partners) return;
+    if (block_y * (NWV * QN) >= n_partners) return;
     ChainDev *g = gq;
     const int nb = c.n_bits, Kpad = c.Kpad, n_out = c.n_out, K = c.K;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // LDS: consumed digits of A [n_out] and B [n_out] | per-wave, per-partner counters [UPD_WAVES][QN][3][Kpad] | the
+    // LDS: consumed digits of A [n_out] and B [n_out] | per-wave, per-partner counters [NWV][QN][3][Kpad] | the
     // substituted columns [n_out] | column -> 1 + index of the substituted column, 0 = not substituted [n_out]
     Cell *s_mA = reinterpret_cast<Cell *>(smem);
     Cell *s_mB = s_mA + n_out;
     uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_mB + n_out);
-    int *s_col = reinterpret_cast<int *>(s_cnt + (size_t)UPD_WAVES * QN * 3 * Kpad);
+    int *s_col = reinterpret_cast<int *>(s_cnt + (size_t)NWV * QN * 3 * Kpad);
     uint16_t *s_cmap = reinterpret_cast<uint16_t *>(s_col + n_out);
     const int tid = threadIdx.x, lane = lane_id(), wid = wave_id();
     const int q = lane >> 4, l = lane & (QG - 1), qsh = q * QG;
-    const int total_waves = grid_y * UPD_WAVES, gw = (int)blockIdx.y * UPD_WAVES + wid;
+    const int total_waves = grid_y * NWV, gw = block_y * NWV + wid;
     // ---- ONE vector round trip: the group's first partner reference and the new row's record leave together with the
     // hand-off of k_iter_select (they used to wait behind the hand-off barrier: two more dependent round trips)
     unsigned long long ref_next = gw * QN + q < n_partners ? plist[gw * QN + q] : 0ull;
@@ -1398,8 +1420,8 @@ __global__ void __launch_bounds__(UPD_THREADS, DA_UPD_OCC) __attribute__((amdgpu
     __shared__ unsigned int s_stat[2];
     if (tid < 2) s_stat[tid] = 0;
     {  // the hand-off of k_iter_select into LDS: one pass, one barrier (the column map arrives ready-made)
-        for (int j = tid; j < n_out; j += UPD_THREADS) s_cmap[j] = cmap[j];
-        for (int j = tid; j < m; j += UPD_THREADS) {
+        for (int j = tid; j < n_out; j += NTHR) s_cmap[j] = cmap[j];
+        for (int j = tid; j < m; j += NTHR) {
             s_col[j] = mcol[j];
             s_mA[j] = mA[j];
             s_mB[j] = mB[j];
@@ -1562,6 +1584,230 @@ __global__ void __launch_bounds__(UPD_THREADS, DA_UPD_OCC) __attribute__((amdgpu
     if (tid == 0) {
         if (s_stat[0]) atomicAdd(&g->st_found, (unsigned long long)s_stat[0]);
         if (s_stat[1]) atomicAdd(&g->st_inserts, (unsigned long long)s_stat[1]);
+    }
+}
+template <class Cell>
+__global__ void __launch_bounds__(UPD_THREADS, DA_UPD_OCC) __attribute__((amdgpu_num_sgpr(DA_UPD_SGPRS))) k_iter_update(ChainDev *chains, int n_chains) {
+    // Grid (chains padded to a multiple of 8, blocks per chain): the chain index is the FAST grid dimension (see update_body)
+    update_body<Cell, UPD_WAVES>(&chains[(int)blockIdx.x < n_chains ? blockIdx.x : 0], (int)blockIdx.x < n_chains, (int)blockIdx.y, (int)gridDim.y);  // clamped: the descriptor read is unconditional
+}
+
+// ------------------------------------------------------------------------------------------------ k_greedy (persistent)
+// The whole greedy loop of a batch of chains in ONE launch.  With one (select, update) kernel pair per step a 64-chain batch is
+// bound by the two kernel boundaries per step, by the host's launch rate and -- chains advance in lockstep groups -- by the
+// slowest chain of every group in every step.  Here a grid of one 1024-thread workgroup per CU stays resident and the steps of
+// a chain are tasks:
+//   * SELECT  (select_body, one workgroup): arg-max, substitution, partner rows; then the step's update is published as
+//             n chunks in the chain's `work` word (epoch:32 | next chunk:16 | chunks:16);
+//   * UPDATE  (update_body, one chunk of the partner rows per workgroup): a workgroup takes a chunk with one atomic add on the
+//             work word, and the workgroup that finishes the LAST chunk of a step goes straight on to the chain's next SELECT.
+// Nobody ever waits for anybody: an idle workgroup polls the work words of its chains, claims an unstarted chain, or leaves
+// when nothing is left -- so the loop cannot deadlock whatever part of the grid is resident (a single workgroup alone runs every
+// chain to its end: that is how the CPU emulation executes it), and chains progress independently of each other.
+//
+// Visibility between workgroups.  A chain is HOMED on the XCD of the workgroup that claimed it, and only workgroups that read
+// the same HW_REG_XCC_ID ever touch it afterwards: everything a chain's tasks exchange goes through that XCD's one L2.  Hand-over
+// = every wave drains its stores (s_waitcnt vmcnt(0): acknowledged by the L2), workgroup barrier, ONE atomic on the chain's
+// sync record; take-over = the atomic that returned the task, then an agent-scope acquire (buffer_inv sc1: this CU's L1 is
+// dropped; the XCD's L2 is the point of coherence, nothing has to be written back for a reader behind the same L2), workgroup
+// barrier.  The home is established at run time from the hardware register, never from blockIdx or from an assumed dispatch
+// order; a workgroup on another XCD simply never sees the chain.  Within a task the sharing rules are those of one launch of
+// the kernel pair (tombstone tags, single writers per slot, atomics for claims / bounds).
+struct GreedySync {            // per chain
+    unsigned long long work;   // epoch:32 | next chunk:16 | chunks:16 of the step being updated
+    unsigned int done_chunks;  // chunks of that step that are finished
+    unsigned int pad;
+};
+struct GreedyXcd {             // one 128-byte line per XCD
+    unsigned int tickets;      // workgroups that asked for a first chain (the first ceil(n / 8) per XCD get one: balance)
+    unsigned int n_homed;      // chains homed on this XCD
+    unsigned int n_fin;        // ... that are finished
+    unsigned int pad[29];
+};
+struct GreedyCtl {
+    unsigned int next_chain;   // chains claimed so far
+    unsigned int n_finished;   // chains finished (the n_done counter of select_body)
+    unsigned int pad0[30];
+    GreedyXcd xcd[8];
+    // workgroup time by role (wall-clock ticks of s_memrealtime, 100 MHz) and task counts, summed over the grid at exit
+    unsigned long long t_select, t_update, t_idle, t_total, n_select, n_update, n_polls, n_wgs;
+};
+constexpr int GREEDY_XCDS = 8;
+#define DA_DRAIN_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+// this workgroup's XCD: s_getreg_b32 hwreg(HW_REG_XCC_ID, 0, 4)  (id 20; simm16 = (size - 1) << 11 | offset << 6 | id)
+__device__ __forceinline__ int xcc_id() { return (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u); }
+template <class T> __device__ __forceinline__ T ld_agent(const T *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <class T> __device__ __forceinline__ void st_agent(T *p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void greedy_take_over() {  // after the atomic that handed this workgroup a task
+    if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __syncthreads();
+}
+__device__ __forceinline__ void greedy_hand_over() {  // before the atomic that publishes what this workgroup wrote
+    DA_DRAIN_VMEM();
+    __syncthreads();
+}
+
+// The two task bodies are CALLED, not inlined: each keeps the register allocation it has as a kernel of its own (inlined into the
+// task loop, the scheduler's state and both bodies shared one allocation: 128 VGPRs and 53 spilled to scratch).
+template <class Cell> __device__ __attribute__((noinline)) int greedy_select(ChainDev *g, unsigned int *n_done) { return select_body<Cell, false>(g, n_done); }
+template <class Cell> __device__ __attribute__((noinline)) void greedy_update(ChainDev *g, int chunk, int n_chunks) {
+    update_body<Cell, SEL_THREADS / WAVE>(g, true, chunk, n_chunks);
+}
+
+template <class Cell>
+__global__ void __launch_bounds__(SEL_THREADS) k_greedy(ChainDev *chains, int n_chains, GreedyCtl *ctl, GreedySync *sync, unsigned int *homed, int max_chunks) {
+    constexpr int NW = SEL_THREADS / WAVE, PER_PASS = NW * QN;  // partner rows a workgroup handles per pass of update_body
+    constexpr unsigned IDLE_STEAL = 64;  // idle polls after which a workgroup claims chains beyond its XCD's share
+    __shared__ int s_task[4];
+    const int tid = threadIdx.x, lane = lane_id();
+    const int x = xcc_id();
+    unsigned int *my_homed = homed + (size_t)x * n_chains;  // entries are chain + 1 (0 = claimed, not yet written)
+    const unsigned quota = ((unsigned)n_chains + GREEDY_XCDS - 1) / GREEDY_XCDS;
+    int own = -1;     // the chain whose next SELECT this workgroup runs
+    int prefer = -1;  // the chain whose chunks it looks at first (the one it has just selected for / worked on)
+    int may_claim = -1;  // -1: not asked yet
+    unsigned idle = 0;
+    long long t_sel = 0, t_upd = 0, t_idle = 0, n_sel = 0, n_upd = 0, n_poll = 0;
+    const long long t_start = wall_clock64();
+    long long t_mark = t_start;
+    for (;;) {
+        int chunk = 0, nch = 0, chain = -1;
+        if (own < 0) {
+            // ---------------- look for work: a chunk of a chain of this XCD, else an unstarted chain, else leave when nothing is left
+            if (wave_id() == 0) {
+                int kind = 0;  // 0 nothing, 1 update chunk, 2 new chain, 3 leave
+                const unsigned nh = ld_agent(&ctl->xcd[x].n_homed);
+                for (unsigned base = 0; base < nh && kind == 0; base += WAVE) {
+                    const unsigned i = base + (unsigned)lane;
+                    const int c = i < nh ? (int)ld_agent(&my_homed[i]) - 1 : -1;
+                    const unsigned long long w = c >= 0 ? ld_agent(&sync[c].work) : 0ull;
+                    const bool avail = c >= 0 && (unsigned)((w >> 16) & 0xFFFFu) < (unsigned)(w & 0xFFFFu);
+                    unsigned long long mask = __ballot(avail);
+                    const unsigned long long pm = __ballot(avail && c == prefer);
+                    while (mask && kind == 0) {
+                        const int l = pm & mask ? __ffsll((long long)(pm & mask)) - 1 : __ffsll((long long)mask) - 1;
+                        mask &= ~(1ull << l);
+                        const int cc = __builtin_amdgcn_readlane(c, l);
+                        unsigned long long old = 0;
+                        if (lane == 0) old = atomicAdd(&sync[cc].work, 1ull << 16);
+                        const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)old);
+                        const int k = (int)(lo >> 16), n = (int)(lo & 0xFFFFu);
+                        if (k < n) {
+                            kind = 1;
+                            chain = cc;
+                            chunk = k;
+                            nch = n;
+                        }
+                    }
+                }
+                if (kind == 0) {
+                    int got = -1, leave = 0;
+                    if (lane == 0) {
+                        const unsigned nc = ld_agent(&ctl->next_chain);
+                        if (nc < (unsigned)n_chains) {
+                            if (may_claim < 0) may_claim = atomicAdd(&ctl->xcd[x].tickets, 1u) < quota ? 1 : 0;
+                            if (may_claim || idle >= IDLE_STEAL) {
+                                const unsigned c = atomicAdd(&ctl->next_chain, 1u);
+                                if (c < (unsigned)n_chains) {
+                                    const unsigned slot = atomicAdd(&ctl->xcd[x].n_homed, 1u);
+                                    st_agent(&my_homed[slot], c + 1u);
+                                    got = (int)c;
+                                }
+                            }
+                        } else if (ld_agent(&ctl->xcd[x].n_fin) >= ld_agent(&ctl->xcd[x].n_homed))
+                            leave = 1;  // every chain is claimed and the ones homed here are finished
+                    }
+                    got = __builtin_amdgcn_readfirstlane(got);
+                    leave = __builtin_amdgcn_readfirstlane(leave);
+                    may_claim = __builtin_amdgcn_readfirstlane(may_claim);
+                    if (got >= 0) {
+                        kind = 2;
+                        chain = got;
+                    } else if (leave)
+                        kind = 3;
+                }
+                if (lane == 0) {
+                    s_task[0] = kind;
+                    s_task[1] = chain;
+                    s_task[2] = chunk;
+                    s_task[3] = nch;
+                }
+            }
+            __syncthreads();
+            // (readfirstlane: the values are workgroup-uniform, and the bodies keep what they derive from them in scalar registers)
+            const int kind = __builtin_amdgcn_readfirstlane(s_task[0]);
+            chain = __builtin_amdgcn_readfirstlane(s_task[1]);
+            chunk = __builtin_amdgcn_readfirstlane(s_task[2]);
+            nch = __builtin_amdgcn_readfirstlane(s_task[3]);
+            __syncthreads();  // s_task is rewritten below / in the next round
+            ++n_poll;
+            if (kind == 3) break;
+            if (kind == 0) {
+                ++idle;
+                __builtin_amdgcn_s_sleep(8);
+                continue;
+            }
+            idle = 0;
+            {
+                const long long now = wall_clock64();
+                t_idle += now - t_mark;
+                t_mark = now;
+            }
+            if (kind == 2)
+                own = chain;
+            else {
+                // ---------------- UPDATE: chunk `chunk` of `nch` of the chain's current step
+                greedy_take_over();
+                greedy_update<Cell>(&chains[chain], chunk, nch);
+                greedy_hand_over();
+                if (tid == 0) s_task[0] = atomicAdd(&sync[chain].done_chunks, 1u) + 1u == (unsigned)nch ? chain : -1;  // last chunk: this workgroup selects next
+                __syncthreads();
+                own = __builtin_amdgcn_readfirstlane(s_task[0]);
+                __syncthreads();
+                prefer = chain;
+                ++n_upd;
+                const long long now = wall_clock64();
+                t_upd += now - t_mark;
+                t_mark = now;
+                if (own < 0) continue;
+            }
+        }
+        // ---------------- SELECT for chain `own`, then publish the step's update
+        greedy_take_over();
+        ChainDev *g = &chains[own];
+        const int fin = greedy_select<Cell>(g, &ctl->n_finished);
+        ++n_sel;
+        if (fin) {
+            __syncthreads();
+            if (tid == 0) atomicAdd(&ctl->xcd[x].n_fin, 1u);
+            own = -1;
+        } else {
+            greedy_hand_over();
+            const int np = __builtin_amdgcn_readfirstlane(ld_agent(&g->n_partners));
+            const int n = np <= 0 ? 0 : min(max_chunks, (np + PER_PASS - 1) / PER_PASS);
+            if (n > 0) {  // (no partner rows: nothing to update, the next selection follows at once)
+                if (tid == 0) {
+                    st_agent(&sync[own].done_chunks, 0u);
+                    DA_DRAIN_VMEM();
+                    st_agent(&sync[own].work, ((unsigned long long)(unsigned)ld_agent(&g->iter) << 32) | (unsigned)n);
+                }
+                prefer = own;
+                own = -1;
+            }
+        }
+        const long long now = wall_clock64();
+        t_sel += now - t_mark;
+        t_mark = now;
+    }
+    if (tid == 0) {
+        atomicAdd(&ctl->t_select, (unsigned long long)t_sel);
+        atomicAdd(&ctl->t_update, (unsigned long long)t_upd);
+        atomicAdd(&ctl->t_idle, (unsigned long long)t_idle);
+        atomicAdd(&ctl->t_total, (unsigned long long)(wall_clock64() - t_start));
+        atomicAdd(&ctl->n_select, (unsigned long long)n_sel);
+        atomicAdd(&ctl->n_update, (unsigned long long)n_upd);
+        atomicAdd(&ctl->n_polls, (unsigned long long)n_poll);
+        atomicAdd(&ctl->n_wgs, 1ull);
     }
 }
 
@@ -1975,6 +2221,12 @@ struct HipBackend::Impl {
     hipStream_t poll_stream = nullptr;
     GpuTimings timings;
     double table_scale = 1.0;  // grows on E_TABLE_CAPACITY retries
+    // greedy loop: one persistent launch per batch (k_greedy, default) or one (select, update) kernel pair per step
+    // (DA4ML_HIP_ENGINE=launch: the path the persistent kernel replaced, kept for A/B measurements)
+    bool persistent = true;
+    int n_cus = 256;         // workgroups of the persistent grid = compute units of the device
+    int max_chunks = 16;     // an update step is split into at most this many chunks (tasks)
+    DeviceBuffer greedy_buf; // GreedyCtl x 2 (narrow / wide chains) | GreedySync [n] | homed [8][n]
 };
 
 HipBackend::HipBackend(int device) : impl_(new Impl) {
@@ -1987,6 +2239,14 @@ HipBackend::HipBackend(int device) : impl_(new Impl) {
     if (const char *e = std::getenv("DA4ML_HIP_ROW_SCALE")) row_scale_ = std::max(1e-4, std::atof(e));
     if (const char *e = std::getenv("DA4ML_HIP_UPD_BLOCKS")) impl_->upd_total_blocks = std::max(2, std::atoi(e));
     if (const char *e = std::getenv("DA4ML_HIP_LANES")) impl_->n_lanes = std::max(1, std::min((int)Impl::MAX_LANES, std::atoi(e)));
+    if (const char *e = std::getenv("DA4ML_HIP_ENGINE")) impl_->persistent = std::string(e) != "launch";
+    if (const char *e = std::getenv("DA4ML_HIP_MAX_CHUNKS")) impl_->max_chunks = std::max(1, std::min(4096, std::atoi(e)));
+    {
+        hipDeviceProp_t prop;
+        HIP_CHECK(hipGetDeviceProperties(&prop, device));
+        impl_->n_cus = std::max(1, prop.multiProcessorCount);
+        if (const char *e = std::getenv("DA4ML_HIP_GREEDY_WGS")) impl_->n_cus = std::max(1, std::atoi(e));
+    }
     HIP_CHECK(hipMalloc(&impl_->d_done, sizeof(unsigned int)));
     HIP_CHECK(hipHostMalloc(&impl_->h_done, 2 * sizeof(unsigned int), hipHostMallocDefault));
     HIP_CHECK(hipStreamCreateWithFlags(&impl_->poll_stream, hipStreamNonBlocking));
@@ -2294,6 +2554,62 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
     HIP_CHECK(hipEventCreate(&ev1));
     HIP_CHECK(hipEventRecord(ev0, st));
     HIP_CHECK(hipStreamSynchronize(st));  // set-up done before the group streams start
+    if (im.persistent) {
+        // ---- 4a. ONE persistent launch per cell width: the workgroups take the steps of all chains as tasks (k_greedy)
+        const size_t ctl_bytes = align_up(sizeof(GreedyCtl), 256), sync_bytes = align_up(sizeof(GreedySync) * (size_t)n, 256),
+                     homed_bytes = align_up(sizeof(unsigned int) * (size_t)GREEDY_XCDS * (size_t)n, 256);
+        unsigned char *gb = static_cast<unsigned char *>(im.greedy_buf.get(2 * ctl_bytes + sync_bytes + 2 * homed_bytes));
+        HIP_CHECK(hipMemsetAsync(gb, 0, 2 * ctl_bytes + sync_bytes + 2 * homed_bytes, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        GreedySync *d_sync = reinterpret_cast<GreedySync *>(gb + 2 * ctl_bytes);
+        for (int w = 0; w < 2; ++w) {
+            const Range &r = ranges[w];
+            if (r.count == 0) continue;
+            GreedyCtl *d_ctl = reinterpret_cast<GreedyCtl *>(gb + (size_t)w * ctl_bytes);
+            unsigned int *d_homed = reinterpret_cast<unsigned int *>(gb + 2 * ctl_bytes + sync_bytes + (size_t)w * homed_bytes);
+            // dynamic LDS: the larger of the selection's carve and the update's carve for a 16-wave workgroup
+            size_t upd16 = 0;
+            for (int i = 0; i < n; ++i)
+                if (geo[i].wide == r.wide) {
+                    const size_t no = (size_t)jobs[i].n_out, cellb = geo[i].wide ? 8 : 4;
+                    upd16 = std::max(upd16, align_up((size_t)(SEL_THREADS / WAVE) * 4 * 3 * (size_t)geo[i].Kpad * 4 + 2 * no * cellb + no * 6, 16));
+                }
+            const size_t lds = std::max(sel_lds[w], upd16);
+            if (lds > 150 * 1024) throw std::runtime_error("greedy kernel needs more than 150 KiB of LDS (n_out too large)");
+            hipStream_t gs = im.lanes[w];
+            if (!r.wide) {
+                HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_greedy<uint32_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL(k_greedy<uint32_t>, dim3(im.n_cus), dim3(SEL_THREADS), lds, gs, d_desc + r.first, r.count, d_ctl, d_sync + r.first, d_homed, im.max_chunks);
+            } else {
+                HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_greedy<uint64_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL(k_greedy<uint64_t>, dim3(im.n_cus), dim3(SEL_THREADS), lds, gs, d_desc + r.first, r.count, d_ctl, d_sync + r.first, d_homed, im.max_chunks);
+            }
+            HIP_CHECK(hipGetLastError());
+        }
+        for (int w = 0; w < 2; ++w)
+            if (ranges[w].count) HIP_CHECK(hipStreamSynchronize(im.lanes[w]));
+        GreedyCtl h_ctl[2];
+        for (int w = 0; w < 2; ++w) {
+            if (ranges[w].count == 0) continue;
+            HIP_CHECK(hipMemcpy(&h_ctl[w], gb + (size_t)w * ctl_bytes, sizeof(GreedyCtl), hipMemcpyDeviceToHost));
+            im.timings.greedy_launches += 1;
+            im.timings.wg_ticks_select += (double)h_ctl[w].t_select;
+            im.timings.wg_ticks_update += (double)h_ctl[w].t_update;
+            im.timings.wg_ticks_idle += (double)h_ctl[w].t_idle;
+            im.timings.wg_ticks_total += (double)h_ctl[w].t_total;
+            im.timings.tasks_select += (double)h_ctl[w].n_select;
+            im.timings.tasks_update += (double)h_ctl[w].n_update;
+            im.timings.polls += (double)h_ctl[w].n_polls;
+            im.timings.workgroups += (double)h_ctl[w].n_wgs;
+            if (verbose) {
+                std::string homes;
+                for (int xq = 0; xq < GREEDY_XCDS; ++xq) homes += " " + std::to_string(h_ctl[w].xcd[xq].n_homed);
+                std::fprintf(stderr, "[da4ml_hip] k_greedy: %llu workgroups, tasks select %llu update %llu, polls %llu; workgroup time select %.1f%% update %.1f%% idle %.1f%%; chains per XCD:%s\n",
+                             h_ctl[w].n_wgs, h_ctl[w].n_select, h_ctl[w].n_update, h_ctl[w].n_polls, 100.0 * h_ctl[w].t_select / std::max<double>(1, h_ctl[w].t_total),
+                             100.0 * h_ctl[w].t_update / std::max<double>(1, h_ctl[w].t_total), 100.0 * h_ctl[w].t_idle / std::max<double>(1, h_ctl[w].t_total), homes.c_str());
+            }
+        }
+    }
     struct Group {
         int first, count, w;  // descriptor range, cell width index
         hipStream_t stream;
@@ -2346,7 +2662,7 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
     }
     im.h_done[0] = im.h_done[1] = 0;
     long long window = 0;
-    while (active > 0) {
+    while (active > 0 && !im.persistent) {
         if (launched_iters > iter_cap + 2 * poll_every) throw std::runtime_error("greedy loop did not terminate within its row capacity (internal error)");
         // sampled eager iteration (all groups; the first group's kernels are bracketed by events on its stream)
         for (size_t gi = 0; gi < groups.size(); ++gi) {
@@ -2554,6 +2870,8 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
     }
     lap("extract + download + unpack");
     im.timings.loop_ms += loop_ms;
+    if (im.persistent)  // no lockstep: the longest chain of the batch
+        for (int sidx = 0; sidx < n; ++sidx) launched_iters = std::max<long long>(launched_iters, fin[sidx].iter);
     im.timings.lockstep_iters += launched_iters;
     im.timings.chains += n;
     im.timings.arena_bytes = std::max(im.timings.arena_bytes, (double)arena_bytes);

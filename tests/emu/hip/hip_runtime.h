@@ -169,6 +169,8 @@ inline void __builtin_amdgcn_s_waitcnt(int) {}
 inline void __builtin_amdgcn_s_sleep(int) {}
 inline void __builtin_amdgcn_sched_barrier(int) {}  // instruction-scheduling fence: no meaning on the host
 inline void __builtin_amdgcn_s_setprio(int) {}
+inline unsigned __builtin_amdgcn_s_getreg(int) { return 0u; }  // HW_REG_XCC_ID: one emulated XCD
+#define __builtin_amdgcn_fence(order, scope) ((void)0)         // blocks run one after the other: every store is visible
 inline void __syncthreads() { hipemu::block_barrier(); }
 inline void __threadfence() {}
 inline void __threadfence_block() {}
@@ -234,6 +236,10 @@ inline hipError_t hipGetLastError() { return hipSuccess; }
 inline hipError_t hipSetDevice(int) { return hipSuccess; }
 inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
 inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+struct hipDeviceProp_t {
+    int multiProcessorCount;
+};
+inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) { p->multiProcessorCount = 3; return hipSuccess; }  // three workgroups in the persistent grid
 inline hipError_t hipMemGetInfo(size_t *free_b, size_t *total_b) { *free_b = (size_t)3 << 30; *total_b = (size_t)4 << 30; return hipSuccess; }
 inline hipError_t hipMalloc(void **p, size_t n) { return posix_memalign(p, 256, n ? n : 1) == 0 ? hipSuccess : 2; }  // exact size: a sanitizer build sees overruns
 template <class T> inline hipError_t hipMalloc(T **p, size_t n) { return hipMalloc((void **)p, n); }
