@@ -155,6 +155,7 @@ __device__ __forceinline__ void load_fence() {
     asm volatile("" ::: "memory");         // the optimiser does not move memory operations across
     __builtin_amdgcn_sched_barrier(0);      // nor does the instruction scheduler move anything (e.g. a wait + v_readfirstlane of
 }                                           // the first loaded value in front of the other loads)
+__host__ __device__ __forceinline__ size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
 typedef float da_f4 __attribute__((ext_vector_type(4)));
 typedef int da_i4 __attribute__((ext_vector_type(4)));
 typedef unsigned int da_u2 __attribute__((ext_vector_type(2)));
@@ -1371,67 +1372,89 @@ __device__ __forceinline__ unsigned long long row_max_u64(unsigned long long v) 
     return v;
 }
 
-// update_body: the partner rows [block_y * NWV * QN + ..., stride grid_y * NWV * QN) of chain `gq`'s current step, by a
-// workgroup of NWV wavefronts.  k_iter_update (256-thread blocks, grid = chains x blocks) and the persistent k_greedy (1024-thread
-// workgroups, one "chunk" of a step per call) both run it.
-template <class Cell, int NWV>
-__device__ __forceinline__ void update_body(ChainDev *gq, bool in_range, int block_y, int grid_y) {
-    constexpr int NTHR = NWV * WAVE;
+// ---- one update step of a chain, as the wave-uniform values its workers need (scalar registers)
+template <class Cell> struct UpdStep {
+    Ctx c;
+    int done, n_partners, m, n_in;
+    uint32_t A, B, Nw;
+    const DA_GLOBAL int *mcol;
+    const DA_GLOBAL Cell *mA, *mB;
+    const DA_GLOBAL uint16_t *cmap;
+    const DA_GLOBAL typename RowFmt<Cell>::Entry *rl;
+    const DA_GLOBAL unsigned long long *plist;
+};
+// ONE round trip: every descriptor field an update worker needs, pinned before the first branch (pin_sgpr)
+template <class Cell> __device__ __forceinline__ UpdStep<Cell> load_upd_step(ChainDev *gq) {
+    using Entry = typename RowFmt<Cell>::Entry;
+    UpdStep<Cell> u;
+    int iter = gq->iter;
+    u.done = gq->done, u.n_partners = gq->n_partners, u.m = gq->m, u.n_in = gq->n_in;
+    u.A = gq->A, u.B = gq->B, u.Nw = gq->Nw;
+    u.c = make_ctx_raw(gq, 2 * iter - 1);
+    u.mcol = (const DA_GLOBAL int *)gq->mcol;
+    u.mA = (const DA_GLOBAL Cell *)gq->mA, u.mB = (const DA_GLOBAL Cell *)gq->mB;
+    u.cmap = (const DA_GLOBAL uint16_t *)gq->cmap;
+    u.rl = (const DA_GLOBAL Entry *)gq->rlist;
+    u.plist = (const DA_GLOBAL unsigned long long *)gq->plist;
+    pin_sgpr(u.done, u.n_partners, iter, u.m, u.n_in, u.A, u.B, u.Nw, u.mcol, u.mA, u.mB, u.cmap, u.rl, u.plist);
+    pin_sgpr(u.c.n_out, u.c.n_bits, u.c.K, u.c.Kpad, u.c.method, u.c.gs_log2, u.c.pb_log2, u.c.cmask, u.c.windows, u.c.hkey, u.c.hrank, u.c.hblk, u.c.ub, u.c.gdirty, u.c.rows);
+    u.c.tomb = KEY_TOMB - (unsigned long long)((2 * iter - 1) & 3);
+    ctx_finish(u.c);
+    return u;
+}
+// LDS of an update worker: the hand-off of the selection (consumed digits of A and B [n_out each], the substituted columns
+// [n_out], column -> 1 + index of the substituted column [n_out]) -- shared by the waves that copied it together -- and ONE
+// wave's per-partner counters [QN][3][Kpad]
+template <class Cell> struct UpdLds {
+    Cell *mA, *mB;
+    int *col;
+    uint16_t *cmap;
+    uint32_t *cnt;
+    static __device__ __forceinline__ size_t table_bytes(int n_out) { return (size_t)n_out * (2 * sizeof(Cell) + 4 + 2); }
+    static __device__ __forceinline__ size_t wave_bytes(int Kpad) { return (size_t)QN * 3 * Kpad * 4; }
+    __device__ __forceinline__ void carve(unsigned char *tables, unsigned char *counters, int n_out) {
+        mA = reinterpret_cast<Cell *>(tables);
+        mB = mA + n_out;
+        col = reinterpret_cast<int *>(mB + n_out);
+        cmap = reinterpret_cast<uint16_t *>(col + n_out);
+        cnt = reinterpret_cast<uint32_t *>(counters);
+    }
+};
+// the hand-off of the selection into LDS by `nthr` threads (t = this thread's index among them): one pass; the caller makes
+// it visible (block barrier, or lds_fence() when one wave copies for itself)
+template <class Cell> __device__ __forceinline__ void copy_handoff(const UpdStep<Cell> &u, const UpdLds<Cell> &s, int t, int nthr) {
+    for (int j = t; j < u.c.n_out; j += nthr) s.cmap[j] = u.cmap[j];
+    for (int j = t; j < u.m; j += nthr) {
+        s.col[j] = u.mcol[j];
+        s.mA[j] = u.mA[j];
+        s.mB[j] = u.mB[j];
+    }
+}
+
+// update_partners: ONE WAVEFRONT works through the partner rows first + q, first + stride + q, ... < limit of the step (q = its
+// four 16-lane groups); no block-level synchronisation inside.  `ref_next` = the (pre-fetched) reference of this group's first
+// partner, `rnew` the record of the new row.
+template <class Cell>
+__device__ __forceinline__ void update_partners(ChainDev *g, const UpdStep<Cell> &u, const UpdLds<Cell> &s, int first, int stride, int limit, unsigned long long ref_next,
+                                                const RowInfo &rnew, unsigned int &found, unsigned int &inserts) {
     using F = RowFmt<Cell>;
     using Entry = typename F::Entry;
     constexpr int QCW = sizeof(Cell) == 4 ? 2 : 4;  // count words per lane: narrow layout Kpad / 2 <= 24 words, wide <= 60
-    // Grid (chains padded to a multiple of 8, blocks per chain): the chain index is the FAST grid dimension.  Workgroups go to
-    // the XCDs round-robin by their linear id, so all blocks of chain c -- and block c of k_iter_select, which has the same
-    // linear id modulo 8 -- run on XCD c mod 8: the table lines, bounds and lists of a chain stay in ONE of the eight
-    // non-coherent L2s instead of being spread over all of them.
-    // ---- ONE scalar round trip: every descriptor field the block needs, pinned before the first branch (pin_sgpr)
-    int done = gq->done, n_partners = gq->n_partners, iter = gq->iter, m = gq->m, n_in = gq->n_in;
-    uint32_t A = gq->A, B = gq->B, Nw = gq->Nw;
-    Ctx c = make_ctx_raw(gq, 2 * iter - 1);
-    const DA_GLOBAL int *mcol = (const DA_GLOBAL int *)gq->mcol;
-    const DA_GLOBAL Cell *mA = (const DA_GLOBAL Cell *)gq->mA, *mB = (const DA_GLOBAL Cell *)gq->mB;
-    const DA_GLOBAL uint16_t *cmap = (const DA_GLOBAL uint16_t *)gq->cmap;
-    const DA_GLOBAL Entry *rl = (const DA_GLOBAL Entry *)gq->rlist;
-    const DA_GLOBAL unsigned long long *plist = (const DA_GLOBAL unsigned long long *)gq->plist;
-    pin_sgpr(done, n_partners, iter, m, n_in, A, B, Nw, grid_y, mcol, mA, mB, cmap, rl, plist);
-    pin_sgpr(c.n_out, c.n_bits, c.K, c.Kpad, c.method, c.gs_log2, c.pb_log2, c.cmask, c.windows, c.hkey, c.hrank, c.hblk, c.ub, c.gdirty, c.rows);
-    ctx_finish(c);
-    if (!in_range || done) return;
-    // the grid is sized for the partner counts of the first steps of a chain (thousands); later most blocks have nothing
-    // to do and leave before the hand-off is copied
-    if (block_y * (NWV * QN) >= n_partners) return;
-    ChainDev *g = gq;
-    const int nb = c.n_bits, Kpad = c.Kpad, n_out = c.n_out, K = c.K;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // LDS: consumed digits of A [n_out] and B [n_out] | per-wave, per-partner counters [NWV][QN][3][Kpad] | the
-    // substituted columns [n_out] | column -> 1 + index of the substituted column, 0 = not substituted [n_out]
-    Cell *s_mA = reinterpret_cast<Cell *>(smem);
-    Cell *s_mB = s_mA + n_out;
-    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_mB + n_out);
-    int *s_col = reinterpret_cast<int *>(s_cnt + (size_t)NWV * QN * 3 * Kpad);
-    uint16_t *s_cmap = reinterpret_cast<uint16_t *>(s_col + n_out);
-    const int tid = threadIdx.x, lane = lane_id(), wid = wave_id();
+    const Ctx &c = u.c;
+    const uint32_t A = u.A, B = u.B, Nw = u.Nw;
+    const int m = u.m, n_in = u.n_in;
+    const DA_GLOBAL Entry *rl = u.rl;
+    const DA_GLOBAL unsigned long long *plist = u.plist;
+    Cell *s_mA = s.mA, *s_mB = s.mB;
+    int *s_col = s.col;
+    uint16_t *s_cmap = s.cmap;
+    uint32_t *s_cnt = s.cnt;
+    const int nb = c.n_bits, Kpad = c.Kpad, K = c.K;
+    const int lane = lane_id();
     const int q = lane >> 4, l = lane & (QG - 1), qsh = q * QG;
-    const int total_waves = grid_y * NWV, gw = block_y * NWV + wid;
-    // ---- ONE vector round trip: the group's first partner reference and the new row's record leave together with the
-    // hand-off of k_iter_select (they used to wait behind the hand-off barrier: two more dependent round trips)
-    unsigned long long ref_next = gw * QN + q < n_partners ? plist[gw * QN + q] : 0ull;
-    const RowInfo rnew = load_row(c.rows, Nw);
-    __shared__ unsigned int s_stat[2];
-    if (tid < 2) s_stat[tid] = 0;
-    {  // the hand-off of k_iter_select into LDS: one pass, one barrier (the column map arrives ready-made)
-        for (int j = tid; j < n_out; j += NTHR) s_cmap[j] = cmap[j];
-        for (int j = tid; j < m; j += NTHR) {
-            s_col[j] = mcol[j];
-            s_mA[j] = mA[j];
-            s_mB[j] = mB[j];
-        }
-    }
-    __syncthreads();
     const bool same = A == B;
-    uint32_t *dA = s_cnt + ((size_t)wid * QN + q) * 3 * Kpad, *dB = dA + Kpad, *cN = dB + Kpad;  // this group's counters
+    uint32_t *dA = s_cnt + (size_t)q * 3 * Kpad, *dB = dA + Kpad, *cN = dB + Kpad;  // this group's counters
     const int KW = Kpad / 2;  // 32-bit words of counts per block (two u16 counts each)
-    unsigned int found = 0, inserts = 0;
     UPD_TIMER_DECL
     // partner p of the list: pass p / (QN total_waves), wave (p / QN) mod total_waves, group p mod QN -- all groups of all
     // waves are busy except in the last pass
@@ -1439,12 +1462,12 @@ __device__ __forceinline__ void update_body(ChainDev *gq, bool in_range, int blo
 #define DA_UPD_CH 4  // measured on MI355X (C3 batch 64): 1 -> 52.7, 2 -> 53.8, 4 -> 54.5 solves/s
 #endif
     constexpr int CH = DA_UPD_CH;  // list chunks (16 entries each) fetched together; longer lists continue in the loop below
-    for (int base = gw * QN; base < n_partners; base += total_waves * QN) {
+    for (int base = first; base < limit; base += stride) {
         const int idx = base + q;
-        const bool valid = idx < n_partners;
+        const bool valid = idx < limit;
         // ---- round trip 1: the group's partner reference (the next pass's one is fetched now: off the critical path there)
         const unsigned long long ref = ref_next;
-        ref_next = idx + total_waves * QN < n_partners ? plist[idx + total_waves * QN] : 0ull;
+        ref_next = idx + stride < limit ? plist[idx + stride] : 0ull;
         const uint32_t pr = ref_row(ref), off = ref_off(ref);
         const bool dense = valid && (int)pr < n_in;  // dense input row: entry j is column j -- fetch the substituted columns only
         const int cnt = !valid ? 0 : dense ? m : (int)ref_len(ref);
@@ -1546,7 +1569,7 @@ __device__ __forceinline__ void update_body(ChainDev *gq, bool in_range, int blo
                 const uint32_t rpr = (uint32_t)__builtin_amdgcn_readlane((int)pr, qq * QG);
                 const int rsA = __builtin_amdgcn_readlane(sA, qq * QG), rsB = __builtin_amdgcn_readlane(sB, qq * QG);
                 const int rnewb = __builtin_amdgcn_readlane((int)gnew, qq * QG);
-                const uint32_t *rdA = s_cnt + ((size_t)wid * QN + qq) * 3 * Kpad, *rdB = rdA + Kpad, *rcN = rdB + Kpad;
+                const uint32_t *rdA = s_cnt + (size_t)qq * 3 * Kpad, *rdB = rdA + Kpad, *rcN = rdB + Kpad;
                 if (rsA == SLOT_SLOW) {
                     const uint32_t lo = min(A, rpr), hi = max(A, rpr);
                     const int slot = table_find_from(c, pack_pair(lo, hi), hash_pair(lo, hi), 1);
@@ -1573,6 +1596,37 @@ __device__ __forceinline__ void update_body(ChainDev *gq, bool in_range, int blo
         lds_fence();  // the next pass overwrites the counters
     }
     UPD_TIMER_FLUSH
+}
+
+// update_body: the partner rows [block_y * NWV * QN + ..., stride grid_y * NWV * QN) of chain `gq`'s current step, by a
+// workgroup of NWV wavefronts (k_iter_update: 256-thread blocks, grid = chains x blocks per chain).
+template <class Cell, int NWV>
+__device__ __forceinline__ void update_body(ChainDev *gq, bool in_range, int block_y, int grid_y) {
+    constexpr int NTHR = NWV * WAVE;
+    // Grid (chains padded to a multiple of 8, blocks per chain): the chain index is the FAST grid dimension.  Workgroups go to
+    // the XCDs round-robin by their linear id, so all blocks of chain c -- and block c of k_iter_select, which has the same
+    // linear id modulo 8 -- run on XCD c mod 8: the table lines, bounds and lists of a chain stay in ONE of the eight
+    // non-coherent L2s instead of being spread over all of them.
+    const UpdStep<Cell> u = load_upd_step<Cell>(gq);
+    if (!in_range || u.done) return;
+    // the grid is sized for the partner counts of the first steps of a chain (thousands); later most blocks have nothing
+    // to do and leave before the hand-off is copied
+    if (block_y * (NWV * QN) >= u.n_partners) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = lane_id(), wid = wave_id();
+    UpdLds<Cell> s;
+    s.carve(smem, smem + align16(UpdLds<Cell>::table_bytes(u.c.n_out)) + (size_t)wid * UpdLds<Cell>::wave_bytes(u.c.Kpad), u.c.n_out);
+    const int total_waves = grid_y * NWV, gw = block_y * NWV + wid;
+    // ---- ONE vector round trip: the group's first partner reference and the new row's record leave together with the
+    // hand-off of k_iter_select (they used to wait behind the hand-off barrier: two more dependent round trips)
+    const unsigned long long ref0 = gw * QN + (lane >> 4) < u.n_partners ? u.plist[gw * QN + (lane >> 4)] : 0ull;
+    const RowInfo rnew = load_row(u.c.rows, u.Nw);
+    __shared__ unsigned int s_stat[2];
+    if (tid < 2) s_stat[tid] = 0;
+    copy_handoff<Cell>(u, s, tid, NTHR);  // one pass, one barrier (the column map arrives ready-made)
+    __syncthreads();
+    unsigned int found = 0, inserts = 0;
+    update_partners<Cell>(gq, u, s, gw * QN, total_waves * QN, u.n_partners, ref0, rnew, found, inserts);
     // statistics: summed per block in LDS, then ONE pair of device atomics per block.  (Four atomics per wave on one line
     // of the chain descriptor -- 640 per chain and launch, from all XCDs -- serialise at ~12 ns each and every launch had
     // to wait for them; the partner / cell counts are added by k_iter_select, which knows them without counting.)
@@ -1582,8 +1636,8 @@ __device__ __forceinline__ void update_body(ChainDev *gq, bool in_range, int blo
     }
     __syncthreads();
     if (tid == 0) {
-        if (s_stat[0]) atomicAdd(&g->st_found, (unsigned long long)s_stat[0]);
-        if (s_stat[1]) atomicAdd(&g->st_inserts, (unsigned long long)s_stat[1]);
+        if (s_stat[0]) atomicAdd(&gq->st_found, (unsigned long long)s_stat[0]);
+        if (s_stat[1]) atomicAdd(&gq->st_inserts, (unsigned long long)s_stat[1]);
     }
 }
 template <class Cell>
@@ -1595,26 +1649,29 @@ __global__ void __launch_bounds__(UPD_THREADS, DA_UPD_OCC) __attribute__((amdgpu
 // ------------------------------------------------------------------------------------------------ k_greedy (persistent)
 // The whole greedy loop of a batch of chains in ONE launch.  With one (select, update) kernel pair per step a 64-chain batch is
 // bound by the two kernel boundaries per step, by the host's launch rate and -- chains advance in lockstep groups -- by the
-// slowest chain of every group in every step.  Here a grid of one 1024-thread workgroup per CU stays resident and the steps of
-// a chain are tasks:
-//   * SELECT  (select_body, one workgroup): arg-max, substitution, partner rows; then the step's update is published as
-//             n chunks in the chain's `work` word (epoch:32 | next chunk:16 | chunks:16);
-//   * UPDATE  (update_body, one chunk of the partner rows per workgroup): a workgroup takes a chunk with one atomic add on the
-//             work word, and the workgroup that finishes the LAST chunk of a step goes straight on to the chain's next SELECT.
-// Nobody ever waits for anybody: an idle workgroup polls the work words of its chains, claims an unstarted chain, or leaves
-// when nothing is left -- so the loop cannot deadlock whatever part of the grid is resident (a single workgroup alone runs every
-// chain to its end: that is how the CPU emulation executes it), and chains progress independently of each other.
+// slowest chain of every group in every step.  Here a grid of one 1024-thread workgroup per CU stays resident:
+//   * an OWNER workgroup claims a chain and runs its steps to the end: selection (select_body: arg-max, substitution, partner
+//     rows), then it publishes the step's update as n chunks of partner rows in the chain's `work` word, lets its own sixteen
+//     wavefronts take chunks like everybody else, waits until all n are finished and selects again;
+//   * every wavefront of the other workgroups is an independent HELPER: it looks at the work words of the chains of its XCD,
+//     takes a chunk with one atomic add, processes its partner rows (update_partners -- wave-level, no block barrier) and
+//     counts it finished.  Sixteen helpers per CU are in sixteen different phases of their dependent memory round trips, which
+//     is what keeps a CU's memory pipeline busy (a workgroup stepping through the phases in lockstep does not).
+// The only wait in the system is the owner's wait for chunks that helpers have already taken -- helpers never wait for anybody,
+// so they always finish them; an owner without helpers (the other workgroups not resident, or on other XCDs) processes all chunks
+// itself.  There is no grid-wide barrier and no assumption about how much of the grid is resident: the CPU emulation runs the
+// workgroups one after the other and the first one finishes every chain alone.
 //
-// Visibility between workgroups.  A chain is HOMED on the XCD of the workgroup that claimed it, and only workgroups that read
-// the same HW_REG_XCC_ID ever touch it afterwards: everything a chain's tasks exchange goes through that XCD's one L2.  Hand-over
-// = every wave drains its stores (s_waitcnt vmcnt(0): acknowledged by the L2), workgroup barrier, ONE atomic on the chain's
-// sync record; take-over = the atomic that returned the task, then an agent-scope acquire (buffer_inv sc1: this CU's L1 is
-// dropped; the XCD's L2 is the point of coherence, nothing has to be written back for a reader behind the same L2), workgroup
-// barrier.  The home is established at run time from the hardware register, never from blockIdx or from an assumed dispatch
-// order; a workgroup on another XCD simply never sees the chain.  Within a task the sharing rules are those of one launch of
-// the kernel pair (tombstone tags, single writers per slot, atomics for claims / bounds).
+// Visibility between workgroups.  A chain is HOMED on the XCD of the workgroup that claimed it, and only wavefronts that read
+// the same HW_REG_XCC_ID ever touch it: everything its owner and its helpers exchange goes through that XCD's one L2.  Hand-over
+// = the wave drains its stores (s_waitcnt vmcnt(0): acknowledged by the L2) [+ block barrier for the owner], then ONE atomic on
+// the chain's sync record; take-over = the atomic / load that observed it, then an agent-scope acquire (buffer_inv sc1: this
+// CU's L1 is dropped; the XCD's L2 is the point of coherence, nothing has to be written back for a reader behind the same L2).
+// The home is established at run time from the hardware register, never from blockIdx or an assumed dispatch order; a
+// wavefront on another XCD simply never sees the chain.  Within a step the sharing rules are those of one launch of
+// k_iter_update (tombstone tags, single writers per slot, atomics for claims and bounds).
 struct GreedySync {            // per chain
-    unsigned long long work;   // epoch:32 | next chunk:16 | chunks:16 of the step being updated
+    unsigned long long work;   // next chunk:24 | chunks:24 | partner rows per chunk:16 of the step being updated
     unsigned int done_chunks;  // chunks of that step that are finished
     unsigned int pad;
 };
@@ -1629,186 +1686,302 @@ struct GreedyCtl {
     unsigned int n_finished;   // chains finished (the n_done counter of select_body)
     unsigned int pad0[30];
     GreedyXcd xcd[8];
-    // workgroup time by role (wall-clock ticks of s_memrealtime, 100 MHz) and task counts, summed over the grid at exit
-    unsigned long long t_select, t_update, t_idle, t_total, n_select, n_update, n_polls, n_wgs;
+    // wave / workgroup time by role (wall-clock ticks of s_memrealtime, 100 MHz) and task counts, summed over the grid at exit
+    unsigned long long t_select, t_own_update, t_own_wait, t_owner_total, t_helper_busy, t_helper_total, n_select, n_own_chunks, n_helper_chunks, n_polls, n_wgs;
 };
 constexpr int GREEDY_XCDS = 8;
+constexpr int WORK_NEXT_SHIFT = 40, WORK_N_SHIFT = 16;
 #define DA_DRAIN_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 // this workgroup's XCD: s_getreg_b32 hwreg(HW_REG_XCC_ID, 0, 4)  (id 20; simm16 = (size - 1) << 11 | offset << 6 | id)
 __device__ __forceinline__ int xcc_id() { return (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u); }
 template <class T> __device__ __forceinline__ T ld_agent(const T *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 template <class T> __device__ __forceinline__ void st_agent(T *p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void greedy_take_over() {  // after the atomic that handed this workgroup a task
-    if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    __syncthreads();
+
+// one chunk of a step by ONE wavefront: partner rows [k * cp, min((k + 1) * cp, n_partners)); `tables` = the hand-off in LDS
+// (already there when the owner's waves call, copied by the wave itself when a helper calls), `counters` = this wave's own
+template <class Cell> __device__ __forceinline__ void greedy_chunk(ChainDev *g, unsigned char *tables, unsigned char *counters, int k, int cp, bool copy_tables) {
+    const UpdStep<Cell> u = load_upd_step<Cell>(g);
+    UpdLds<Cell> s;
+    s.carve(tables, counters, u.c.n_out);
+    const int lane = lane_id();
+    const int first = k * cp, limit = min(first + cp, u.n_partners);
+    const unsigned long long ref0 = first + (lane >> 4) < limit ? u.plist[first + (lane >> 4)] : 0ull;
+    const RowInfo rnew = load_row(u.c.rows, u.Nw);
+    if (copy_tables) {
+        copy_handoff<Cell>(u, s, lane, WAVE);
+        lds_fence();
+    }
+    unsigned int found = 0, inserts = 0;
+    update_partners<Cell>(g, u, s, first, QN, limit, ref0, rnew, found, inserts);
+    if (lane == 0) {
+        if (found) atomicAdd(&g->st_found, (unsigned long long)found);
+        if (inserts) atomicAdd(&g->st_inserts, (unsigned long long)inserts);
+    }
 }
-__device__ __forceinline__ void greedy_hand_over() {  // before the atomic that publishes what this workgroup wrote
-    DA_DRAIN_VMEM();
-    __syncthreads();
+// (called, not inlined, from the owner's loop: the selection keeps the register allocation it has as a kernel of its own)
+template <class Cell> __device__ __attribute__((noinline)) void greedy_own_chunk(ChainDev *g, unsigned char *tables, unsigned char *counters, int k, int cp) {
+    greedy_chunk<Cell>(g, tables, counters, k, cp, false);
 }
 
-// The two task bodies are CALLED, not inlined: each keeps the register allocation it has as a kernel of its own (inlined into the
-// task loop, the scheduler's state and both bodies shared one allocation: 128 VGPRs and 53 spilled to scratch).
-template <class Cell> __device__ __attribute__((noinline)) int greedy_select(ChainDev *g, unsigned int *n_done) { return select_body<Cell, false>(g, n_done); }
-template <class Cell> __device__ __attribute__((noinline)) void greedy_update(ChainDev *g, int chunk, int n_chunks) {
-    update_body<Cell, SEL_THREADS / WAVE>(g, true, chunk, n_chunks);
-}
+struct GreedyArgs {
+    ChainDev *chains;
+    int n_chains;
+    GreedyCtl *ctl;
+    GreedySync *sync;
+    unsigned int *homed;
+    int target_chunks, lds_bytes;
+};
 
-template <class Cell>
-__global__ void __launch_bounds__(SEL_THREADS) k_greedy(ChainDev *chains, int n_chains, GreedyCtl *ctl, GreedySync *sync, unsigned int *homed, int max_chunks) {
-    constexpr int NW = SEL_THREADS / WAVE, PER_PASS = NW * QN;  // partner rows a workgroup handles per pass of update_body
-    constexpr unsigned IDLE_STEAL = 64;  // idle polls after which a workgroup claims chains beyond its XCD's share
-    __shared__ int s_task[4];
-    const int tid = threadIdx.x, lane = lane_id();
-    const int x = xcc_id();
-    unsigned int *my_homed = homed + (size_t)x * n_chains;  // entries are chain + 1 (0 = claimed, not yet written)
-    const unsigned quota = ((unsigned)n_chains + GREEDY_XCDS - 1) / GREEDY_XCDS;
-    int own = -1;     // the chain whose next SELECT this workgroup runs
-    int prefer = -1;  // the chain whose chunks it looks at first (the one it has just selected for / worked on)
-    int may_claim = -1;  // -1: not asked yet
-    unsigned idle = 0;
-    long long t_sel = 0, t_upd = 0, t_idle = 0, n_sel = 0, n_upd = 0, n_poll = 0;
+// ================= OWNER: the steps of chain `own`, then of the next unclaimed chain, ...  (one 1024-thread workgroup)
+template <class Cell> __device__ __attribute__((noinline)) void greedy_owner_loop(const GreedyArgs a, int own, int x, unsigned char *smem, int *s_own) {
+    constexpr int NW = SEL_THREADS / WAVE;
+    const int tid = threadIdx.x, lane = lane_id(), wid = wave_id();
+    GreedyCtl *ctl = a.ctl;
+    long long t_sel = 0, t_upd = 0, t_wait = 0, n_sel = 0, n_own = 0;
     const long long t_start = wall_clock64();
-    long long t_mark = t_start;
-    for (;;) {
-        int chunk = 0, nch = 0, chain = -1;
-        if (own < 0) {
-            // ---------------- look for work: a chunk of a chain of this XCD, else an unstarted chain, else leave when nothing is left
-            if (wave_id() == 0) {
-                int kind = 0;  // 0 nothing, 1 update chunk, 2 new chain, 3 leave
-                const unsigned nh = ld_agent(&ctl->xcd[x].n_homed);
-                for (unsigned base = 0; base < nh && kind == 0; base += WAVE) {
-                    const unsigned i = base + (unsigned)lane;
-                    const int c = i < nh ? (int)ld_agent(&my_homed[i]) - 1 : -1;
-                    const unsigned long long w = c >= 0 ? ld_agent(&sync[c].work) : 0ull;
-                    const bool avail = c >= 0 && (unsigned)((w >> 16) & 0xFFFFu) < (unsigned)(w & 0xFFFFu);
-                    unsigned long long mask = __ballot(avail);
-                    const unsigned long long pm = __ballot(avail && c == prefer);
-                    while (mask && kind == 0) {
-                        const int l = pm & mask ? __ffsll((long long)(pm & mask)) - 1 : __ffsll((long long)mask) - 1;
-                        mask &= ~(1ull << l);
-                        const int cc = __builtin_amdgcn_readlane(c, l);
-                        unsigned long long old = 0;
-                        if (lane == 0) old = atomicAdd(&sync[cc].work, 1ull << 16);
-                        const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)old);
-                        const int k = (int)(lo >> 16), n = (int)(lo & 0xFFFFu);
-                        if (k < n) {
-                            kind = 1;
-                            chain = cc;
-                            chunk = k;
-                            nch = n;
-                        }
-                    }
-                }
-                if (kind == 0) {
-                    int got = -1, leave = 0;
-                    if (lane == 0) {
-                        const unsigned nc = ld_agent(&ctl->next_chain);
-                        if (nc < (unsigned)n_chains) {
-                            if (may_claim < 0) may_claim = atomicAdd(&ctl->xcd[x].tickets, 1u) < quota ? 1 : 0;
-                            if (may_claim || idle >= IDLE_STEAL) {
-                                const unsigned c = atomicAdd(&ctl->next_chain, 1u);
-                                if (c < (unsigned)n_chains) {
-                                    const unsigned slot = atomicAdd(&ctl->xcd[x].n_homed, 1u);
-                                    st_agent(&my_homed[slot], c + 1u);
-                                    got = (int)c;
-                                }
-                            }
-                        } else if (ld_agent(&ctl->xcd[x].n_fin) >= ld_agent(&ctl->xcd[x].n_homed))
-                            leave = 1;  // every chain is claimed and the ones homed here are finished
-                    }
-                    got = __builtin_amdgcn_readfirstlane(got);
-                    leave = __builtin_amdgcn_readfirstlane(leave);
-                    may_claim = __builtin_amdgcn_readfirstlane(may_claim);
-                    if (got >= 0) {
-                        kind = 2;
-                        chain = got;
-                    } else if (leave)
-                        kind = 3;
-                }
-                if (lane == 0) {
-                    s_task[0] = kind;
-                    s_task[1] = chain;
-                    s_task[2] = chunk;
-                    s_task[3] = nch;
-                }
-            }
-            __syncthreads();
-            // (readfirstlane: the values are workgroup-uniform, and the bodies keep what they derive from them in scalar registers)
-            const int kind = __builtin_amdgcn_readfirstlane(s_task[0]);
-            chain = __builtin_amdgcn_readfirstlane(s_task[1]);
-            chunk = __builtin_amdgcn_readfirstlane(s_task[2]);
-            nch = __builtin_amdgcn_readfirstlane(s_task[3]);
-            __syncthreads();  // s_task is rewritten below / in the next round
-            ++n_poll;
-            if (kind == 3) break;
-            if (kind == 0) {
-                ++idle;
-                __builtin_amdgcn_s_sleep(8);
-                continue;
-            }
-            idle = 0;
-            {
-                const long long now = wall_clock64();
-                t_idle += now - t_mark;
-                t_mark = now;
-            }
-            if (kind == 2)
-                own = chain;
-            else {
-                // ---------------- UPDATE: chunk `chunk` of `nch` of the chain's current step
-                greedy_take_over();
-                greedy_update<Cell>(&chains[chain], chunk, nch);
-                greedy_hand_over();
-                if (tid == 0) s_task[0] = atomicAdd(&sync[chain].done_chunks, 1u) + 1u == (unsigned)nch ? chain : -1;  // last chunk: this workgroup selects next
-                __syncthreads();
-                own = __builtin_amdgcn_readfirstlane(s_task[0]);
-                __syncthreads();
-                prefer = chain;
-                ++n_upd;
-                const long long now = wall_clock64();
-                t_upd += now - t_mark;
-                t_mark = now;
-                if (own < 0) continue;
-            }
-        }
-        // ---------------- SELECT for chain `own`, then publish the step's update
-        greedy_take_over();
-        ChainDev *g = &chains[own];
-        const int fin = greedy_select<Cell>(g, &ctl->n_finished);
+    while (own >= 0) {
+        ChainDev *g = &a.chains[own];
+        GreedySync *sy = &a.sync[own];
+        const long long t0 = wall_clock64();
+        if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // what the helpers of the last step wrote
+        __syncthreads();
+        const int fin = select_body<Cell, false>(g, &ctl->n_finished);
         ++n_sel;
         if (fin) {
             __syncthreads();
-            if (tid == 0) atomicAdd(&ctl->xcd[x].n_fin, 1u);
-            own = -1;
-        } else {
-            greedy_hand_over();
-            const int np = __builtin_amdgcn_readfirstlane(ld_agent(&g->n_partners));
-            const int n = np <= 0 ? 0 : min(max_chunks, (np + PER_PASS - 1) / PER_PASS);
-            if (n > 0) {  // (no partner rows: nothing to update, the next selection follows at once)
-                if (tid == 0) {
-                    st_agent(&sync[own].done_chunks, 0u);
-                    DA_DRAIN_VMEM();
-                    st_agent(&sync[own].work, ((unsigned long long)(unsigned)ld_agent(&g->iter) << 32) | (unsigned)n);
+            if (tid == 0) {  // the next unclaimed chain, whatever its XCD share
+                atomicAdd(&ctl->xcd[x].n_fin, 1u);
+                int got = -1;
+                if (ld_agent(&ctl->next_chain) < (unsigned)a.n_chains) {
+                    const unsigned c = atomicAdd(&ctl->next_chain, 1u);
+                    if (c < (unsigned)a.n_chains) {
+                        const unsigned slot = atomicAdd(&ctl->xcd[x].n_homed, 1u);
+                        st_agent(&a.homed[(size_t)x * a.n_chains + slot], c + 1u);
+                        got = (int)c;
+                    }
                 }
-                prefer = own;
-                own = -1;
+                *s_own = got;
+            }
+            __syncthreads();
+            own = __builtin_amdgcn_readfirstlane(*s_own);
+            __syncthreads();
+            t_sel += wall_clock64() - t0;
+            continue;
+        }
+        DA_DRAIN_VMEM();
+        __syncthreads();
+        const int np = __builtin_amdgcn_readfirstlane(ld_agent(&g->n_partners));
+        if (np <= 0) {  // no partner rows: nothing to update, the next selection follows at once
+            t_sel += wall_clock64() - t0;
+            continue;
+        }
+        // chunks of the step: about target_chunks of them, whole passes of a wavefront (QN partner rows).  The first n_mine are
+        // the owner's (one per wavefront, no atomics), the others are handed out through the work word
+        int cp = (np + a.target_chunks - 1) / a.target_chunks;
+        cp = min(65532, (cp + QN - 1) / QN * QN);
+        const int n = (np + cp - 1) / cp, n_mine = min(n, NW);
+        if (tid == 0) {
+            st_agent(&sy->done_chunks, 0u);
+            DA_DRAIN_VMEM();
+            st_agent(&sy->work, ((unsigned long long)(unsigned)n_mine << WORK_NEXT_SHIFT) | ((unsigned long long)(unsigned)n << WORK_N_SHIFT) | (unsigned)cp);
+        }
+        const long long t1 = wall_clock64();
+        t_sel += t1 - t0;
+        {
+            const UpdStep<Cell> u = load_upd_step<Cell>(g);
+            UpdLds<Cell> s;
+            s.carve(smem, smem, u.c.n_out);
+            copy_handoff<Cell>(u, s, tid, SEL_THREADS);  // once for the sixteen waves
+            __syncthreads();
+            unsigned char *counters = smem + align16(UpdLds<Cell>::table_bytes(u.c.n_out)) + (size_t)wid * UpdLds<Cell>::wave_bytes(u.c.Kpad);
+            int k = wid;
+            while (k < n) {
+                greedy_own_chunk<Cell>(g, smem, counters, k, cp);
+                DA_DRAIN_VMEM();
+                if (lane == 0) atomicAdd(&sy->done_chunks, 1u);
+                ++n_own;
+                unsigned long long old = ~0ull;  // more, if the helpers have left any
+                if (lane == 0 && n > n_mine) old = atomicAdd(&sy->work, 1ull << WORK_NEXT_SHIFT);
+                const unsigned nk = (unsigned)(old >> WORK_NEXT_SHIFT);
+                k = __builtin_amdgcn_readfirstlane((int)min(nk, 0x7FFFFFFFu));
             }
         }
-        const long long now = wall_clock64();
-        t_sel += now - t_mark;
-        t_mark = now;
+        __syncthreads();
+        const long long t2 = wall_clock64();
+        t_upd += t2 - t1;
+        if (tid == 0)
+            while (ld_agent(&sy->done_chunks) < (unsigned)n) __builtin_amdgcn_s_sleep(1);  // chunks that helpers took: they never wait, so they finish
+        __syncthreads();
+        t_wait += wall_clock64() - t2;
     }
     if (tid == 0) {
         atomicAdd(&ctl->t_select, (unsigned long long)t_sel);
-        atomicAdd(&ctl->t_update, (unsigned long long)t_upd);
-        atomicAdd(&ctl->t_idle, (unsigned long long)t_idle);
-        atomicAdd(&ctl->t_total, (unsigned long long)(wall_clock64() - t_start));
+        atomicAdd(&ctl->t_own_update, (unsigned long long)t_upd);
+        atomicAdd(&ctl->t_own_wait, (unsigned long long)t_wait);
+        atomicAdd(&ctl->t_owner_total, (unsigned long long)(wall_clock64() - t_start));
         atomicAdd(&ctl->n_select, (unsigned long long)n_sel);
-        atomicAdd(&ctl->n_update, (unsigned long long)n_upd);
-        atomicAdd(&ctl->n_polls, (unsigned long long)n_poll);
-        atomicAdd(&ctl->n_wgs, 1ull);
     }
+    if (lane == 0 && n_own) atomicAdd(&ctl->n_own_chunks, (unsigned long long)n_own);
+}
+
+// ================= HELPERS: a workgroup of sixteen independent wavefronts.  Wave 0 is the SCOUT: it watches the work words
+// of the chains homed on this XCD, takes as many chunks as it has idle waves with ONE atomic add, and hands them out through a
+// mailbox in LDS; the other fifteen wait on their mailbox word (LDS polling costs the memory system nothing -- sixteen waves
+// per CU polling the work words themselves slowed the selection down 2.4 x).
+constexpr unsigned long long MAIL_EXIT = ~0ull;
+template <class Cell> __device__ __attribute__((noinline)) void greedy_helper_loop(const GreedyArgs a, int x, unsigned char *smem, unsigned long long *s_mail) {
+    constexpr int NW = SEL_THREADS / WAVE;
+    const int lane = lane_id(), wid = wave_id();
+    GreedyCtl *ctl = a.ctl;
+    unsigned int *my_homed = a.homed + (size_t)x * a.n_chains;  // entries are chain + 1 (0 = claimed, not yet written)
+    // a helper's LDS: a private copy of a step's hand-off + its counters (workgroups whose LDS does not hold fifteen of them --
+    // very wide matrices -- run fewer helpers)
+    size_t per_wave = 0;
+    {
+        int mo = 0, mk = 0;
+        for (int i = lane; i < a.n_chains; i += WAVE) {
+            mo = max(mo, a.chains[i].n_out);
+            mk = max(mk, a.chains[i].Kpad);
+        }
+        mo = (int)wave_max_u32((uint32_t)mo);
+        mk = (int)wave_max_u32((uint32_t)mk);
+        per_wave = align16(UpdLds<Cell>::table_bytes(mo)) + align16(UpdLds<Cell>::wave_bytes(mk));
+    }
+    const int n_workers = min(NW - 1, (int)((size_t)a.lds_bytes / per_wave));  // waves 1 .. n_workers
+    long long t_busy = 0, n_chunks = 0, n_polls = 0;
+    const long long th0 = wall_clock64();
+    if (wid == 0) {
+        // ---------------- the scout
+        unsigned nh = 0;
+        int c_mine = -1;  // lane i: the i-th chain homed on this XCD (the first 64; more are read from memory)
+        const int rot = (int)(blockIdx.x * 7u) & (WAVE - 1);
+        for (;;) {
+            // idle workers
+            const unsigned long long mail = lane >= 1 && lane <= n_workers ? __hip_atomic_load(&s_mail[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 1ull;
+            unsigned long long idle = __ballot(mail == 0ull);
+            if (idle == 0ull) {
+                __builtin_amdgcn_s_sleep(4);
+                continue;
+            }
+            const unsigned nh_now = ld_agent(&ctl->xcd[x].n_homed);
+            if (nh_now != nh || (c_mine < 0 && (unsigned)lane < nh_now)) {
+                nh = nh_now;
+                c_mine = (unsigned)lane < nh ? (int)ld_agent(&my_homed[lane]) - 1 : -1;
+            }
+            bool any = false;
+            for (unsigned base = 0; base < nh && idle; base += WAVE) {
+                const unsigned i = base + (unsigned)lane;
+                const int c = base == 0 ? c_mine : (i < nh ? (int)ld_agent(&my_homed[i]) - 1 : -1);
+                const unsigned long long w = c >= 0 ? ld_agent(&a.sync[c].work) : 0ull;
+                const unsigned nx = (unsigned)(w >> WORK_NEXT_SHIFT), nn = (unsigned)(w >> WORK_N_SHIFT) & 0xFFFFFFu;
+                const int rem = c >= 0 && nx < nn ? (int)(nn - nx) : 0;
+                unsigned long long mask = __ballot(rem > 0);
+                while (mask && idle) {
+                    // start at a workgroup-specific lane so that the scouts of an XCD spread over its chains
+                    const unsigned long long hi = mask & ~((1ull << rot) - 1ull);
+                    const int l = __ffsll((long long)(hi ? hi : mask)) - 1;
+                    mask &= ~(1ull << l);
+                    const int cand = __builtin_amdgcn_readlane(c, l);
+                    const int want = min(__builtin_amdgcn_readlane(rem, l), __popcll(idle));
+                    unsigned long long old = 0;
+                    if (lane == 0) old = atomicAdd(&a.sync[cand].work, (unsigned long long)(unsigned)want << WORK_NEXT_SHIFT);
+                    const unsigned ohi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(old >> 32)), olo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)old);
+                    const unsigned long long o = ((unsigned long long)ohi << 32) | olo;
+                    const int k0 = (int)(unsigned)(o >> WORK_NEXT_SHIFT), nn2 = (int)((unsigned)(o >> WORK_N_SHIFT) & 0xFFFFFFu), cp = (int)(olo & 0xFFFFu);
+                    const int got = max(0, min(want, nn2 - k0));
+                    // the j-th idle worker gets chunk k0 + j
+                    for (int j = 0; j < got; ++j) {
+                        const int wv = __ffsll((long long)idle) - 1;
+                        idle &= idle - 1;
+                        if (lane == 0)
+                            __hip_atomic_store(&s_mail[wv], ((unsigned long long)(unsigned)(cand + 1) << 40) | ((unsigned long long)(unsigned)(k0 + j) << 16) | (unsigned)cp, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                    any |= got > 0;
+                }
+            }
+            ++n_polls;
+            if (!any) {
+                // nothing to hand out: leave when every chain is claimed and the ones homed here are finished
+                int leave = 0;
+                if (lane == 0) leave = ld_agent(&ctl->next_chain) >= (unsigned)a.n_chains && ld_agent(&ctl->xcd[x].n_fin) >= ld_agent(&ctl->xcd[x].n_homed);
+                if (__builtin_amdgcn_readfirstlane(leave)) break;
+                __builtin_amdgcn_s_sleep(16);
+            }
+        }
+        // dismiss the workers (each reads its word once it is idle)
+        for (int wv = 1; wv <= n_workers; ++wv) {
+            if (lane == 0) {
+                while (__hip_atomic_load(&s_mail[wv], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0ull) __builtin_amdgcn_s_sleep(2);
+                __hip_atomic_store(&s_mail[wv], MAIL_EXIT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+    } else if (wid <= n_workers) {
+        // ---------------- a worker
+        unsigned char *tables = smem + (size_t)(wid - 1) * per_wave;
+        for (;;) {
+            unsigned long long mail = 0;
+            if (lane == 0)
+                while ((mail = __hip_atomic_load(&s_mail[wid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) == 0ull) __builtin_amdgcn_s_sleep(2);
+            const unsigned mhi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(mail >> 32)), mlo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)mail);
+            const unsigned long long mw = ((unsigned long long)mhi << 32) | mlo;
+            if (mw == MAIL_EXIT) break;
+            const long long tb = wall_clock64();
+            const int cc = (int)(unsigned)(mw >> 40) - 1, k = (int)((unsigned)(mw >> 16) & 0xFFFFFFu), cp = (int)(mlo & 0xFFFFu);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            ChainDev *g = &a.chains[cc];
+            const int no = __builtin_amdgcn_readfirstlane(g->n_out);
+            greedy_chunk<Cell>(g, tables, tables + align16(UpdLds<Cell>::table_bytes(no)), k, cp, true);
+            DA_DRAIN_VMEM();
+            if (lane == 0) {
+                atomicAdd(&a.sync[cc].done_chunks, 1u);
+                __hip_atomic_store(&s_mail[wid], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            ++n_chunks;
+            t_busy += wall_clock64() - tb;
+        }
+    }
+    if (lane == 0 && wid <= n_workers) {
+        if (wid) {
+            atomicAdd(&ctl->t_helper_busy, (unsigned long long)t_busy);
+            atomicAdd(&ctl->t_helper_total, (unsigned long long)(wall_clock64() - th0));
+            atomicAdd(&ctl->n_helper_chunks, (unsigned long long)n_chunks);
+        } else {
+            atomicAdd(&ctl->n_polls, (unsigned long long)n_polls);
+            atomicAdd(&ctl->n_wgs, 1ull);
+        }
+    }
+}
+
+template <class Cell>
+__global__ void __launch_bounds__(SEL_THREADS) k_greedy(ChainDev *chains, int n_chains, GreedyCtl *ctl, GreedySync *sync, unsigned int *homed, int target_chunks, int lds_bytes) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ int s_own;
+    __shared__ unsigned long long s_mail[SEL_THREADS / WAVE];
+    const int tid = threadIdx.x;
+    const int x = xcc_id();
+    const GreedyArgs a{chains, n_chains, ctl, sync, homed, target_chunks, lds_bytes};
+    // a first chain for this workgroup, within its XCD's share (the first ceil(n / 8) workgroups of an XCD that ask)
+    if (tid < SEL_THREADS / WAVE) s_mail[tid] = 0ull;
+    if (tid == 0) {
+        int got = -1;
+        const unsigned quota = ((unsigned)n_chains + GREEDY_XCDS - 1) / GREEDY_XCDS;
+        if (ld_agent(&ctl->next_chain) < (unsigned)n_chains && atomicAdd(&ctl->xcd[x].tickets, 1u) < quota) {
+            const unsigned c = atomicAdd(&ctl->next_chain, 1u);
+            if (c < (unsigned)n_chains) {
+                const unsigned slot = atomicAdd(&ctl->xcd[x].n_homed, 1u);
+                st_agent(&homed[(size_t)x * n_chains + slot], c + 1u);
+                got = (int)c;
+            }
+        }
+        s_own = got;
+    }
+    __syncthreads();
+    const int own = __builtin_amdgcn_readfirstlane(s_own);
+    __syncthreads();
+    if (own >= 0) greedy_owner_loop<Cell>(a, own, x, smem, &s_own);
+    __syncthreads();
+    greedy_helper_loop<Cell>(a, x, smem, s_mail);
 }
 
 // ================================================================================= column-sharded chains (cmvm_shard.h)
@@ -2225,7 +2398,7 @@ struct HipBackend::Impl {
     // (DA4ML_HIP_ENGINE=launch: the path the persistent kernel replaced, kept for A/B measurements)
     bool persistent = true;
     int n_cus = 256;         // workgroups of the persistent grid = compute units of the device
-    int max_chunks = 16;     // an update step is split into at most this many chunks (tasks)
+    int max_chunks = 64;     // an update step is split into about this many chunks (wave-level tasks)
     DeviceBuffer greedy_buf; // GreedyCtl x 2 (narrow / wide chains) | GreedySync [n] | homed [8][n]
 };
 
@@ -2513,7 +2686,7 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
         size_t s = no * entb + 6 * (size_t)geo[i].Kpad * 4 + (5 * no + 1) * 4 + claim_bytes;
         s = align_up(s, 16);
         sel_lds[w] = std::max(sel_lds[w], s);
-        upd_lds[w] = std::max(upd_lds[w], align_up((size_t)UPD_WAVES * 4 * 3 * (size_t)geo[i].Kpad * 4 + 2 * no * cellb + no * 6, 16));
+        upd_lds[w] = std::max(upd_lds[w], align_up(2 * no * cellb + no * 6, 16) + align_up((size_t)UPD_WAVES * QN * 3 * (size_t)geo[i].Kpad * 4, 16));  // UpdLds: hand-off tables | counters
         pair_lds[w] = std::max(pair_lds[w], (size_t)4 * geo[i].Kpad * 4);
         max_pairs[w] = std::max(max_pairs[w], (long long)jobs[i].n_in * (jobs[i].n_in + 1) / 2);
     }
@@ -2567,22 +2740,26 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
             if (r.count == 0) continue;
             GreedyCtl *d_ctl = reinterpret_cast<GreedyCtl *>(gb + (size_t)w * ctl_bytes);
             unsigned int *d_homed = reinterpret_cast<unsigned int *>(gb + 2 * ctl_bytes + sync_bytes + (size_t)w * homed_bytes);
-            // dynamic LDS: the larger of the selection's carve and the update's carve for a 16-wave workgroup
-            size_t upd16 = 0;
+            // dynamic LDS: the selection's carve, the owner's update carve (shared hand-off + sixteen counter sets), and as many
+            // private (hand-off + counters) areas of helper wavefronts as fit (sixteen unless the matrices are very wide)
+            size_t own_upd = 0, per_wave = 0;
             for (int i = 0; i < n; ++i)
                 if (geo[i].wide == r.wide) {
                     const size_t no = (size_t)jobs[i].n_out, cellb = geo[i].wide ? 8 : 4;
-                    upd16 = std::max(upd16, align_up((size_t)(SEL_THREADS / WAVE) * 4 * 3 * (size_t)geo[i].Kpad * 4 + 2 * no * cellb + no * 6, 16));
+                    const size_t tb = align_up(no * (2 * cellb + 6), 16), wb = align_up((size_t)QN * 3 * (size_t)geo[i].Kpad * 4, 16);
+                    own_upd = std::max(own_upd, tb + (size_t)(SEL_THREADS / WAVE) * wb);
+                    per_wave = std::max(per_wave, tb + wb);
                 }
-            const size_t lds = std::max(sel_lds[w], upd16);
+            size_t lds = std::max(sel_lds[w], own_upd);
             if (lds > 150 * 1024) throw std::runtime_error("greedy kernel needs more than 150 KiB of LDS (n_out too large)");
+            lds = std::max(lds, std::min<size_t>((size_t)(SEL_THREADS / WAVE) * per_wave, 144 * 1024));
             hipStream_t gs = im.lanes[w];
             if (!r.wide) {
                 HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_greedy<uint32_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                hipLaunchKernelGGL(k_greedy<uint32_t>, dim3(im.n_cus), dim3(SEL_THREADS), lds, gs, d_desc + r.first, r.count, d_ctl, d_sync + r.first, d_homed, im.max_chunks);
+                hipLaunchKernelGGL(k_greedy<uint32_t>, dim3(im.n_cus), dim3(SEL_THREADS), lds, gs, d_desc + r.first, r.count, d_ctl, d_sync + r.first, d_homed, im.max_chunks, (int)lds);
             } else {
                 HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_greedy<uint64_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                hipLaunchKernelGGL(k_greedy<uint64_t>, dim3(im.n_cus), dim3(SEL_THREADS), lds, gs, d_desc + r.first, r.count, d_ctl, d_sync + r.first, d_homed, im.max_chunks);
+                hipLaunchKernelGGL(k_greedy<uint64_t>, dim3(im.n_cus), dim3(SEL_THREADS), lds, gs, d_desc + r.first, r.count, d_ctl, d_sync + r.first, d_homed, im.max_chunks, (int)lds);
             }
             HIP_CHECK(hipGetLastError());
         }
@@ -2593,20 +2770,28 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
             if (ranges[w].count == 0) continue;
             HIP_CHECK(hipMemcpy(&h_ctl[w], gb + (size_t)w * ctl_bytes, sizeof(GreedyCtl), hipMemcpyDeviceToHost));
             im.timings.greedy_launches += 1;
-            im.timings.wg_ticks_select += (double)h_ctl[w].t_select;
-            im.timings.wg_ticks_update += (double)h_ctl[w].t_update;
-            im.timings.wg_ticks_idle += (double)h_ctl[w].t_idle;
-            im.timings.wg_ticks_total += (double)h_ctl[w].t_total;
-            im.timings.tasks_select += (double)h_ctl[w].n_select;
-            im.timings.tasks_update += (double)h_ctl[w].n_update;
-            im.timings.polls += (double)h_ctl[w].n_polls;
-            im.timings.workgroups += (double)h_ctl[w].n_wgs;
+            const GreedyCtl &h = h_ctl[w];
+            im.timings.wg_ticks_select += (double)h.t_select;
+            im.timings.wg_ticks_update += (double)h.t_own_update;
+            im.timings.wg_ticks_idle += (double)h.t_own_wait;
+            im.timings.wg_ticks_total += (double)h.t_owner_total;
+            im.timings.helper_ticks_busy += (double)h.t_helper_busy;
+            im.timings.helper_ticks_total += (double)h.t_helper_total;
+            im.timings.tasks_select += (double)h.n_select;
+            im.timings.tasks_update += (double)(h.n_own_chunks + h.n_helper_chunks);
+            im.timings.tasks_helper += (double)h.n_helper_chunks;
+            im.timings.polls += (double)h.n_polls;
+            im.timings.workgroups += (double)h.n_wgs;
             if (verbose) {
                 std::string homes;
-                for (int xq = 0; xq < GREEDY_XCDS; ++xq) homes += " " + std::to_string(h_ctl[w].xcd[xq].n_homed);
-                std::fprintf(stderr, "[da4ml_hip] k_greedy: %llu workgroups, tasks select %llu update %llu, polls %llu; workgroup time select %.1f%% update %.1f%% idle %.1f%%; chains per XCD:%s\n",
-                             h_ctl[w].n_wgs, h_ctl[w].n_select, h_ctl[w].n_update, h_ctl[w].n_polls, 100.0 * h_ctl[w].t_select / std::max<double>(1, h_ctl[w].t_total),
-                             100.0 * h_ctl[w].t_update / std::max<double>(1, h_ctl[w].t_total), 100.0 * h_ctl[w].t_idle / std::max<double>(1, h_ctl[w].t_total), homes.c_str());
+                for (int xq = 0; xq < GREEDY_XCDS; ++xq) homes += " " + std::to_string(h.xcd[xq].n_homed);
+                const double ot = std::max<double>(1, (double)h.t_owner_total), ht = std::max<double>(1, (double)h.t_helper_total);
+                std::fprintf(stderr,
+                             "[da4ml_hip] k_greedy: steps %llu, chunks by owners %llu by helpers %llu, polls %llu; owner time: select %.1f%% own chunks %.1f%% waiting %.1f%%; "
+                             "helper waves busy %.1f%%; us per select %.2f, per helper chunk %.2f; chains per XCD:%s\n",
+                             h.n_select, h.n_own_chunks, h.n_helper_chunks, h.n_polls, 100.0 * h.t_select / ot, 100.0 * h.t_own_update / ot, 100.0 * h.t_own_wait / ot,
+                             100.0 * h.t_helper_busy / ht, 0.01 * h.t_select / std::max<double>(1, (double)h.n_select), 0.01 * h.t_helper_busy / std::max<double>(1, (double)h.n_helper_chunks),
+                             homes.c_str());
             }
         }
     }

@@ -34,7 +34,8 @@ struct GpuTimings {  // accumulated since the last reset; read by the benchmark 
     // persistent greedy kernel (k_greedy): launches, workgroup time by role (100 MHz wall-clock ticks summed over the grid), tasks
     long long greedy_launches = 0;
     double wg_ticks_select = 0, wg_ticks_update = 0, wg_ticks_idle = 0, wg_ticks_total = 0;
-    double tasks_select = 0, tasks_update = 0, polls = 0, workgroups = 0;
+    double helper_ticks_busy = 0, helper_ticks_total = 0;  // wavefront time of the helpers (busy = inside a chunk)
+    double tasks_select = 0, tasks_update = 0, tasks_helper = 0, polls = 0, workgroups = 0;
 };
 
 class HipBackend : public Backend {

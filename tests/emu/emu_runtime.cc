@@ -46,7 +46,7 @@ namespace hipemu {
 thread_local ThreadCtx *g_ctx = nullptr;
 
 namespace {
-enum State : uint8_t { RUNNABLE, AT_WAVE_OP, AT_BARRIER, DONE };
+enum State : uint8_t { RUNNABLE, AT_WAVE_OP, AT_BARRIER, SLEEPING, DONE };  // SLEEPING: inside s_sleep (a spin-wait): resumed after the other waves have run
 struct Fiber {
     void *sp = nullptr;  // saved stack pointer while the fiber is not running
     State state = DONE;
@@ -221,6 +221,11 @@ void run_block(Machine *m, int n_threads) {
                         if (m->fibers[t].state == DONE) --live;
                         ran = true;
                     }
+                // a lane that spins in s_sleep holds its wavefront where it is (on the machine the other lanes are masked off
+                // until it leaves the loop): the wave's pending operations wait, the other wavefronts get their turn
+                bool sleeping = false;
+                for (int t = l0; t < l1; ++t) sleeping |= m->fibers[t].state == SLEEPING;
+                if (sleeping) break;
                 // complete the pending wave-level operation with the lowest call-site address
                 const void *site = nullptr;
                 for (int t = l0; t < l1; ++t)
@@ -243,6 +248,16 @@ void run_block(Machine *m, int n_threads) {
                         m->fibers[t].state = RUNNABLE;
                     }
             }
+        }
+        // lanes that slept go on (what they wait for may have happened meanwhile); the barrier stays shut until nobody sleeps
+        {
+            int slept = 0;
+            for (int t = 0; t < n_threads; ++t)
+                if (m->fibers[t].state == SLEEPING) {
+                    m->fibers[t].state = RUNNABLE;
+                    ++slept;
+                }
+            if (slept) continue;
         }
         // every live thread waits at the block barrier: open it
         int waiting = 0;
@@ -269,6 +284,11 @@ void wave_exchange(uint64_t my_val, const void *site, Snap &out) {
     TSAN_ONLY(char *ws = m->wave_sync[(f - m->fibers.data()) / WAVE]; __tsan_release(ws);)
     yield_to_scheduler();
     TSAN_ONLY(__tsan_acquire(ws);)  // the lanes of a wavefront are in lockstep at a wave-level operation
+}
+
+void sleep_yield() {  // s_sleep: the calling lane spins on something another wavefront of the block will do
+    g_m->cur->state = SLEEPING;
+    yield_to_scheduler();
 }
 
 void block_barrier() {

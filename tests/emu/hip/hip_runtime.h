@@ -54,6 +54,7 @@ struct ThreadCtx {
 extern thread_local ThreadCtx *g_ctx;
 void wave_exchange(uint64_t my_val, const void *site, Snap &out);  // blocks the calling lane until the group is complete
 void block_barrier();
+void sleep_yield();
 unsigned char *dyn_shared();
 void launch_impl(dim3 grid, dim3 block, size_t lds, void (*tramp)(void *), void *closure);
 template <class F> void launch(dim3 grid, dim3 block, size_t lds, F &&f) {
@@ -166,7 +167,7 @@ __attribute__((noinline)) inline void __builtin_amdgcn_wave_barrier() {  // the 
     hipemu::wave_exchange(0, HIPEMU_SITE, s);
 }
 inline void __builtin_amdgcn_s_waitcnt(int) {}
-inline void __builtin_amdgcn_s_sleep(int) {}
+inline void __builtin_amdgcn_s_sleep(int) { hipemu::sleep_yield(); }  // a spin-wait: let the other wavefronts of the block run
 inline void __builtin_amdgcn_sched_barrier(int) {}  // instruction-scheduling fence: no meaning on the host
 inline void __builtin_amdgcn_s_setprio(int) {}
 inline unsigned __builtin_amdgcn_s_getreg(int) { return 0u; }  // HW_REG_XCC_ID: one emulated XCD

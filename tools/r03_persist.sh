@@ -16,6 +16,6 @@ stage single 120 python tests/gpu_profile.py 256 1
 stage batch64 180 python tests/gpu_profile.py 256 64
 unset DA4ML_HIP_VERBOSE
 TAIL=4 stage parity 1200 python -m pytest tests -m gpu -x -q "$@"
-for mc in 4 8 16 32 64; do DA4ML_HIP_MAX_CHUNKS=$mc timeout 120 python tests/gpu_profile.py 256 64 2>&1 | sed -n 1p | sed "s/^/[max_chunks $mc] /"; done | tee $O/chunks.txt
+for mc in 16 32 64 128 256; do DA4ML_HIP_MAX_CHUNKS=$mc timeout 120 python tests/gpu_profile.py 256 64 2>&1 | sed -n 1p | sed "s/^/[max_chunks $mc] /"; done | tee $O/chunks.txt
 DA4ML_HIP_ENGINE=launch timeout 120 python tests/gpu_profile.py 256 64 2>&1 | sed -n 1p | sed "s/^/[launch engine] /" | tee -a $O/chunks.txt
 DA4ML_HIP_ENGINE=launch timeout 120 python tests/gpu_profile.py 256 1 2>&1 | sed -n 1p | sed "s/^/[launch engine] /" | tee -a $O/chunks.txt
