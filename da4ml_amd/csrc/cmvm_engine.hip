@@ -2394,9 +2394,10 @@ struct HipBackend::Impl {
     hipStream_t poll_stream = nullptr;
     GpuTimings timings;
     double table_scale = 1.0;  // grows on E_TABLE_CAPACITY retries
-    // greedy loop: one persistent launch per batch (k_greedy, default) or one (select, update) kernel pair per step
-    // (DA4ML_HIP_ENGINE=launch: the path the persistent kernel replaced, kept for A/B measurements)
-    bool persistent = true;
+    // greedy loop: one (select, update) kernel pair per step on up to four streams (default), or ONE persistent launch per batch
+    // (DA4ML_HIP_ENGINE=persistent: k_greedy -- parity-green on MI355X but 1.8 - 2.1 x slower per step, DESIGN.md section 9;
+    // kept as the measured answer to "why not a persistent kernel", not as a product path)
+    bool persistent = false;
     int n_cus = 256;         // workgroups of the persistent grid = compute units of the device
     int max_chunks = 64;     // an update step is split into about this many chunks (wave-level tasks)
     DeviceBuffer greedy_buf; // GreedyCtl x 2 (narrow / wide chains) | GreedySync [n] | homed [8][n]
@@ -2412,7 +2413,7 @@ HipBackend::HipBackend(int device) : impl_(new Impl) {
     if (const char *e = std::getenv("DA4ML_HIP_ROW_SCALE")) row_scale_ = std::max(1e-4, std::atof(e));
     if (const char *e = std::getenv("DA4ML_HIP_UPD_BLOCKS")) impl_->upd_total_blocks = std::max(2, std::atoi(e));
     if (const char *e = std::getenv("DA4ML_HIP_LANES")) impl_->n_lanes = std::max(1, std::min((int)Impl::MAX_LANES, std::atoi(e)));
-    if (const char *e = std::getenv("DA4ML_HIP_ENGINE")) impl_->persistent = std::string(e) != "launch";
+    if (const char *e = std::getenv("DA4ML_HIP_ENGINE")) impl_->persistent = std::string(e) == "persistent";
     if (const char *e = std::getenv("DA4ML_HIP_MAX_CHUNKS")) impl_->max_chunks = std::max(1, std::min(4096, std::atoi(e)));
     {
         hipDeviceProp_t prop;
