@@ -13,14 +13,17 @@ ranks time.  Synthetic data: default_rng(seed).integers(-128, 128).
 relays rank 0's line; under `python -m torch.distributed.run` it is one of the ranks.
 
 Extra objects on the JSON line:
-  roofline      dominant kernel k_iter_update: algorithmic bytes per launch / its average
-                duration measured with HIP events on the launch stream inside the library; `traffic` and `valu` from the
-                committed rocprofv3 PMC passes of the same workload (profiles/)
-  cpu_baseline  the reference's own sources (oracle/_ref/libref.so) on ALL host cores, one single-threaded solver process
-                per core on its own matrix: a bounded prefix of every 256x256 chain, scaled to full chains with the time
-                curve of a complete run (labelled extrapolated), plus a fully MEASURED 64x64 batch through the same pool
-  verify        outside the timed region: every result of the last step replayed (own numpy replay of the C arrays) and
-                compared with its matrix; digests of seeds 0-3 against the committed oracle records
+  roofline      the greedy loop's two kernels, dominant one (by live launch time) on top and both under `kernels`: algorithmic
+                bytes per launch (device-counted) / average launch duration measured with HIP events on
+                the launch stream inside the library; `traffic` (FETCH_SIZE x 2 as MI355X_MICROARCH.md prescribes for gfx950 +
+                WRITE_SIZE) and `valu` from the committed rocprofv3 PMC passes -- ONLY when those passes were taken on the very
+                sources that are loaded now (profiles/rNN_pmc_meta.json carries their digest), otherwise null + `stale_profiles`
+  cpu_baseline  the reference's own sources (oracle/_ref/libref.so) on the host cores, one single-threaded solver process per
+                core on its own matrix: a bounded prefix of every 256x256 chain scaled to full chains with the time curve of a
+                complete run (labelled extrapolated), plus two fully MEASURED pairs through the same pool with the GPU timed on
+                the same matrices in the same run: 64x64 and 128x128 complete chains
+  check.verify  outside the timed region: every result of the last step replayed (own numpy replay of the C arrays) and
+                compared with its matrix; digests of every seed that has a committed record (reference build preferred)
 
 Other workloads (`--workload`): the 8-matrix default search, the 64x64 batch, and `c5_model_batch` = the end-to-end
 compile of a synthetic layer stack through `solve_many_sharded` (BASELINE configs[4]) with a CPU process-pool baseline.
@@ -81,33 +84,51 @@ def launch_ranks(n: int) -> int:
 
 
 # ------------------------------------------------------------------------------------------------ PMC-derived figures
-def pmc_per_dispatch(counter: str, kernel: str = 'k_iter_update'):
-    """per-dispatch mean of a counter of `kernel` from the newest committed rocprofv3 PMC summary (profiles/rNN_pmc_*.txt,
-    produced by tools/collect_profiles.sh + tools/summarise_pmc.py); (value, chains per dispatch of that pass) or None."""
+def source_digest() -> str:
+    """sha256 over the sources libda4ml_hip.so is built from: what a set of profiles must have been taken on to describe the
+    loaded library (tools/collect_profiles.sh stores it in profiles/rNN_pmc_meta.json)"""
+    import hashlib
+
+    h = hashlib.sha256()
+    files = sorted((ROOT / 'da4ml_amd' / 'csrc').glob('*')) + [ROOT / 'include' / 'da4ml_hip.h']
+    for f in files:
+        if f.suffix in ('.hip', '.cc', '.h') or f.name == 'Makefile':
+            h.update(f.name.encode())
+            h.update(f.read_bytes())
+    return h.hexdigest()
+
+
+def newest_pmc_meta():
+    metas = sorted((ROOT / 'profiles').glob('r*_pmc_meta.json'), reverse=True)
+    if not metas:
+        return None, None
+    return metas[0].name.split('_pmc_meta')[0], json.loads(metas[0].read_text())
+
+
+def pmc_per_dispatch(counter: str, kernel: str, tag: str):
+    """per-dispatch mean of a counter of `kernel` from the committed rocprofv3 PMC summaries profiles/<tag>_pmc_*.txt
+    (tools/collect_profiles.sh + tools/summarise_pmc.py), or None"""
     import re
 
-    for path in sorted((ROOT / 'profiles').glob('r*_pmc_*.txt'), reverse=True):
+    for path in sorted((ROOT / 'profiles').glob(f'{tag}_pmc_*.txt')):
         text = path.read_text()
         m = re.search(re.escape(kernel) + r'[^\n]*\n((?:    [^\n]*\n)+)', text)
         if not m:
             continue
         c = re.search(r'^\s+' + re.escape(counter) + r'\s+sum=\S+\s+per_dispatch=([0-9.eE+-]+)', m.group(1), re.M)
         if c:
-            meta = ROOT / 'profiles' / (path.name.split('_pmc_')[0] + '_pmc_meta.json')
-            chains = json.loads(meta.read_text())['chains_per_dispatch'] if meta.exists() else 8.0  # round 1: --batch 16, two groups
-            return float(c.group(1)), float(chains)
+            return float(c.group(1))
     return None
 
 
-def pmc_traffic_per_chain():
-    """HBM bytes per chain and k_iter_update launch: FETCH_SIZE + WRITE_SIZE (KiB as reported, uncorrected)."""
-    total = 0.0
-    for name in ('FETCH_SIZE', 'WRITE_SIZE'):
-        r = pmc_per_dispatch(name)
-        if r is None:
-            return None
-        total += r[0] * 1024.0 / r[1]
-    return total
+def pmc_traffic(kernel: str, tag: str):
+    """HBM bytes per dispatch of `kernel`: FETCH_SIZE and WRITE_SIZE are reported in KiB; on gfx950 FETCH_SIZE tallies the 128-byte
+    requests of the L2's fabric side at 64 bytes, so it is doubled (MI355X_MICROARCH.md, HBM section); WRITE_SIZE is taken as
+    reported (uncalibrated there).  Returns (corrected bytes, raw bytes) or None."""
+    f, w = pmc_per_dispatch('FETCH_SIZE', kernel, tag), pmc_per_dispatch('WRITE_SIZE', kernel, tag)
+    if f is None or w is None:
+        return None
+    return (2.0 * f + w) * 1024.0, (f + w) * 1024.0
 
 
 def make_batch(n_in, n_out, batch, first_seed):
@@ -168,7 +189,8 @@ def verify(hip, raw, kernels, n_in, n_out, opts, first_seed):
     kind = 'default' if not opts else 'single_chain'
     digests, marshal_s = {}, []
     for i in range(len(kernels)):
-        gold = records.get(f'{n_in}x{n_out}_seed{first_seed + i}_{kind}')
+        key = f'{n_in}x{n_out}_seed{first_seed + i}_{kind}'
+        gold = records.get(key + '_ref') or records.get(key)  # the reference build's record where there is one
         if gold is None:
             continue
         t_obj = time.perf_counter()
@@ -179,6 +201,8 @@ def verify(hip, raw, kernels, n_in, n_out, opts, first_seed):
         digests[f'seed{first_seed + i}'] = {'match': sha == gold['sha256'], 'cost': p.cost, 'adders': p.n_adders, 'oracle_adders': gold['adders'],
                                             'oracle': gold.get('oracle', 'oracle/liboracle.so')}  # fmt: skip
     out['digests_vs_oracle'] = digests
+    out['digests_checked'], out['digests_of'] = len(digests), len(kernels)
+    out['digests_from_reference_build'] = sum(1 for d in digests.values() if d['oracle'].endswith('libref.so'))
     # Python object construction is reported separately from the timed C-ABI call
     out['python_objects_seconds_per_result'] = float(np.mean(marshal_s)) if marshal_s else None
     out['all_ok'] = not bad and all(d['match'] for d in digests.values())
@@ -187,9 +211,10 @@ def verify(hip, raw, kernels, n_in, n_out, opts, first_seed):
 
 
 # ------------------------------------------------------------------------------------------------ CPU baseline
-def cpu_baseline(n_in, n_out, opts, budget_s, batch):
-    """The reference CPU path on all host cores (oracle/cpu_pool.py: one single-threaded solver process per core, each on its
-    own matrix -- the CPU's best case for independent matrices; the reference itself only threads over <= 10 candidates)."""
+def cpu_baseline(n_in, n_out, opts, budget_s, batch, gpu_time_batch=None):
+    """The reference CPU path on the host cores (oracle/cpu_pool.py: one single-threaded solver process per core, each on its
+    own matrix -- the CPU's best case for independent matrices; the reference itself only threads over <= 10 candidates).
+    `gpu_time_batch(kernels, opts)` -> seconds of one GPU batch call on the given matrices (for the measured pairs)."""
     from oracle import cpu_pool
     from oracle.oracle import HERE
 
@@ -198,33 +223,42 @@ def cpu_baseline(n_in, n_out, opts, budget_s, batch):
     cores = cpu_pool.host_cores()
     # one 256x256 chain of the reference holds its 64.7 M initial pairs (24 bytes each) plus the sort buffer: ~4 GB per process
     need_gb = 4.0 * (n_in * n_out / 65536.0) ** 2 + 0.5
-    workers = max(1, min(cores, batch, int(cpu_pool.mem_available_gb() / need_gb)))
+    workers = max(1, min(cores, int(cpu_pool.mem_available_gb() / need_gb)))  # every core the memory allows (seeds repeat beyond the batch)
     method = opts.get('method0', 'wmc')
-    # (1) a time-bounded prefix of every chain of the batch, all cores busy at once
-    samples, wall = cpu_pool.run_pool(cpu_pool.sample_worker, [(okind, n_in, n_out, seed, method, budget_s) for seed in range(workers)], workers)
+    # (1) a time-bounded prefix of a chain of the batch on every core, all cores busy at once
+    samples, wall = cpu_pool.run_pool(cpu_pool.sample_worker, [(okind, n_in, n_out, i % batch, method, budget_s) for i in range(workers)], workers)
     cal_path = ROOT / 'tests' / 'golden' / 'cpu_calibration.json'
     cal = (json.loads(cal_path.read_text()) if cal_path.exists() else {}).get(f'{n_in}x{n_out}')
     est = []
-    for s in samples:
-        if s['finished']:
-            est.append(s['create_s'] + s['iter_s'])
+    for smp in samples:
+        if smp['finished']:
+            est.append(smp['create_s'] + smp['iter_s'])
         elif cal:
             # same-prefix scaling: (full-chain time) / (time of the same first iterations) from the complete run of the same code
             its, tms = np.asarray(cal['iter_marks'], np.float64), np.asarray(cal['time_marks_s'], np.float64)
-            t_prefix = float(np.interp(s['iterations'], its, tms)) - cal['create_s']
-            est.append(s['create_s'] + s['iter_s'] * (cal['total_s'] - cal['create_s']) / max(t_prefix, 1e-9))
-    finished = all(s['finished'] for s in samples)
+            t_prefix = float(np.interp(smp['iterations'], its, tms)) - cal['create_s']
+            est.append(smp['create_s'] + smp['iter_s'] * (cal['total_s'] - cal['create_s']) / max(t_prefix, 1e-9))
+    finished = all(smp['finished'] for smp in samples)
     out = {'value': float(sum(1.0 / e for e in est)) if est else None, 'unit': 'solves/s', 'cores': workers, 'host_cores': cores, 'kind': kind,
            'extrapolated': not finished,
-           'sample': f'{workers} processes x 1 thread, each the seed-i {n_in}x{n_out} chain: state + pair table build (mean {np.mean([s["create_s"] for s in samples]):.1f} s) + '
-                     f'first {int(np.mean([s["iterations"] for s in samples]))} greedy iterations in {budget_s:.0f} s (wall {wall:.1f} s)'
+           'sample': f'{workers} processes x 1 thread, each a seed-i {n_in}x{n_out} chain: state + pair table build (mean {np.mean([smp["create_s"] for smp in samples]):.1f} s) + '
+                     f'first {int(np.mean([smp["iterations"] for smp in samples]))} greedy iterations in {budget_s:.0f} s (wall {wall:.1f} s)'
                      + ('' if finished else f'; scaled to full chains with the time curve of a complete run of the same code ({cal["source"] if cal else "no calibration"})'),
            'est_seconds_per_solve_one_core': float(np.mean(est)) if est else None}  # fmt: skip
-    # (2) fully measured, no scaling: the 64x64 batch through the same pool (complete solves)
-    jobs = [(okind, 64, 64, seed, SINGLE_CHAIN) for seed in range(batch)]
-    res, wall64 = cpu_pool.run_pool(cpu_pool.solve_worker, jobs, workers)
-    out['measured_64x64'] = {'value': batch / wall64, 'unit': 'solves/s', 'cores': workers, 'wall_s': wall64, 'one_core_seconds_per_solve': float(np.mean([r[0] for r in res])),
-                             'sample': f'{batch} complete 64x64 int8 single-chain solves, process pool of {workers}'}  # fmt: skip
+    # (2) fully measured, no scaling, GPU and CPU on the SAME matrices in the same run: complete 64x64 and 128x128 chains
+    for n, key in ((64, 'measured_64x64'), (128, 'measured_128x128')):
+        count = batch if n == 64 or cores >= batch else max(1, min(batch, cores))  # 128x128: ~60-90 s per chain and core -- one wave of the pool
+        w = max(1, min(cores, count))
+        res, wall_n = cpu_pool.run_pool(cpu_pool.solve_worker, [(okind, n, n, seed, SINGLE_CHAIN) for seed in range(count)], w)
+        rec = {'value': count / wall_n, 'unit': 'solves/s', 'cores': w, 'wall_s': wall_n, 'one_core_seconds_per_solve': float(np.mean([r[0] for r in res])),
+               'sample': f'{count} complete {n}x{n} int8 single-chain solves (seeds 0..{count - 1}), process pool of {w}, {kind} build'}  # fmt: skip
+        if gpu_time_batch is not None:
+            ks = make_batch(n, n, count, 0)
+            gpu_time_batch(ks, SINGLE_CHAIN)  # warm-up (arena growth)
+            g = min(gpu_time_batch(ks, SINGLE_CHAIN) for _ in range(3))
+            rec['gpu'] = {'value': count / g, 'unit': 'solves/s', 'seconds_per_batch': g, 'sample': f'the same {count} matrices in one da_solve_batch call, best of 3'}
+            rec['gpu_over_cpu'] = rec['gpu']['value'] / rec['value']
+        out[key] = rec
     return out
 
 
@@ -323,7 +357,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--workload', default='c3_256x256_int8_batch64_single_chain', choices=sorted(WORKLOADS))
     ap.add_argument('--batch', type=int, default=0, help='override the per-GPU batch size')
-    ap.add_argument('--cpu-seconds', type=float, default=15.0, help='budget of the CPU baseline sample (0 = skip)')
+    ap.add_argument('--cpu-seconds', type=float, default=30.0, help='budget of the CPU baseline sample (0 = skip)')
     ap.add_argument('--no-verify', action='store_true', help='skip the replay of all results after the timed region')
     ap.add_argument('--selftest-launcher', action='store_true', help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -391,25 +425,50 @@ def main():
     upd_avg_us = 1e3 * tm['update_ms_sampled'] / samples
     sel_avg_us = 1e3 * tm['select_ms_sampled'] / samples
     chains_per_launch = tm['sampled_chain_launches'] / samples  # the batch runs as a few chain groups on separate streams
-    # algorithmic bytes of k_iter_update: per partner row its cells in the substituted columns
-    # and two 8-byte pair keys; per touched count block its interval record, rank and K u16 counts read + written;
-    # per created block key + record + rank + index + K counts + the partner's interval.  Counted on the device,
-    # summed over all chains and iterations; one launch covers `chains_per_launch` chains for one iteration.
+    iters = max(tm['iterations'], 1.0)
+    # Algorithmic bytes, counted on the device and summed over all chains and steps; one launch covers
+    # `chains_per_launch` chains for one step.
+    #   k_iter_update: per partner row its cells in the substituted columns and two 8-byte pair keys; per touched count block its
+    #     interval record, rank and K u16 counts read + written; per created block key + record + rank + index + K counts + the
+    #     partner's interval
+    #   k_iter_select: bounds, dirty flags and tie words of all groups, every re-read group, both row lists read and written back,
+    #     the row bitmaps of the substituted columns, partner ids / references, the hand-off stores (st_sel_bytes in the kernel)
     K = 2 * (2 * 8 - 1)
-    alg_bytes = tm['cell_bytes'] + 16.0 * tm['partners'] + tm['found'] * (12.0 + 4.0 * K) + tm['inserts'] * (37.0 + 2.0 * K)
-    alg_per_chain_iter = alg_bytes / max(tm['iterations'], 1.0)
-    alg_per_launch = alg_per_chain_iter * chains_per_launch
-    achieved = alg_per_launch / (upd_avg_us * 1e-6) / 1e9 if upd_avg_us > 0 else 0.0
-    per_chain = pmc_traffic_per_chain()
-    traffic = per_chain * chains_per_launch if per_chain else None
+    alg = {'k_iter_update': tm['cell_bytes'] + 16.0 * tm['partners'] + tm['found'] * (12.0 + 4.0 * K) + tm['inserts'] * (37.0 + 2.0 * K),
+           'k_iter_select': tm['select_bytes']}
+    avg_us = {'k_iter_update': upd_avg_us, 'k_iter_select': sel_avg_us}
+    tag, meta = newest_pmc_meta()
+    fresh = bool(meta) and meta.get('src_sha256') == source_digest()
     launches = tm['lockstep_iters'] * max(1.0, round(batch / max(chains_per_launch, 1.0)))
-    valu = None
-    insts = pmc_per_dispatch('SQ_INSTS_VALU')
-    if insts and upd_avg_us > 0:
-        lane_ops = insts[0] / insts[1] * chains_per_launch * 64.0  # wave instructions x 64 lanes (upper bound: full exec mask)
-        act, cyc = pmc_per_dispatch('SQ_ACTIVE_INST_VALU'), pmc_per_dispatch('SQ_WAVE_CYCLES')
-        valu = {'achieved': lane_ops / (upd_avg_us * 1e-6) / 1e12, 'peak': VALU_PEAK_TOPS, 'unit': 'T lane-ops/s', 'frac': lane_ops / (upd_avg_us * 1e-6) / 1e12 / VALU_PEAK_TOPS,
-                'valu_busy_of_wave_cycles': act[0] / cyc[0] if act and cyc else None, 'source': 'profiles/ PMC pass SQ_INSTS_VALU of k_iter_update x 64 lanes / live launch duration'}  # fmt: skip
+    kernels = {}
+    for name in ('k_iter_select', 'k_iter_update'):
+        per_launch = alg[name] / iters * chains_per_launch
+        ach = per_launch / (avg_us[name] * 1e-6) / 1e9 if avg_us[name] > 0 else 0.0
+        k = {'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS, 'alg_bytes_per_launch': per_launch,
+             'alg_bytes_per_chain_step': alg[name] / iters, 'avg_launch_us': avg_us[name], 'launches': launches, 'traffic': None}
+        if fresh:
+            tr = pmc_traffic(name, tag)
+            scale = chains_per_launch / float(meta.get('chains_per_dispatch', chains_per_launch) or chains_per_launch)
+            if tr:
+                k['traffic'], k['traffic_uncorrected'] = tr[0] * scale, tr[1] * scale
+                k['traffic_over_algorithmic'] = k['traffic'] / per_launch if per_launch else None
+            insts = pmc_per_dispatch('SQ_INSTS_VALU', name, tag)
+            if insts and avg_us[name] > 0:
+                lane_ops = insts * scale * 64.0  # wave instructions x 64 lanes (upper bound: full exec mask)
+                act, cyc = pmc_per_dispatch('SQ_ACTIVE_INST_VALU', name, tag), pmc_per_dispatch('SQ_WAVE_CYCLES', name, tag)
+                k['valu'] = {'achieved': lane_ops / (avg_us[name] * 1e-6) / 1e12, 'peak': VALU_PEAK_TOPS, 'unit': 'T lane-ops/s',
+                             'frac': lane_ops / (avg_us[name] * 1e-6) / 1e12 / VALU_PEAK_TOPS, 'valu_busy_of_wave_cycles': act / cyc if act and cyc else None}
+        kernels[name] = k
+    dominant = max(kernels, key=lambda n: avg_us[n])
+    loop_s = max(tm['loop_ms'] * 1e-3, 1e-9)
+    roofline = {'kernel': dominant, **{k: v for k, v in kernels[dominant].items() if k != 'valu'}, 'chains_per_launch': chains_per_launch,
+                'kernels': kernels,
+                'profiles': {'tag': tag, 'fresh': fresh, 'note': None if fresh else 'stale_profiles: the committed PMC passes were taken on other sources than the loaded library; traffic / valu withheld'},
+                'traffic_source': f'profiles/{tag}_pmc_*: (2 x FETCH_SIZE + WRITE_SIZE) KiB per dispatch (gfx950 correction of MI355X_MICROARCH.md), scaled to the live chains per launch' if fresh else None,
+                # the chain groups' launches overlap (4 streams): the algorithmic bytes of both kernels over the whole greedy loop
+                'whole_loop': {'achieved': sum(alg.values()) / loop_s / 1e9, 'unit': 'GB/s', 'frac': sum(alg.values()) / loop_s / 1e9 / HBM_PEAK_GBS,
+                               'what': 'algorithmic bytes of all k_iter_select + k_iter_update launches of the timed steps / their greedy-loop time (concurrent chain groups included)'},
+                'note': 'bound by dependent memory round trips into an HBM-resident pair table and by wave slots, not by bytes or VALU; see DESIGN.md section 5'}  # fmt: skip
     line = {
         'metric': 'CMVM solves/sec, 256x256 int8 matrix' if n_in == 256 else f'CMVM solves/sec, {n_in}x{n_out} int8 matrix',
         'value': total_solves / elapsed,
@@ -425,22 +484,25 @@ def main():
         'data': 'synthetic',
         'config': {'workload': args.workload, 'matrix': f'{n_in}x{n_out} int8 (default_rng(seed).integers(-128,128))', 'batch_per_gpu': batch,
                    'solve_options': opts, 'parallelism': f'{world} x independent-instance shard, no data-path collective'},  # fmt: skip
-        'roofline': {'kernel': 'k_iter_update', 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                     'traffic': traffic, 'traffic_source': 'profiles/ PMC passes (FETCH_SIZE + WRITE_SIZE per chain) x chains per launch' if traffic else None,
-                     'alg_bytes_per_launch': alg_per_launch, 'chains_per_launch': chains_per_launch, 'avg_launch_us': upd_avg_us, 'launches': launches,
-                     'select_avg_launch_us': sel_avg_us, 'valu': valu,
-                     # the chain groups' launches overlap (4 streams): the same algorithmic bytes over the whole greedy loop
-                     'whole_loop': {'achieved': alg_bytes / max(tm['loop_ms'] * 1e-3, 1e-9) / 1e9, 'unit': 'GB/s', 'frac': alg_bytes / max(tm['loop_ms'] * 1e-3, 1e-9) / 1e9 / HBM_PEAK_GBS,
-                                    'what': 'algorithmic bytes of all k_iter_update launches of the timed steps / their greedy-loop time (concurrent chain groups included)'},
-                     'note': 'bound by dependent memory round trips into an HBM-resident pair table, not by bytes or VALU; see DESIGN.md section 5'},  # fmt: skip
+        'roofline': roofline,
         'engine': {'greedy_loop_ms_per_step': tm['loop_ms'] / args.steps, 'library_ms_per_step': tm['total_ms'] / args.steps,
                    'greedy_iterations_per_step': tm['iterations'] / args.steps, 'lockstep_iterations_per_step': tm['lockstep_iters'] / args.steps,
-                   'partner_rows_per_step': tm['partners'] / args.steps, 'arena_GB': tm['arena_bytes'] / 1e9},  # fmt: skip
+                   'partner_rows_per_step': tm['partners'] / args.steps, 'arena_GB': tm['arena_bytes'] / 1e9,
+                   'us_per_lockstep_iteration': 1e3 * tm['loop_ms'] / max(tm['lockstep_iters'], 1.0),
+                   # the launch thread: host time spent queueing the loop's launches vs the time the device needed for them
+                   'host_launch_us_per_iter': 1e3 * tm['host_launch_ms'] / max(tm['lockstep_iters'], 1.0),
+                   'host_launch_share_of_loop': tm['host_launch_ms'] / max(tm['loop_ms'], 1e-9),
+                   'source_digest': source_digest()},  # fmt: skip
         'check': check,
     }
     if args.cpu_seconds > 0 and world == 1:
         try:
-            line['cpu_baseline'] = cpu_baseline(n_in, n_out, opts, args.cpu_seconds, batch)
+            def gpu_time_batch(ks, o):
+                t = time.perf_counter()
+                hip.solve_many_raw(ks, **o).free()
+                return time.perf_counter() - t
+
+            line['cpu_baseline'] = cpu_baseline(n_in, n_out, opts, args.cpu_seconds, batch, gpu_time_batch)
         except Exception as e:  # the baseline leg must never break the benchmark line
             line['cpu_baseline'] = {'value': None, 'unit': 'solves/s', 'cores': 0, 'kind': 'port', 'sample': f'failed: {type(e).__name__}: {e}'}
     print(json.dumps(line), flush=True)

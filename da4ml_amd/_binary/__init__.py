@@ -28,7 +28,7 @@ _i32p = np.ctypeslib.ndpointer(np.int32, flags='C_CONTIGUOUS')
 EXPORTS = (
     'da_last_error da_last_error_code da_version da_device_count da_set_device da_get_lsb_loc da_iceil_log2 da_cost_add da_int_arr_to_csd '
     'da_csd_decompose da_kernel_decompose da_solve da_solve_batch da_solve_sharded da_n_stages da_picked da_stage_info da_stage_copy '
-    'da_result_stats da_free da_timings da_dais_run da_dais_last_error da_dais_run_on'
+    'da_result_stats da_free da_timings da_engine_stats da_dais_run da_dais_last_error da_dais_run_on'
 ).split()
 
 
@@ -87,6 +87,7 @@ def lib():
     L.da_result_stats.argtypes = [C.c_void_p, _i64p]
     L.da_free.argtypes = [C.c_void_p]
     L.da_timings.argtypes = [np.ctypeslib.ndpointer(np.float64, flags='C_CONTIGUOUS'), C.c_int]
+    L.da_engine_stats.argtypes = [np.ctypeslib.ndpointer(np.float64, flags='C_CONTIGUOUS'), C.c_int]
     _lib = L
     return L
 
@@ -350,6 +351,8 @@ def solve_many_raw(kernels, method0='wmc', method1='auto', hard_dc=-1, decompose
 def timings(reset: bool = False) -> dict:
     """Accumulated device-side timings / counters of the greedy loops (benchmark instrumentation)."""
     t = np.zeros(32, np.float64)
+    e = np.zeros(16, np.float64)
+    lib().da_engine_stats(e, 16)  # before the (possibly resetting) da_timings
     rc = lib().da_timings(t, int(reset))
     if rc != 0:
         _raise(rc)
@@ -357,7 +360,9 @@ def timings(reset: bool = False) -> dict:
              'select_ms_sampled', 'update_ms_sampled', 'samples', 'found', 'inserts', 'cell_reads', 'block_bytes', 'cell_bytes',
              'sel_load_bounds', 'sel_argmax', 'sel_newrow', 'sel_substitute', 'sel_prefix', 'sel_claims', 'sel_special',
              'upd_fetch', 'upd_probe', 'upd_cells', 'upd_blocks', 'upd_create', 'retries', 'sampled_chain_launches')
-    return dict(zip(names, t.tolist()))
+    extra = ('select_bytes', 'host_launch_ms', 'greedy_launches', 'owner_ticks_select', 'owner_ticks_own_chunks', 'owner_ticks_waiting', 'owner_ticks_total',
+             'helper_ticks_busy', 'helper_ticks_total', 'greedy_steps', 'greedy_chunks', 'greedy_chunks_by_helpers', 'scout_polls', 'greedy_workgroups')
+    return {**dict(zip(names, t.tolist())), **dict(zip(extra, e.tolist()))}
 
 
 _DAIS_EXECUTORS = {'host': 0, 'cpu': 0, 'device': 1, 'gpu': 1, 'host-scalar': 2}

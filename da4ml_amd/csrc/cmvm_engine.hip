@@ -262,6 +262,7 @@ struct ChainDev {
     int32_t *cs_slab;             // [(3 cs_nuni + 6)][K] partial / summed count changes
     // statistics
     unsigned long long st_rescans, st_partners, st_matches, st_found, st_inserts, st_cells;
+    unsigned long long st_sel_bytes;  // algorithmic bytes of the selection steps (all but the group re-reads, which st_rescans prices)
     unsigned long long st_phase[12];  // shader-clock cycles per kernel phase (select: 0-6, update: 7-11)
 };
 
@@ -1330,6 +1331,17 @@ template <class Cell, bool SHARDED = false> __device__ __forceinline__ int selec
         atomicAdd(&g->st_matches, (unsigned long long)s_matches);
         atomicAdd(&g->st_partners, (unsigned long long)s_np);
         atomicAdd(&g->st_cells, (unsigned long long)s_np * (unsigned)m);
+        {
+            // algorithmic bytes of this selection step: bound / dirty / tie word of every group, the list
+            // lengths of all columns, records and list references of A and B, both row lists read and written back, the row
+            // bitmaps of the m substituted columns, per partner its id + list reference + partner-list entry, the hand-off
+            // (matched columns, consumed digits, new row's list, column map, column-list and bitmap updates), six special blocks
+            const unsigned long long eb = sizeof(Entry), cb = sizeof(Cell);
+            const unsigned long long nwords = (Nw + 31) >> 5;
+            atomicAdd(&g->st_sel_bytes, 17ull * (unsigned)n_groups + 4ull * (unsigned)n_out + 48ull + 2ull * eb * (unsigned)(lenA + (same ? 0 : lenB)) +
+                                            4ull * (unsigned)m * nwords + 20ull * (unsigned)s_np + (unsigned)m * (4ull + 2ull * cb + eb + 8ull + 12ull) + 2ull * (unsigned)n_out +
+                                            6ull * (16ull + 4ull * (unsigned)c.K));
+        }
         g->A = A;
         g->B = B;
         g->Nw = Nw;
@@ -2848,7 +2860,9 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
     }
     im.h_done[0] = im.h_done[1] = 0;
     long long window = 0;
+    double host_launch_ms = 0;  // host time spent queueing launches (not waiting for the device)
     while (active > 0 && !im.persistent) {
+        const auto t_q0 = std::chrono::steady_clock::now();
         if (launched_iters > iter_cap + 2 * poll_every) throw std::runtime_error("greedy loop did not terminate within its row capacity (internal error)");
         // sampled eager iteration (all groups; the first group's kernels are bracketed by events on its stream)
         for (size_t gi = 0; gi < groups.size(); ++gi) {
@@ -2876,6 +2890,7 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
         }
         HIP_CHECK(hipMemcpyAsync(&im.h_done[p], im.d_done, sizeof(unsigned int), hipMemcpyDeviceToHost, im.poll_stream));
         HIP_CHECK(hipEventRecord(copy_ev[p], im.poll_stream));
+        host_launch_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_q0).count();
         if (window > 0) {
             HIP_CHECK(hipEventSynchronize(copy_ev[p ^ 1]));
             active = n - pre_done - (int)im.h_done[p ^ 1];
@@ -3051,11 +3066,13 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
         im.timings.cell_bytes += (geo[i].wide ? 8.0 : 4.0) * (double)d.st_cells;
         im.timings.iterations += d.iter;
         im.timings.rescans += (long long)d.st_rescans;
+        im.timings.select_bytes += (double)d.st_sel_bytes + (double)d.st_rescans * ((double)(4u << d.gs_log2) + 24.0);  // + every re-read group: its ranks, ~2 tied slots' key and index
         im.timings.partners += (long long)d.st_partners;
         im.timings.table_bytes += (double)d.C * (8.0 + 4.0 + (double)(1 << d.pb_log2));
     }
     lap("extract + download + unpack");
     im.timings.loop_ms += loop_ms;
+    im.timings.host_launch_ms += host_launch_ms;
     if (im.persistent)  // no lockstep: the longest chain of the batch
         for (int sidx = 0; sidx < n; ++sidx) launched_iters = std::max<long long>(launched_iters, fin[sidx].iter);
     im.timings.lockstep_iters += launched_iters;

@@ -31,6 +31,8 @@ struct GpuTimings {  // accumulated since the last reset; read by the benchmark 
     double phase_cycles[12] = {0};  // shader-clock cycles: k_iter_select phases 0-6, k_iter_update per-wave phases 7-11
     double table_bytes = 0;   // bytes of pair-table storage summed over chains
     double arena_bytes = 0;   // largest device arena used
+    double select_bytes = 0;    // algorithmic bytes of k_iter_select, counted on the device
+    double host_launch_ms = 0;  // host time spent queueing the greedy loop's launches (the launch thread's share of the loop)
     // persistent greedy kernel (k_greedy): launches, workgroup time by role (100 MHz wall-clock ticks summed over the grid), tasks
     long long greedy_launches = 0;
     double wg_ticks_select = 0, wg_ticks_update = 0, wg_ticks_idle = 0, wg_ticks_total = 0;

@@ -41,22 +41,35 @@ def test_committed_bench_line_has_the_contract_fields():
         assert len(v['digests_vs_oracle']) >= 4 and all(d['match'] for d in v['digests_vs_oracle'].values())
         assert c['cores'] > 1 or c.get('host_cores', 1) == 1  # all host cores, not one
         assert 'extrapolated' in c and c['measured_64x64']['value'] > 0
-        assert r['valu'] is None or 0 < r['valu']['frac'] < 1
+        assert r.get('valu') is None or 0 < r['valu']['frac'] < 1
     else:
         assert chk['adders_match_oracle'] is True
 
 
 def test_pmc_traffic_helper_reads_the_committed_passes():
+    """the committed PMC summaries are readable per kernel; a bench line of the two-kernel format (round 3 on) agrees with them
+    when it says its profiles were fresh, and withholds traffic when it says they were stale"""
     sys.path.insert(0, str(ROOT))
     import bench
 
-    per_chain = bench.pmc_traffic_per_chain()
-    assert per_chain and per_chain > 0
+    tag, meta = bench.newest_pmc_meta()
+    assert tag and meta and meta['chains_per_dispatch'] >= 1
+    for kernel in ('k_iter_select', 'k_iter_update'):
+        tr = bench.pmc_traffic(kernel, tag)
+        assert tr and tr[0] > tr[1] > 0  # corrected (2 x FETCH_SIZE + WRITE_SIZE) above the raw sum
     r = _last_bench_line()['roofline']
-    # within 1 %: the PMC passes were collected once more after the committed bench line was produced
-    assert abs(per_chain * r['chains_per_launch'] - r['traffic']) < 1e-2 * r['traffic']
-    insts = bench.pmc_per_dispatch('SQ_INSTS_VALU')
-    assert insts and insts[0] > 0 and insts[1] >= 1
+    if 'kernels' in r:
+        assert set(r['kernels']) == {'k_iter_select', 'k_iter_update'} and r['kernel'] in r['kernels']
+        for name, k in r['kernels'].items():
+            assert abs(k['frac'] - k['achieved'] / k['peak']) < 1e-12
+            assert abs(k['achieved'] - k['alg_bytes_per_launch'] / (k['avg_launch_us'] * 1e-6) / 1e9) < 1e-6 * max(k['achieved'], 1e-9)
+            if r['profiles']['fresh']:
+                # within 1 %: same passes, scaled to the line's chains per launch
+                want = bench.pmc_traffic(name, r['profiles']['tag'])[0] * r['chains_per_launch'] / meta['chains_per_dispatch']
+                assert abs(want - k['traffic']) < 1e-2 * k['traffic']
+            else:
+                assert k['traffic'] is None and 'stale_profiles' in r['profiles']['note']
+    assert len(bench.source_digest()) == 64
     assert 'c3_256x256_int8_batch64_single_chain' in bench.WORKLOADS and bench.WORKLOADS['c3_256x256_int8_batch64_single_chain'][:3] == (256, 256, 64)
     ks = bench.make_batch(4, 3, 2, first_seed=5)
     assert len(ks) == 2 and ks[0].shape == (4, 3) and ks[0].dtype.name == 'float32' and abs(ks[0]).max() <= 128

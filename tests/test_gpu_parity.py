@@ -35,6 +35,26 @@ def test_scalar_and_decompositions(hip, oracle):
     assert np.array_equal(hip.int_arr_to_csd(x), oracle.int_arr_to_csd(x))
 
 
+@pytest.mark.parametrize('shape', [(64, 64), (256, 256), (257, 257), (96, 300)])
+def test_decompositions_at_benchmark_sizes(hip, oracle, shape):
+    """csd_decompose (k_prepare + k_init_cells digit recoding), kernel_decompose (k_col_dist at up to 257 x 257 columns + the
+    host's spanning tree, dc in {-2, -1, 0, 2, 4}) and int_arr_to_csd (k_naf_digits / k_absmax on 10^6 elements) called directly
+    at the sizes of the benchmark and beyond the narrow layout -- reference mat_decompose.cc:63-137, bit_decompose.cc:22-62"""
+    k = int_matrix(shape[0] * 1000 + shape[1], *shape, -128, 128)
+    a, b = hip.csd_decompose(k), oracle.csd_decompose(k)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    a, b = hip.csd_decompose(k, center=False), oracle.csd_decompose(k, center=False)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    for dc in (-2, -1, 0, 2, 4):
+        m, w = hip.kernel_decompose(k, dc), oracle.kernel_decompose(k, dc)
+        assert all(np.array_equal(x, y) for x, y in zip(m, w)), dc
+        assert np.all(m[0] @ m[1] == k)
+    if shape == (256, 256):
+        rng = np.random.default_rng(11)
+        for x in (rng.integers(-(2**20), 2**20, (1000, 1000)).astype(np.int32), rng.integers(-128, 128, (3, 333, 1001)).astype(np.int32), np.zeros((7, 5), np.int32)):
+            assert np.array_equal(hip.int_arr_to_csd(x), oracle.int_arr_to_csd(x))
+
+
 @pytest.mark.parametrize('seed', range(120))
 def test_random_small(hip, oracle, seed):
     k, opts, zero_input = random_case(seed)
@@ -165,13 +185,22 @@ def test_c3_256x256_seed0_against_oracle_record(hip):
     from pathlib import Path
 
     gold = json.loads((Path(__file__).parent / 'golden' / 'large_chain_golden.json').read_text())
-    assert '256x256_seed0_single_chain' in gold
+    assert '256x256_seed0_single_chain' in gold and '256x256_seed0_single_chain_ref' in gold
+    assert sum(1 for name in gold if name.startswith('256x256') and name.endswith('_ref')) >= 6  # seed 0 and seeds 4.. from the reference build
+    problems = {}  # (n, seed) -> records (the restatement's and / or the reference build's)
     for name, rec in sorted(gold.items()):
         n, seed = (int(v) for v in re.fullmatch(r'(\d+)x\1_seed(\d+)_single_chain(?:_ref)?', name).groups())
-        p = hip.solve(int_matrix(seed, n, n, -128, 128), **rec['opts'])
+        problems.setdefault((n, seed), []).append((name, rec))
+    keys = sorted(problems)
+    opts = problems[keys[0]][0][1]['opts']
+    assert all(rec['opts'] == opts for recs in problems.values() for _, rec in recs)
+    results = hip.solve_many([int_matrix(seed, n, n, -128, 128) for n, seed in keys], **opts)  # one batch: the chains run concurrently
+    for key, p in zip(keys, results):
         dump = json.loads(json.dumps(p, default=lambda o: o.to_dict()))
-        assert p.cost == rec['cost'] and [len(s.ops) for s in p.solutions] == rec['n_ops'], name
-        assert hashlib.sha256(json.dumps(dump, separators=(',', ':')).encode()).hexdigest() == rec['sha256'], name
+        sha = hashlib.sha256(json.dumps(dump, separators=(',', ':')).encode()).hexdigest()
+        for name, rec in problems[key]:
+            assert p.cost == rec['cost'] and [len(s.ops) for s in p.solutions] == rec['n_ops'], name
+            assert sha == rec['sha256'], name
 
 
 def test_default_search_against_oracle_records(hip):
