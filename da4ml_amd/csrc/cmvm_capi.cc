@@ -5,6 +5,7 @@
 #include <cstdlib>
 #include <chrono>
 #include <cstdio>
+#include <algorithm>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -45,16 +46,23 @@ int fail(const std::exception &e) {
     return g_err_code;
 }
 
+// Steps the latency model has no logarithm for are refused up front: non-positive, NaN / infinite and subnormal ones (the
+// reference computes -log2 of whatever it is given; a result with infinite or NaN latencies is of no use to anybody).  Steps
+// that are not powers of two are accepted (StepLog2, cmvm_core.h) up to STEP_MANTS distinct mantissas per matrix.
 void check_dyadic_steps(const float *q, int64_t n_in) {
     if (!q) return;
+    std::vector<uint32_t> mants;
     for (int64_t i = 0; i < n_in; ++i) {
         float lo = q[3 * i], hi = q[3 * i + 1], st = q[3 * i + 2];
         if (lo == 0.0f && hi == 0.0f) continue;  // constant-zero input: its digits are dropped, the step is never used
         uint32_t b;
         std::memcpy(&b, &st, 4);
-        bool pow2 = (b >> 31) == 0 && (b & 0x7FFFFFu) == 0 && ((b >> 23) & 0xFF) != 0 && ((b >> 23) & 0xFF) != 255;
-        if (!pow2) throw std::invalid_argument("qintervals[" + std::to_string(i) + "].step must be a positive power of two");
+        const uint32_t e = (b >> 23) & 0xFF, m = b & 0x7FFFFFu;
+        if ((b >> 31) || e == 0 || e == 255) throw std::invalid_argument("qintervals[" + std::to_string(i) + "].step must be a positive normal number");
+        if (m && std::find(mants.begin(), mants.end(), m) == mants.end()) mants.push_back(m);
     }
+    if ((int)mants.size() > da::STEP_MANTS)
+        throw std::invalid_argument("more than " + std::to_string(da::STEP_MANTS) + " distinct non-power-of-two quantisation steps in one matrix are not supported");
 }
 
 }  // namespace

@@ -31,7 +31,7 @@ enum ChainError : int {
     E_ROW_CAPACITY = 1,    // more greedy iterations than the row arena holds
     E_TABLE_CAPACITY = 2,  // pair-block table arena too small
     E_LIST_CAPACITY = 3,   // a column row-list overflowed (cannot happen with the exact bound; guarded anyway)
-    E_FLOAT_DOMAIN = 4,    // a quantisation step that is not a power of two reached the latency model
+    E_FLOAT_DOMAIN = 4,    // the latency model met a step it has no logarithm for (subnormal / non-positive, or more than STEP_MANTS distinct non-power-of-two mantissas)
     E_COUNT_OVERFLOW = 5,  // a pair count exceeded 16 bits
 };
 
@@ -344,22 +344,37 @@ DA_HD float ceil_log2f_emul(float x, const Log2Table &tab, int &domain_err) {
     if (m == 0 || m <= tab.tie[ee + 150]) return (float)ee;
     return (float)(ee + 1);
 }
-// -std::log2(step) for a power-of-two step (state_opr.cc:57)
-DA_HD float neg_log2f_pow2(float st, int &domain_err) {
+// -std::log2(step) (state_opr.cc:57).  A power of two is read off the exponent.  Any other step gets the HOST libm's value from a
+// table: every row's step is an input step times a power of two (qint_add keeps min(step0, step1 * 2^shift)), so only the
+// mantissas of the input steps ever occur; for each of them (at most STEP_MANTS per chain) the host tabulates
+// -log2f(mantissa * 2^(e - 127)) for all 254 normal exponents with its own std::log2 -- exact by construction, no libm
+// re-implementation on the device.
+constexpr int STEP_MANTS = 8;
+struct StepLog2 {
+    int n;                 // distinct non-power-of-two step mantissas of the chain's inputs
+    const uint32_t *mant;  // [n] their 23 mantissa bits
+    const float *tab;      // [n][256] -log2f of (mantissa, biased exponent)
+};
+DA_HD float neg_log2f_step(float st, const StepLog2 &sl, int &domain_err) {
     uint32_t b = f2u(st);
     int e = (int)((b >> 23) & 0xFF);
     if (st != st) return st;
     if (st == 0.0f) return __builtin_inff();
     if (e == 255 && (b & 0x7FFFFFu) == 0) return (b >> 31) ? st : -__builtin_inff();
-    if ((b >> 31) || (b & 0x7FFFFFu) != 0 || e == 0) {
+    if ((b >> 31) || e == 0 || e == 255) {
         domain_err = 1;
         return 0.0f;
     }
-    return -(float)(e - 127);
+    const uint32_t m = b & 0x7FFFFFu;
+    if (m == 0) return -(float)(e - 127);
+    for (int i = 0; i < sl.n; ++i)
+        if (sl.mant[i] == m) return sl.tab[i * 256 + e];
+    domain_err = 1;
+    return 0.0f;
 }
 // latency increment of cost_add (state_opr.cc:31-67); the cost itself is recomputed on the host
 DA_HD float adder_dlat(const RowInfo &a, const RowInfo &b, int shift, int sub, int adder_size, int carry_size,
-                       const Log2Table &tab, int &domain_err) {
+                       const Log2Table &tab, const StepLog2 &sl, int &domain_err) {
     if (adder_size < 0 && carry_size < 0) return 1.0f;
     if (carry_size < 0) carry_size = 65535;
     float lo0 = a.lo, hi0 = a.hi, st0 = a.step, lo1 = b.lo, hi1 = b.hi, st1 = b.step;
@@ -382,7 +397,7 @@ DA_HD float adder_dlat(const RowInfo &a, const RowInfo &b, int shift, int sub, i
     hi0 = hi0 + st0;
     hi1 = hi1 + st1;
 #endif
-    float f = neg_log2f_pow2(st0 > st1 ? st0 : (st1 > st0 ? st1 : st0), domain_err);
+    float f = neg_log2f_step(st0 > st1 ? st0 : (st1 > st0 ? st1 : st0), sl, domain_err);
     float m = __builtin_fabsf(lo0);
     float t1 = __builtin_fabsf(lo1), t2 = __builtin_fabsf(hi0), t3 = __builtin_fabsf(hi1);
     m = m < t1 ? t1 : m;

@@ -262,6 +262,10 @@ struct ChainDev {
     int32_t *cs_slab;             // [(3 cs_nuni + 6)][K] partial / summed count changes
     // statistics
     unsigned long long st_rescans, st_partners, st_matches, st_found, st_inserts, st_cells;
+    // -log2f of non-power-of-two input steps (StepLog2, cmvm_core.h): table built by the host libm, nullptr / 0 when all steps are powers of two
+    const uint32_t *step_mant;
+    const float *step_tab;
+    int n_step_mant;
     unsigned long long st_sel_bytes;  // algorithmic bytes of the selection steps (all but the group re-reads, which st_rescans prices)
     unsigned long long st_phase[12];  // shader-clock cycles per kernel phase (select: 0-6, update: 7-11)
 };
@@ -715,6 +719,9 @@ template <class Cell, bool SHARDED = false> __device__ __forceinline__ int selec
     int was_done = g->done, had_error = g->error, iter = g->iter, n_groups = g->n_groups, lcap = g->lcap, claim_words = g->claim_words;
     int n_rows0 = g->n_rows, rcap = g->rcap, cbw = g->cb_words, adder_size = g->adder_size, carry_size = g->carry_size;
     uint32_t offN = g->rl_used, rl_cap = g->rl_cap, n_live0 = g->n_live, live_peak0 = g->live_peak;
+    const uint32_t *step_mant = g->step_mant;
+    const float *step_tab = g->step_tab;
+    int n_step_mant = g->n_step_mant;
     Ctx c = make_ctx_raw(g, 2 * iter);
     DA_GLOBAL int *collen = (DA_GLOBAL int *)g->collen;
     DA_GLOBAL unsigned long long *gtie_arr = (DA_GLOBAL unsigned long long *)g->gtie;
@@ -729,7 +736,7 @@ template <class Cell, bool SHARDED = false> __device__ __forceinline__ int selec
     DA_GLOBAL unsigned long long *plist = (DA_GLOBAL unsigned long long *)g->plist;
     DA_GLOBAL da_i4 *picks = (DA_GLOBAL da_i4 *)g->picks;
     DA_GLOBAL int32_t *cs_slab = (DA_GLOBAL int32_t *)g->cs_slab, *cs_flags = (DA_GLOBAL int32_t *)g->cs_flags;
-    pin_sgpr(was_done, had_error, iter, n_groups, lcap, claim_words, n_rows0, rcap, cbw, adder_size, carry_size, offN, rl_cap, n_live0, live_peak0);
+    pin_sgpr(was_done, had_error, iter, n_groups, lcap, claim_words, n_rows0, rcap, cbw, adder_size, carry_size, offN, rl_cap, n_live0, live_peak0, step_mant, step_tab, n_step_mant);
     pin_sgpr(c.n_out, c.n_bits, c.K, c.Kpad, c.method, c.gs_log2, c.pb_log2, c.cmask, c.windows, c.hkey, c.hrank, c.hblk, c.ub, c.gdirty, c.rows);
     pin_sgpr(collen, gtie_arr, rowoff, rl, mA, mB, mcol, collist, cmap, colbits, pl_ids, plist, picks);
     if constexpr (SHARDED) pin_sgpr(cs_slab, cs_flags);
@@ -1054,7 +1061,7 @@ template <class Cell, bool SHARDED = false> __device__ __forceinline__ int selec
     int derr = 0;
     if (tid == 0) {  // arithmetic only, while the entries are in flight; the global stores follow once they have been consumed
         qint_add_pair(ra, rb, shift, sub, rn.lo, rn.hi, rn.step);
-        float dlat = adder_dlat(ra, rb, shift, sub, adder_size, carry_size, s_log2, derr);
+        float dlat = adder_dlat(ra, rb, shift, sub, adder_size, carry_size, s_log2, StepLog2{n_step_mant, step_mant, step_tab}, derr);
         rn.lat = (ra.lat < rb.lat ? rb.lat : ra.lat) + dlat;
         s_new = rn;
     }
@@ -2493,6 +2500,8 @@ size_t carve_chain(unsigned char *base, const ChainJob &job, const Geometry &g, 
     d.pk_row = c.take<uint32_t>((size_t)g.pk_cap);
     d.pk_cell = c.take<unsigned long long>((size_t)g.pk_cap);
     d.pk_lat = c.take<float>(g.rcap);
+    d.step_mant = c.take<uint32_t>(STEP_MANTS);  // filled only when an input step is not a power of two (StepLog2)
+    d.step_tab = c.take<float>((size_t)STEP_MANTS * 256);
     return align_up(c.off, 256);
 }
 
@@ -2660,6 +2669,18 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
         d.iter = 0;
         d.done = (jobs[i].method == M_DUMMY || jobs[i].method < 0) ? 1 : 0;
         d.cb_words = (g.rcap + 31) / 32;
+    }
+    // -log2f tables of non-power-of-two input steps (rare: the tracer's `variable * 3`), by the host libm; they stay alive until
+    // the set-up stream has been synchronised below
+    std::vector<StepLog2Host> step_tabs(n);
+    for (int i = 0; i < n; ++i) {
+        if (jobs[i].adder_size < 0 && jobs[i].carry_size < 0) continue;  // the latency model is off: steps are never looked at
+        step_tabs[i].build(jobs[i].qints, jobs[i].n_in);
+        desc[i].n_step_mant = (int)step_tabs[i].mant.size();
+        if (desc[i].n_step_mant) {
+            HIP_CHECK(hipMemcpyAsync(const_cast<uint32_t *>(desc[i].step_mant), step_tabs[i].mant.data(), step_tabs[i].mant.size() * 4, hipMemcpyHostToDevice, st));
+            HIP_CHECK(hipMemcpyAsync(const_cast<float *>(desc[i].step_tab), step_tabs[i].tab.data(), step_tabs[i].tab.size() * 4, hipMemcpyHostToDevice, st));
+        }
     }
     HIP_CHECK(hipMemcpyAsync(d_desc, desc.data(), sizeof(ChainDev) * (size_t)n, hipMemcpyHostToDevice, st));
     HIP_CHECK(hipMemsetAsync(im.d_done, 0, sizeof(unsigned int), st));
@@ -3184,6 +3205,14 @@ class HipShardEngine : public ShardEngine {
         HIP_CHECK(hipMemsetAsync(d_.gdirty, 1, (size_t)g.n_groups, st_));
         d_.cb_words = (g.rcap + 31) / 32;
         HIP_CHECK(hipMemsetAsync(d_.colbits, 0, sizeof(uint32_t) * (size_t)n_loc_ * d_.cb_words, st_));
+        if (job.adder_size >= 0 || job.carry_size >= 0) {  // -log2f of non-power-of-two input steps (StepLog2), as in run_chains
+            step_tab_.build(job.qints, job.n_in);
+            d_.n_step_mant = (int)step_tab_.mant.size();
+            if (d_.n_step_mant) {
+                HIP_CHECK(hipMemcpyAsync(const_cast<uint32_t *>(d_.step_mant), step_tab_.mant.data(), step_tab_.mant.size() * 4, hipMemcpyHostToDevice, st_));
+                HIP_CHECK(hipMemcpyAsync(const_cast<float *>(d_.step_tab), step_tab_.tab.data(), step_tab_.tab.size() * 4, hipMemcpyHostToDevice, st_));
+            }
+        }
         push();
         HIP_CHECK(hipMalloc(&d_done_, sizeof(unsigned int)));
         HIP_CHECK(hipMemsetAsync(d_done_, 0, sizeof(unsigned int), st_));
@@ -3315,6 +3344,7 @@ class HipShardEngine : public ShardEngine {
         HIP_CHECK(hipStreamSynchronize(st_));
     }
     hipStream_t st_;
+    StepLog2Host step_tab_;
     int device_;
     ChainJob job_;
     int n_loc_;  // columns of this rank (the first of them is d_.col0)

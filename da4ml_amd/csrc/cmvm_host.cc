@@ -77,6 +77,22 @@ Log2Table measure_log2_table() {
     return t;
 }
 
+void StepLog2Host::build(const QInt *q, int n_in) {
+    mant.clear();
+    tab.clear();
+    if (!q) return;
+    for (int i = 0; i < n_in; ++i) {
+        if (q[i].lo == 0.0f && q[i].hi == 0.0f) continue;
+        const uint32_t b = f2u(q[i].step), m = b & 0x7FFFFFu, e = (b >> 23) & 0xFFu;
+        if ((b >> 31) || m == 0 || e == 0 || e == 255) continue;
+        if (std::find(mant.begin(), mant.end(), m) != mant.end() || (int)mant.size() >= STEP_MANTS) continue;
+        mant.push_back(m);
+    }
+    tab.assign(mant.size() * 256, 0.0f);
+    for (size_t i = 0; i < mant.size(); ++i)
+        for (uint32_t e = 1; e < 255; ++e) tab[i * 256 + e] = -std::log2(u2f((e << 23) | mant[i]));  // float overload, as state_opr.cc:57
+}
+
 void center_matrix(std::vector<float> &a, int n_in, int n_out, std::vector<int8_t> &s0, std::vector<int8_t> &s1) {
     s0.assign(n_in, 0);
     s1.assign(n_out, 0);

@@ -99,6 +99,16 @@ void cost_add(const QInt &a, const QInt &b, int64_t shift, bool sub, int adder_s
 
 // host description of the local libm's log2f for the device latency model
 Log2Table measure_log2_table();
+// -log2f of the non-power-of-two input steps of a chain, by the local libm (StepLog2 in cmvm_core.h): distinct mantissas of
+// the inputs' steps (constant-zero inputs skipped: their step is never used) and, per mantissa, 256 values indexed by the
+// biased exponent.  More than STEP_MANTS distinct mantissas: the surplus is left out and the chain reports E_FLOAT_DOMAIN if
+// such a step reaches the latency model.
+struct StepLog2Host {
+    std::vector<uint32_t> mant;
+    std::vector<float> tab;
+    void build(const QInt *q, int n_in);
+    StepLog2 view() const { return StepLog2{(int)mant.size(), mant.data(), tab.data()}; }
+};
 
 // bit_decompose.hh:25-34 on the host (needed for the m0/m1 assembly)
 void center_matrix(std::vector<float> &a, int n_in, int n_out, std::vector<int8_t> &s0, std::vector<int8_t> &s1);

@@ -13,6 +13,9 @@ def reference_style_kernel(seed, n, bits):
     return np.round((r.random((n, n)) - 0.5) * 2 ** (bits + 1)).astype(np.float32)
 
 
+METHODS = ('mc', 'mc-dc', 'mc-pdc', 'wmc', 'wmc-dc', 'wmc-pdc')
+
+
 def random_case(seed):
     """A random small matrix with a random option set, covering every method / cost-model / search combination."""
     rng = np.random.default_rng(seed)
@@ -48,6 +51,33 @@ def random_case(seed):
     return k, opts, zero_input
 
 
+def odd_step_case(seed):
+    """Input intervals whose quantisation steps are NOT powers of two (what the tracer's `variable * 3` produces, reference
+    trace/fixed_variable.py:594): steps m * 2^k with up to five different mantissas per matrix, every cost model that looks at
+    the steps, every method.  The latency model then needs -log2f(step) of the host libm for them (StepLog2, cmvm_core.h)."""
+    rng = np.random.default_rng(50_000 + seed)
+    n_in, n_out = (int(v) for v in rng.integers(2, 11, 2))
+    k = rng.integers(-64, 64, (n_in, n_out)).astype(np.float32)
+    mants = rng.choice(np.array([1.0, 3.0, 5.0, 0.3, 1.7, 6.25, 0.1], np.float32), size=int(rng.integers(1, 6)), replace=False)
+    st = (rng.choice(mants, n_in) * 2.0 ** rng.integers(-4, 3, n_in)).astype(np.float32)
+    lo = rng.integers(-40, 1, n_in)
+    hi = lo + rng.integers(1, 120, n_in)
+    opts = dict(
+        method0=str(rng.choice(METHODS)),
+        method1=str(rng.choice(['auto', 'wmc', 'mc-dc', 'wmc-pdc'])),
+        hard_dc=int(rng.choice([-1, 0, 2])),
+        decompose_dc=int(rng.choice([-2, -1, 0, 1])),
+        adder_size=int(rng.choice([1, 4, -1])),
+        carry_size=int(rng.choice([2, 8, -1])),
+        search_all_decompose_dc=bool(rng.integers(0, 2)),
+        qintervals=[(float(np.float32(a) * s), float(np.float32(c) * s), float(s)) for a, c, s in zip(lo, hi, st)],
+        latencies=[float(v) for v in rng.integers(0, 3, n_in)],
+    )
+    if opts['adder_size'] < 0 and opts['carry_size'] < 0:
+        opts['carry_size'] = 8  # at least one of the two, or the steps are never looked at
+    return k, opts
+
+
 TEST_CMVM_GRID = [
     dict(hard_dc=h, method0=m0, method1=m1, decompose_dc=d, search_all_decompose_dc=s, adder_size=1, carry_size=-1)
     for h in (0, 2, -1)
@@ -58,7 +88,6 @@ TEST_CMVM_GRID = [
 ]
 
 
-METHODS = ('mc', 'mc-dc', 'mc-pdc', 'wmc', 'wmc-dc', 'wmc-pdc')
 COST_MODELS = ((-1, -1), (1, -1), (4, 8))
 
 

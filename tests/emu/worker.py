@@ -34,6 +34,19 @@ def random_cases(lo, hi):
     out(bad=bad, n=hi - lo)
 
 
+def odd_steps(lo, hi):
+    """input steps that are not powers of two: the table-driven -log2f of the latency model (StepLog2)"""
+    from cases import odd_step_case
+
+    o = Oracle('port')
+    bad = []
+    for seed in range(lo, hi):
+        k, opts = odd_step_case(seed)
+        if hip.solve(k, **opts) != o.solve(k, **opts):
+            bad.append(seed)
+    out(bad=bad, n=hi - lo)
+
+
 def layouts():
     """both entry layouts and their boundaries: narrow u32 entries (<= 256 columns, <= 12 digits) and the wide 16-byte ones"""
     o = Oracle('port')
@@ -192,5 +205,5 @@ def dais():
 
 if __name__ == '__main__':
     what = sys.argv[1]
-    {'random': lambda: random_cases(int(sys.argv[2]), int(sys.argv[3])), 'layouts': layouts, 'batch': batch, 'retry': retry, 'big_table': big_table, 'fork': fork_after_use, 'record': lambda: record(sys.argv[2], sys.argv[3]),
+    {'random': lambda: random_cases(int(sys.argv[2]), int(sys.argv[3])), 'oddsteps': lambda: odd_steps(int(sys.argv[2]), int(sys.argv[3])), 'layouts': layouts, 'batch': batch, 'retry': retry, 'big_table': big_table, 'fork': fork_after_use, 'record': lambda: record(sys.argv[2], sys.argv[3]),
      'shard_single': shard_single, 'shard_rank': shard_rank, 'dais': dais, 'race_cases': race_cases}[what]()  # fmt: skip

@@ -40,6 +40,7 @@ template <class Cell> struct Chain {
     std::vector<std::vector<uint32_t>> collist;  // rows that have (had) digits in a column
     std::unordered_map<uint64_t, Block> table;   // key = id1 << 32 | id0
     Log2Table tab;
+    StepLog2Host step_tab;  // -log2f of non-power-of-two input steps, as the product's host builds it
     int err = 0;
     ChainStats st;
 
@@ -92,6 +93,7 @@ template <class Cell> struct Chain {
         adder = job.adder_size;
         carry = job.carry_size;
         tab = measure_log2_table();
+        step_tab.build(job.qints, job.n_in);
         std::vector<float> a(job.kernel, job.kernel + (size_t)n_in * n_out);
         center_matrix(a, n_in, n_out, out.shift0, out.shift1);
         uint32_t mx = 0;
@@ -149,7 +151,7 @@ template <class Cell> struct Chain {
         // new row record
         RowInfo ni;
         qint_add_pair(rows[A], rows[B], shift, sub, ni.lo, ni.hi, ni.step);
-        float dlat = adder_dlat(rows[A], rows[B], shift, sub, adder, carry, tab, err);
+        float dlat = adder_dlat(rows[A], rows[B], shift, sub, adder, carry, tab, step_tab.view(), err);
         ni.lat = (rows[A].lat < rows[B].lat ? rows[B].lat : rows[A].lat) + dlat;
         rows.push_back(ni);
         out.picks.insert(out.picks.end(), {(int32_t)A, (int32_t)B, sub, shift});
@@ -275,6 +277,7 @@ template <class Cell> struct ShardChain : Chain<Cell>, ShardEngine {
         this->adder = job.adder_size;
         this->carry = job.carry_size;
         this->tab = measure_log2_table();
+        this->step_tab.build(job.qints, job.n_in);
         std::vector<float> a(job.kernel, job.kernel + (size_t)job.n_in * job.n_out);
         center_matrix(a, job.n_in, job.n_out, head.shift0, head.shift1);  // centring and digit width are properties of the WHOLE matrix
         uint32_t mx = 0;
@@ -341,7 +344,7 @@ template <class Cell> struct ShardChain : Chain<Cell>, ShardEngine {
         Nw = (uint32_t)cells.size();
         RowInfo ni;
         qint_add_pair(rows[A], rows[B], shift, sub, ni.lo, ni.hi, ni.step);
-        float dlat = adder_dlat(rows[A], rows[B], shift, sub, this->adder, this->carry, this->tab, this->err);
+        float dlat = adder_dlat(rows[A], rows[B], shift, sub, this->adder, this->carry, this->tab, this->step_tab.view(), this->err);
         ni.lat = (rows[A].lat < rows[B].lat ? rows[B].lat : rows[A].lat) + dlat;
         rows.push_back(ni);
         head.picks.insert(head.picks.end(), {(int32_t)A, (int32_t)B, sub, shift});

@@ -41,6 +41,12 @@ def test_random_option_sets(emu, block):
     assert r == {'bad': [], 'n': 40}
 
 
+def test_non_power_of_two_steps(emu):
+    """quantisation steps m * 2^k (m not a power of two): the selection's latency model reads -log2f(step) from the table the host
+    built with its libm (StepLog2, cmvm_core.h) -- reference state_opr.cc:57 takes log2 of any step"""
+    assert emu('oddsteps', 0, 30) == {'bad': [], 'n': 30}
+
+
 def test_entry_layouts_and_their_boundaries(emu):
     """narrow and wide row-list entries: 12 / 13 digits, 256 / 257 columns, fractional weights, degenerate shapes"""
     assert emu('layouts')['bad'] == []

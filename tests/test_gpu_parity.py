@@ -3,7 +3,7 @@
 import numpy as np
 import pytest
 
-from cases import TEST_CMVM_GRID, int_matrix, random_case, reference_style_kernel
+from cases import TEST_CMVM_GRID, int_matrix, odd_step_case, random_case, reference_style_kernel
 
 pytestmark = pytest.mark.gpu
 
@@ -115,13 +115,27 @@ def test_layout_boundaries(hip, oracle, shape, lo, hi):
         assert np.all(got.kernel == k)
 
 
+@pytest.mark.parametrize('block', range(4))
+def test_non_power_of_two_steps(hip, oracle, block):
+    """quantisation steps that are not powers of two (reference state_opr.cc:57 takes -log2 of any step; the tracer produces them
+    for `variable * 3`): the device reads -log2f(step) from the table the host built with its libm -- same results as the oracle"""
+    for seed in range(block * 20, block * 20 + 20):
+        k, opts = odd_step_case(seed)
+        got = hip.solve(k, **opts)
+        assert got == oracle.solve(k, **opts), seed
+        assert np.all(got.kernel == k)
+
+
 def test_errors(hip):
     with pytest.raises(TypeError):
         hip.solve(np.eye(3))
     with pytest.raises(RuntimeError, match='Unknown method'):
         hip.solve(int_matrix(0, 8, 8, -8, 8), method0='nope', search_all_decompose_dc=False)
-    with pytest.raises(ValueError):
-        hip.solve(np.eye(3, dtype=np.float32), qintervals=[(-1.0, 1.0, 0.3)] * 3)
+    for bad_step in (0.0, -0.5, float('nan'), float('inf'), 1e-40):  # no logarithm the latency model could use
+        with pytest.raises(ValueError):
+            hip.solve(np.eye(3, dtype=np.float32), qintervals=[(-1.0, 1.0, bad_step)] * 3)
+    with pytest.raises(ValueError, match='distinct'):  # more than STEP_MANTS = 8 different non-power-of-two mantissas
+        hip.solve(np.ones((9, 2), dtype=np.float32), qintervals=[(-8.0, 8.0, 1.0 + 0.1 * (i + 1)) for i in range(9)])
 
 
 def test_capacity_retry(oracle):

@@ -19,6 +19,15 @@ def test_random_cases(model, oracle, block):
             assert np.all(got.kernel == k)
 
 
+def test_non_power_of_two_steps(model, oracle):
+    """the engine model runs the same inline latency model as the kernels (cmvm_core.h) with the same host-built -log2f table"""
+    from cases import odd_step_case
+
+    for seed in range(40):
+        k, opts = odd_step_case(seed)
+        assert model.solve(k, **opts) == oracle.solve(k, **opts), seed
+
+
 @pytest.mark.parametrize('n,bits', [(2, 2), (4, 4), (8, 8), (8, 4)])
 def test_reference_grid(model, oracle, n, bits):
     k = reference_style_kernel(n * 10 + bits, n, bits)

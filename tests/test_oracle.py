@@ -74,6 +74,11 @@ def test_port_equals_reference_build(oracle):
         assert all(np.array_equal(a, b) for a, b in zip(oracle.csd_decompose(k), ref.csd_decompose(k)))
         for dc in (-2, -1, 0, 1, 2):
             assert all(np.array_equal(a, b) for a, b in zip(oracle.kernel_decompose(k, dc), ref.kernel_decompose(k, dc)))
+    from cases import odd_step_case
+
+    for seed in range(40):  # quantisation steps that are not powers of two (state_opr.cc:57 takes log2 of any step)
+        k, opts = odd_step_case(seed)
+        assert oracle.solve(k, **opts) == ref.solve(k, **opts), seed
 
 
 def test_large_records_of_the_restatement_match_the_reference_build():
