@@ -27,7 +27,7 @@ _i32p = np.ctypeslib.ndpointer(np.int32, flags='C_CONTIGUOUS')
 
 EXPORTS = (
     'da_last_error da_last_error_code da_version da_device_count da_set_device da_get_lsb_loc da_iceil_log2 da_cost_add da_int_arr_to_csd '
-    'da_csd_decompose da_kernel_decompose da_solve da_solve_batch da_solve_sharded da_n_stages da_picked da_stage_info da_stage_copy '
+    'da_csd_decompose da_kernel_decompose da_solve da_solve_batch da_solve_sharded da_comm_abort da_n_stages da_picked da_stage_info da_stage_copy '
     'da_result_stats da_free da_timings da_engine_stats da_dais_run da_dais_last_error da_dais_run_on'
 ).split()
 
@@ -247,6 +247,12 @@ def solve_sharded(kernel, method0: str = 'wmc', method1: str = 'auto', hard_dc: 
     if not h:
         _raise(lib().da_last_error_code())
     return _collect(h), dict(zip(('sharded_chains', 'greedy_steps', 'allreduce_calls'), st.tolist()))
+
+
+def comm_abort():
+    """To be called by the owner of the all-reduce callback when a collective failed: the running ``solve_sharded`` stops at
+    its next exchange with a RuntimeError instead of going on with a buffer that was not reduced."""
+    lib().da_comm_abort()
 
 
 def solve_many(

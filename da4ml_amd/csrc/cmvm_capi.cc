@@ -6,6 +6,7 @@
 #include <chrono>
 #include <cstdio>
 #include <algorithm>
+#include <atomic>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -183,8 +184,11 @@ da_result *da_solve(const float *kernel, int64_t n_in, int64_t n_out, const char
     return rc == DA_OK ? r : nullptr;
 }
 
-static std::unique_ptr<da::ShardEngine> make_hip_shard(const da::ChainJob &job, int c0, int c1, void *ctx) {
-    return static_cast<da::gpu::HipBackend *>(ctx)->make_shard_engine(job, c0, c1);
+static std::atomic<int> g_comm_aborted{0};
+void da_comm_abort(void) { g_comm_aborted.store(1); }
+
+static std::unique_ptr<da::ShardEngine> make_hip_shard(const da::ChainJob &job, int c0, int c1, double capacity_scale, void *ctx) {
+    return static_cast<da::gpu::HipBackend *>(ctx)->make_shard_engine(job, c0, c1, capacity_scale);
 }
 
 da_result *da_solve_sharded(const float *kernel, int64_t n_in, int64_t n_out, const char *method0, const char *method1, int hard_dc,
@@ -217,6 +221,8 @@ da_result *da_solve_sharded(const float *kernel, int64_t n_in, int64_t n_out, co
         comm.world = world;
         comm.allreduce = allreduce;
         comm.ctx = ctx;
+        g_comm_aborted.store(0);
+        comm.aborted = &g_comm_aborted;
         da::ShardedBackend be(inner, comm, make_hip_shard, &inner);
         be.force_single = std::getenv("DA4ML_SHARD_FORCE") != nullptr;
         std::vector<da::ChainStats> stats;

@@ -1327,6 +1327,7 @@ template <class Cell, bool SHARDED = false> __device__ __forceinline__ int selec
             const uint32_t b = (s_bits[w >> 3] >> ((w & 7) * 4)) & 0xFu;
             flags[w] = (int32_t)((b & 1u) | ((b & 2u) << 7) | ((b & 4u) << 14) | ((b & 8u) << 21));
         }
+        if (tid < SHARD_TRAILER) flags[(int)((Nw + 3) / 4) + tid] = 0;  // status trailer of a rank that took the step (cmvm_shard.h)
     }
     if (tid == 0) {
         SEL_TIMER_FLUSH
@@ -3175,7 +3176,7 @@ class HipShardEngine : public ShardEngine {
         local.n_out = n_loc_;
         ChainDev tmp;
         const size_t chain_bytes = carve_chain(nullptr, local, g, tmp);
-        const size_t init_b = align_up((size_t)n_pairs_ * g.K * 4, 256), flag_b = align_up(((size_t)g.rcap + 3) / 4 * 4 + 64, 256),
+        const size_t init_b = align_up((size_t)n_pairs_ * g.K * 4, 256), flag_b = align_up((((size_t)g.rcap + 3) / 4 + SHARD_TRAILER) * 4 + 64, 256),
                      uni_b = align_up((size_t)g.rcap * 4, 256), slab_b = align_up((size_t)(6 + 3 * (size_t)g.rcap) * g.K * 4, 256);
         arena_.get(chain_bytes + init_b + flag_b + uni_b + slab_b);
         unsigned char *a = static_cast<unsigned char *>(arena_.ptr);
@@ -3255,22 +3256,38 @@ class HipShardEngine : public ShardEngine {
             hipLaunchKernelGGL(k_cs_init_table<uint64_t>, grid, dim3(256), 0, st_, dd_);
         HIP_CHECK(hipGetLastError());
     }
-    bool select(int32_t *&flags, int64_t &fcount) override {
-        if (!geo_.wide)
-            hipLaunchKernelGGL((k_iter_select<uint32_t, true>), dim3(1), dim3(SEL_THREADS), sel_lds_, st_, dd_, d_done_);
-        else
-            hipLaunchKernelGGL((k_iter_select<uint64_t, true>), dim3(1), dim3(SEL_THREADS), sel_lds_, st_, dd_, d_done_);
-        pull();
-        if (d_.done) return false;
+    void select(int32_t *&flags, int64_t &fcount) override {
+        if (!d_.done) {
+            if (!geo_.wide)
+                hipLaunchKernelGGL((k_iter_select<uint32_t, true>), dim3(1), dim3(SEL_THREADS), sel_lds_, st_, dd_, d_done_);
+            else
+                hipLaunchKernelGGL((k_iter_select<uint64_t, true>), dim3(1), dim3(SEL_THREADS), sel_lds_, st_, dd_, d_done_);
+            pull();
+        }
+        // rows before this step: the new row's id where the step was taken, the unchanged row count where the chain has stopped
+        fw_ = flag_words(d_.done ? d_.n_rows : (int)d_.Nw);
+        if (d_.done) {  // finished or failed: zero flags and the trailer {1, capacity error?, other error?} -- the rank still takes part in the exchange
+            trailer_[0] = 1;
+            trailer_[1] = is_capacity_error(d_.error) ? 1 : 0;
+            trailer_[2] = d_.error != E_OK && !is_capacity_error(d_.error) ? 1 : 0;
+            HIP_CHECK(hipMemsetAsync(d_.cs_flags, 0, (size_t)fw_ * 4, st_));
+            HIP_CHECK(hipMemcpyAsync(d_.cs_flags + fw_, trailer_, sizeof trailer_, hipMemcpyHostToDevice, st_));
+            sync();
+        }
         flags = d_.cs_flags;
-        fcount = flag_words((int)d_.Nw);
-        return true;
+        fcount = fw_ + SHARD_TRAILER;
     }
-    int32_t *partial(int64_t &scount) override {
-        hipLaunchKernelGGL(k_cs_union, dim3(1), dim3(1024), 0, st_, dd_);
+    int32_t *partial(int64_t &scount, int32_t status[SHARD_TRAILER]) override {
+        HIP_CHECK(hipMemcpyAsync(trailer_, d_.cs_flags + fw_, sizeof trailer_, hipMemcpyDeviceToHost, st_));  // the summed status, with the union's size
         int nuni = 0;
-        HIP_CHECK(hipMemcpyAsync(&nuni, &dd_->cs_nuni, sizeof(int), hipMemcpyDeviceToHost, st_));
+        if (!d_.done) {
+            hipLaunchKernelGGL(k_cs_union, dim3(1), dim3(1024), 0, st_, dd_);
+            HIP_CHECK(hipMemcpyAsync(&nuni, &dd_->cs_nuni, sizeof(int), hipMemcpyDeviceToHost, st_));
+        }
         sync();
+        for (int q = 0; q < SHARD_TRAILER; ++q) status[q] = trailer_[q];
+        scount = 0;
+        if (status[0] != 0) return nullptr;
         nuni_ = nuni;
         if (nuni > 0) {
             const dim3 grid((unsigned)((nuni + 3) / 4));
@@ -3345,6 +3362,8 @@ class HipShardEngine : public ShardEngine {
     }
     hipStream_t st_;
     StepLog2Host step_tab_;
+    int64_t fw_ = 0;                      // flag words of the current step (the status trailer follows them)
+    int32_t trailer_[SHARD_TRAILER] = {0, 0, 0};
     int device_;
     ChainJob job_;
     int n_loc_;  // columns of this rank (the first of them is d_.col0)
@@ -3360,8 +3379,8 @@ class HipShardEngine : public ShardEngine {
 
 }  // namespace
 
-std::unique_ptr<ShardEngine> HipBackend::make_shard_engine(const ChainJob &job, int c0, int c1) {
-    return std::unique_ptr<ShardEngine>(new HipShardEngine(impl_->stream, impl_->device, job, c0, c1, impl_->table_scale, row_scale_));
+std::unique_ptr<ShardEngine> HipBackend::make_shard_engine(const ChainJob &job, int c0, int c1, double capacity_scale) {
+    return std::unique_ptr<ShardEngine>(new HipShardEngine(impl_->stream, impl_->device, job, c0, c1, impl_->table_scale * capacity_scale, row_scale_ * capacity_scale));
 }
 
 void HipBackend::column_distances(const int32_t *aug, int n_in, int W, int64_t *d0, int64_t *d1) {

@@ -55,7 +55,7 @@ class HipBackend : public Backend {
     void *stream() const;  // hipStream_t the kernels are launched on
     // one greedy chain on the columns [c0, c1) of its matrix, pair table replicated (cmvm_shard.h); the engine lives on
     // this backend's device and stream and must not outlive it
-    std::unique_ptr<ShardEngine> make_shard_engine(const ChainJob &job, int c0, int c1);
+    std::unique_ptr<ShardEngine> make_shard_engine(const ChainJob &job, int c0, int c1, double capacity_scale = 1.0);
 
   private:
     struct Impl;

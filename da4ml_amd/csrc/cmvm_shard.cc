@@ -22,34 +22,54 @@ void ShardedBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
 void ShardedBackend::run_one(const ChainJob &job, ChainOut &out) {
     int c0, c1;
     shard_columns(job.n_out, comm_.rank, comm_.world, c0, c1);
-    std::unique_ptr<ShardEngine> eng = make_(job, c0, c1, ctx_);
-    const bool dev = eng->on_device();
     ++sharded_chains;
+    std::unique_ptr<ShardEngine> eng;
+    int32_t status[SHARD_TRAILER] = {0, 0, 0};
+    double scale = 1.0;
+    for (int attempt = 0;; ++attempt) {
+        // the arena sizes are heuristics (as in HipBackend::run_chains): a capacity error reruns the chain with four times the
+        // capacities, at most three times.  The decision comes from the SUMMED status words, so every rank takes it together.
+        eng = make_(job, c0, c1, scale, ctx_);
+        const bool dev = eng->on_device();
 
-    // initial pair counts: partial over the own columns, summed over the ranks
-    int64_t count = 0;
-    int32_t *buf = eng->init_counts(count);
-    comm_.sum(buf, count, dev);
-    eng->init_table();
+        // initial pair counts: partial over the own columns, summed over the ranks
+        int64_t count = 0;
+        int32_t *buf = eng->init_counts(count);
+        comm_.sum(buf, count, dev);
+        eng->init_table();
 
-    // greedy loop: two exchanges per step
-    while (true) {
-        int32_t *flags = nullptr;
-        int64_t fcount = 0;
-        if (!eng->select(flags, fcount)) break;  // identical decision on every rank: the table is replicated
-        comm_.sum(flags, fcount, dev);
-        int64_t scount = 0;
-        int32_t *slab = eng->partial(scount);
-        comm_.sum(slab, scount, dev);
-        eng->apply();
-        ++sharded_steps;
+        // greedy loop: two exchanges per step; the first one carries every rank's status (SHARD_TRAILER)
+        while (true) {
+            int32_t *flags = nullptr;
+            int64_t fcount = 0;
+            eng->select(flags, fcount);
+            comm_.sum(flags, fcount, dev);
+            int64_t scount = 0;
+            int32_t *slab = eng->partial(scount, status);
+            if (status[0] != 0) break;  // the chain is finished (the table is replicated: on every rank in the same step) or somebody failed
+            comm_.sum(slab, scount, dev);
+            eng->apply();
+            ++sharded_steps;
+        }
+        if (status[1] != 0 && status[2] == 0 && attempt < 3) {
+            scale *= 4.0;
+            ++capacity_retries;
+            continue;
+        }
+        break;
     }
+    const bool failed = status[1] != 0 || status[2] != 0 || status[0] != comm_.world;
 
     // merge: everything row-related is already global; the surviving digits of the other ranks' columns come in by
     // all-reduce(sum) of buffers in which every rank fills its own segment
     ChainOut own;
     eng->finish(own);
     out = ChainOut{};
+    if (failed) {  // known to every rank from the same summed words: nobody enters the merge exchanges
+        out.error = own.error ? own.error : (status[1] ? E_TABLE_CAPACITY : E_LIST_CAPACITY);
+        out.n_bits = own.n_bits;
+        return;
+    }
     out.error = own.error;
     out.unknown_method_hit = own.unknown_method_hit;
     out.n_bits = own.n_bits;

@@ -17,8 +17,10 @@
 // names it.  The instance-sharded layout (multi_gpu.solve_many_sharded) is the one that scales.
 #pragma once
 
+#include <atomic>
 #include <cstdint>
 #include <memory>
+#include <stdexcept>
 
 #include "cmvm_host.h"
 
@@ -34,8 +36,12 @@ struct ShardComm {
     allreduce_i32_fn allreduce = nullptr;
     void *ctx = nullptr;
     long long calls = 0, elements = 0;  // statistics
+    // set by the callback's owner when a collective failed (the callback itself returns nothing and must not unwind through
+    // this code): the chain stops at once instead of going on with a buffer that was not reduced
+    std::atomic<int> *aborted = nullptr;
     void sum(void *buf, int64_t count, bool on_device) {
         if (world > 1 && count > 0) allreduce(ctx, buf, count, on_device ? 1 : 0);
+        if (aborted && aborted->exchange(0)) throw std::runtime_error("the all-reduce callback reported a failed collective");
         ++calls;
         elements += count;
     }
@@ -47,6 +53,13 @@ inline void shard_columns(int n_out, int rank, int world, int &c0, int &c1) {
 }
 // 8-bit fields of the flag words: four rows per int32, summed over <= 255 ranks without carry between fields
 inline int64_t flag_words(int n_rows) { return (n_rows + 3) / 4; }
+// The flag buffer of a step ends in a STATUS TRAILER of three words, summed over the ranks with the flags -- no extra collective:
+// {ranks that have stopped, of which with a capacity error (row / table / list arena), of which with any other error}.  Every
+// rank takes part in the flag exchange of every step, also one that has stopped (all flags zero): a rank-local error can
+// therefore not leave the others waiting in a collective, and every rank takes the same decision (stop, or retry with larger
+// arenas) from the same summed words.
+constexpr int SHARD_TRAILER = 3;
+inline bool is_capacity_error(int e) { return e == E_ROW_CAPACITY || e == E_TABLE_CAPACITY || e == E_LIST_CAPACITY; }
 
 // One chain on one rank's columns.  Buffers handed out by the engine live where `on_device()` says.
 class ShardEngine {
@@ -57,19 +70,23 @@ class ShardEngine {
     // partial counts of all pairs of input rows (i0 <= i1, index i1 (i1+1)/2 + i0) over the own columns: int32 [n_pairs][K]
     virtual int32_t *init_counts(int64_t &count) = 0;
     virtual void init_table() = 0;  // from the (summed) buffer returned by init_counts
-    // phase 1 of a greedy step: arg-max on the replicated table, substitution in the own columns.  Returns false when
-    // the chain is finished.  flags: packed 8-bit fields, field r != 0 <=> row r shares a substituted column here.
-    virtual bool select(int32_t *&flags, int64_t &flag_count) = 0;
+    // phase 1 of a greedy step: arg-max on the replicated table, substitution in the own columns.  ALWAYS hands out the flag
+    // buffer of the step: flag_words(rows before the step) words of packed 8-bit fields (field r != 0 <=> row r shares a
+    // substituted column here) followed by the status trailer; an engine that has finished or failed hands out zero flags and
+    // the trailer {1, capacity error?, other error?}.
+    virtual void select(int32_t *&flags, int64_t &flag_count) = 0;
     // phase 2: from the summed flags, the union of partner rows (ascending ids, identical on every rank) and this
     // rank's partial count changes: slab int32 [(6 + 3 n_union)][K] = the six pairs among {A, B, new} (AA, AB, BB, AN, BN,
-    // NN), then per partner {lost with A, lost with B, gained with the new row}
-    virtual int32_t *partial(int64_t &slab_count) = 0;
+    // NN), then per partner {lost with A, lost with B, gained with the new row}.  status = the summed trailer; when
+    // status[0] != 0 (somebody has stopped) nothing is computed and nullptr is returned.
+    virtual int32_t *partial(int64_t &slab_count, int32_t status[SHARD_TRAILER]) = 0;
     virtual void apply() = 0;  // phase 3: the summed slab into the table
     // own columns of the finished chain (col_start covers the own columns only; everything row-related is global)
     virtual void finish(ChainOut &own) = 0;
 };
 
-using ShardEngineFactory = std::unique_ptr<ShardEngine> (*)(const ChainJob &job, int c0, int c1, void *factory_ctx);
+// capacity_scale multiplies the engine's arena heuristics (1 on the first attempt, x 4 per retry after a capacity error)
+using ShardEngineFactory = std::unique_ptr<ShardEngine> (*)(const ChainJob &job, int c0, int c1, double capacity_scale, void *factory_ctx);
 
 // Backend whose chains are column-sharded; everything else (stage-1 distances, decompositions, chains that cannot be
 // sharded: fewer columns than ranks, the "dummy" method) goes to `inner`, replicated on every rank.
@@ -85,7 +102,7 @@ class ShardedBackend : public Backend {
     }
     int int_to_csd(const int32_t *x, int64_t n, std::vector<int8_t> &csd) override { return inner_.int_to_csd(x, n, csd); }
     const ShardComm &comm() const { return comm_; }
-    long long sharded_chains = 0, sharded_steps = 0;
+    long long sharded_chains = 0, sharded_steps = 0, capacity_retries = 0;
     bool force_single = false;  // test aid: run the sharded phases with a single rank too (the exchanges are no-ops)
 
   private:

@@ -270,11 +270,13 @@ class _DeviceView:
         self.__cuda_array_interface__ = {'shape': (int(count),), 'typestr': '<i4', 'data': (int(ptr), False), 'version': 2}
 
 
-def make_allreduce_callback(device):
+def make_allreduce_callback(device, abort=None):
     """C callback ``void(ctx, buf, count, on_device)`` = in-place all-reduce(sum) of int32 over the process group: the one
     collective a column-sharded chain uses (``csrc/cmvm_shard.h``).  RCCL (backend ``nccl``) works on device memory
     directly; with ``gloo`` (CPU tests, or several ranks sharing one GPU) device buffers are staged through the host.
-    Returns (callback object -- keep it alive during the solve --, list collecting exceptions raised inside it)."""
+    Returns (callback object -- keep it alive during the solve --, list collecting exceptions raised inside it).
+    ``abort``: called after an exception inside the callback (``_binary.comm_abort``): the C side then stops at once -- an
+    exception cannot unwind through it, and going on with a buffer that was not reduced would desynchronise the ranks."""
     import ctypes as C
 
     import numpy as np
@@ -306,6 +308,8 @@ def make_allreduce_callback(device):
                     dist.all_reduce(t)
         except BaseException as e:  # an exception must not unwind through the C caller
             errors.append(e)
+            if abort is not None:
+                abort()
 
     return FN(allreduce), errors
 
@@ -328,10 +332,20 @@ def solve_column_sharded(kernel, method0: str = 'wmc', method1: str = 'auto', ha
         if _binary.device_count() > 0:
             _binary.set_device(local % _binary.device_count())
         sharded_solver = _binary.solve_sharded
-    cb, errors = make_allreduce_callback(device)
-    pipe, stats = sharded_solver(kernel, method0=method0, method1=method1, hard_dc=hard_dc, decompose_dc=decompose_dc, qintervals=qintervals,
-                                 latencies=latencies, adder_size=adder_size, carry_size=carry_size, search_all_decompose_dc=search_all_decompose_dc,
-                                 rank=rank, world=world, allreduce=cb)  # fmt: skip
+    abort = getattr(getattr(sharded_solver, '__self__', None), 'comm_abort', None)  # the engine model's, when the CPU tests inject it
+    if abort is None:
+        from . import _binary
+
+        abort = _binary.comm_abort
+    cb, errors = make_allreduce_callback(device, abort)
+    try:
+        pipe, stats = sharded_solver(kernel, method0=method0, method1=method1, hard_dc=hard_dc, decompose_dc=decompose_dc, qintervals=qintervals,
+                                     latencies=latencies, adder_size=adder_size, carry_size=carry_size, search_all_decompose_dc=search_all_decompose_dc,
+                                     rank=rank, world=world, allreduce=cb)  # fmt: skip
+    except RuntimeError:
+        if errors:  # the collective's own exception, not the library's "callback reported a failure"
+            raise errors[0] from None
+        raise
     if errors:
         raise errors[0]
     return (pipe, stats) if return_stats else pipe

@@ -88,6 +88,10 @@ typedef void (*da_allreduce_i32)(void *ctx, void *buf, int64_t count, int on_dev
 da_result *da_solve_sharded(const float *kernel, int64_t n_in, int64_t n_out, const char *method0, const char *method1, int hard_dc,
                             int decompose_dc, const float *qintervals, const float *latencies, int adder_size, int carry_size,
                             int search_all_decompose_dc, int rank, int world, da_allreduce_i32 allreduce, void *ctx, int64_t *stats3);
+/* To be called by the all-reduce callback's owner when a collective failed (the callback returns nothing and must not unwind
+ * through the library): the running da_solve_sharded stops at the next exchange and fails with a runtime error instead of
+ * continuing with a buffer that was not reduced. */
+void da_comm_abort(void);
 
 /* ---- result access (da4ml.types.Pipeline / CombLogic / Op, bindings.cc:106-151) ---------------------------- */
 int da_n_stages(const da_result *r);

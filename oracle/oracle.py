@@ -205,7 +205,13 @@ class Oracle:
         h = fn(k, n_in, n_out, method0.encode(), method1.encode(), hard_dc, decompose_dc, None if q is None else q.ctypes.data,
                None if l is None else l.ctypes.data, adder_size, carry_size, int(search_all_decompose_dc), rank, world,
                C.cast(allreduce, C.c_void_p), None, st)  # fmt: skip
+        if not h:
+            raise RuntimeError('column-sharded solve of the engine model failed')
         return self._collect(h), dict(zip(('sharded_chains', 'greedy_steps', 'allreduce_calls'), st.tolist()))
+
+    def comm_abort(self):
+        """what an all-reduce callback's owner calls when a collective failed (the model's da_comm_abort)"""
+        self.lib.mdl_comm_abort()
 
     def chains_run(self, reset=True) -> int:
         """Chains handed to the model backend since the last reset ('model' only)."""

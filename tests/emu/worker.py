@@ -135,6 +135,15 @@ def shard_single():
     out(bad=bad)
 
 
+def shard_retry():
+    """column-sharded chain with arena heuristics far too small: the capacity error travels in the status trailer of the flag
+    exchange, every rank reruns with four times the capacities (ShardedBackend::run_one) -- the result is the oracle's"""
+    o = Oracle('port')
+    k = int_matrix(0, 20, 20, -128, 128)
+    p, st = hip.solve_sharded(k, **SINGLE)
+    out(equal=p == o.solve(k, **SINGLE), chains=st['sharded_chains'], steps=st['greedy_steps'], calls=st['allreduce_calls'])
+
+
 def shard_rank():
     """one rank of a gloo job: the HIP shard engine of every rank runs on its own emulated device"""
     import ctypes as C
@@ -206,4 +215,4 @@ def dais():
 if __name__ == '__main__':
     what = sys.argv[1]
     {'random': lambda: random_cases(int(sys.argv[2]), int(sys.argv[3])), 'oddsteps': lambda: odd_steps(int(sys.argv[2]), int(sys.argv[3])), 'layouts': layouts, 'batch': batch, 'retry': retry, 'big_table': big_table, 'fork': fork_after_use, 'record': lambda: record(sys.argv[2], sys.argv[3]),
-     'shard_single': shard_single, 'shard_rank': shard_rank, 'dais': dais, 'race_cases': race_cases}[what]()  # fmt: skip
+     'shard_single': shard_single, 'shard_retry': shard_retry, 'shard_rank': shard_rank, 'dais': dais, 'race_cases': race_cases}[what]()  # fmt: skip

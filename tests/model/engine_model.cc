@@ -11,6 +11,7 @@
 // It is never linked into the product library.
 
 #include <algorithm>
+#include <atomic>
 #include <cstring>
 #include <map>
 #include <string>
@@ -336,9 +337,18 @@ template <class Cell> struct ShardChain : Chain<Cell>, ShardEngine {
             for (int i0 = 0; i0 <= i1; ++i0) put_block(i0, i1, buf.data() + ((size_t)i1 * (i1 + 1) / 2 + i0) * K);
         st.blocks0 = (int64_t)table.size();
     }
-    bool select(int32_t *&fl, int64_t &fcount) override {
+    bool stopped = false;
+    void select(int32_t *&fl, int64_t &fcount) override {
         int idx;
-        if (!Base::select(A, B, idx)) return false;
+        if (stopped || !Base::select(A, B, idx)) {  // finished (or failed): zero flags + status trailer, the rank still takes part in the exchange
+            stopped = true;
+            flags.assign((size_t)flag_words((int)cells.size()) + SHARD_TRAILER, 0);
+            flags[flags.size() - 3] = 1;
+            flags[flags.size() - 1] = this->err ? 1 : 0;
+            fl = flags.data();
+            fcount = (int64_t)flags.size();
+            return;
+        }
         int shift, sub;
         key_decode(idx, N, shift, sub);
         Nw = (uint32_t)cells.size();
@@ -364,7 +374,7 @@ template <class Cell> struct ShardChain : Chain<Cell>, ShardEngine {
             MB.push_back(mb);
             st.matches += popc32(O::plus(ma) | O::minus(ma));
         }
-        flags.assign((size_t)flag_words((int)Nw), 0);
+        flags.assign((size_t)flag_words((int)Nw) + SHARD_TRAILER, 0);
         for (int j : mcol)
             for (uint32_t r : collist[j])
                 if (r != A && r != B) flags[r >> 2] |= 1 << (8 * (r & 3));
@@ -372,9 +382,11 @@ template <class Cell> struct ShardChain : Chain<Cell>, ShardEngine {
         st.iterations++;
         fl = flags.data();
         fcount = (int64_t)flags.size();
-        return true;
     }
-    int32_t *partial(int64_t &scount) override {
+    int32_t *partial(int64_t &scount, int32_t status[SHARD_TRAILER]) override {
+        for (int q = 0; q < SHARD_TRAILER; ++q) status[q] = flags[flags.size() - SHARD_TRAILER + q];
+        scount = 0;
+        if (status[0] != 0) return nullptr;
         uni.clear();
         for (uint32_t r = 0; r < Nw; ++r)
             if ((flags[r >> 2] >> (8 * (r & 3))) & 0xFF) uni.push_back(r);
@@ -456,7 +468,7 @@ template <class Cell> struct ShardChain : Chain<Cell>, ShardEngine {
     }
 };
 
-std::unique_ptr<ShardEngine> make_model_shard(const ChainJob &job, int c0, int c1, void *) {
+std::unique_ptr<ShardEngine> make_model_shard(const ChainJob &job, int c0, int c1, double, void *) {
     std::vector<float> a(job.kernel, job.kernel + (size_t)job.n_in * job.n_out);
     std::vector<int8_t> s0, s1;
     center_matrix(a, job.n_in, job.n_out, s0, s1);
@@ -624,6 +636,8 @@ int mdl_solve_batch(int count, const float *const *kernels, const int64_t *n_in,
 }
 // One solve with every greedy chain column-sharded over the ranks of the caller's process group (the shape of
 // da_solve_sharded): `allreduce` is called for every exchange; stats3 = {sharded chains, greedy steps, all-reduce calls}.
+static std::atomic<int> g_mdl_comm_aborted{0};
+void mdl_comm_abort(void) { g_mdl_comm_aborted.store(1); }
 void *mdl_solve_sharded(const float *kernel, int64_t n_in, int64_t n_out, const char *method0, const char *method1, int hard_dc,
                         int decompose_dc, const float *qints3, const float *lats, int adder_size, int carry_size, int search_all,
                         int rank, int world, da::allreduce_i32_fn allreduce, void *ctx, int64_t *stats3) {
@@ -634,6 +648,8 @@ void *mdl_solve_sharded(const float *kernel, int64_t n_in, int64_t n_out, const 
         comm.world = world;
         comm.allreduce = allreduce;
         comm.ctx = ctx;
+        g_mdl_comm_aborted.store(0);
+        comm.aborted = &g_mdl_comm_aborted;
         da::ShardedBackend be(inner, comm, make_model_shard, nullptr);
         da::Problem p;
         p.kernel = kernel;

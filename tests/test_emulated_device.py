@@ -93,6 +93,14 @@ def test_column_sharded_engine_single_rank(emu):
     assert emu('shard_single', env=dict(DA4ML_SHARD_FORCE='1'))['bad'] == []
 
 
+def test_column_sharded_capacity_retry(emu):
+    """the sharded path retries on a capacity error like the ordinary one (it used to fail where da_solve succeeds)"""
+    ok = emu('shard_retry', env=dict(DA4ML_SHARD_FORCE='1'))
+    r = emu('shard_retry', env=dict(DA4ML_SHARD_FORCE='1', DA4ML_HIP_TABLE_SCALE='0.02', DA4ML_HIP_ROW_SCALE='0.05'))
+    assert ok['equal'] and r['equal'] and r['chains'] == ok['chains']
+    assert r['steps'] > ok['steps'] and r['calls'] > ok['calls']  # the aborted attempt's steps and exchanges are counted too
+
+
 def test_column_sharded_engine_two_ranks_gloo(emu, tmp_path):
     """two processes, each with its own emulated device, exchanging the slabs over gloo: the product's sharded engine and
     orchestration end to end, bit-identical to the single-process result on every rank"""

@@ -241,3 +241,33 @@ def test_init_needs_a_port_from_the_launcher(monkeypatch):
     monkeypatch.delenv('MASTER_PORT', raising=False)
     with pytest.raises(RuntimeError, match='MASTER_PORT'):
         multi_gpu.init('gloo')
+
+
+def test_failed_collective_stops_the_sharded_solve(model, monkeypatch):
+    """A collective that raises inside the all-reduce callback (a peer died, a timeout) cannot unwind through the C code; the
+    callback reports it (`comm_abort`) and the solve stops at that very exchange with the collective's own exception -- it used
+    to go on with a buffer that was not reduced and raise only after the whole solve (if the peers ever let it finish)."""
+    import numpy as np
+    import torch.distributed as dist
+    from cases import int_matrix
+
+    from da4ml_amd import multi_gpu as mg
+
+    calls = {'n': 0}
+
+    def failing_all_reduce(t, *a, **kw):
+        calls['n'] += 1
+        if calls['n'] == 5:
+            raise TimeoutError('simulated collective failure')
+
+    monkeypatch.setattr(mg, 'init', lambda *a, **kw: (0, 2, 0, __import__('torch').device('cpu')))  # pretend to be rank 0 of 2
+    monkeypatch.setattr(dist, 'all_reduce', failing_all_reduce)
+    monkeypatch.setattr(dist, 'is_initialized', lambda: False)
+    k = int_matrix(0, 16, 16, -128, 128)
+    with pytest.raises(TimeoutError, match='simulated collective failure'):
+        mg.solve_column_sharded(k, sharded_solver=model.solve_sharded, method0='wmc', method1='wmc', decompose_dc=-1, search_all_decompose_dc=False)
+    assert calls['n'] == 5  # no further exchange after the failed one
+    # the library is usable afterwards (one rank: no peer whose contribution the fake collective would have to supply)
+    monkeypatch.setattr(mg, 'init', lambda *a, **kw: (0, 1, 0, __import__('torch').device('cpu')))
+    p = mg.solve_column_sharded(k, sharded_solver=model.solve_sharded, method0='wmc', method1='wmc', decompose_dc=-1, search_all_decompose_dc=False)
+    assert np.all(p.kernel == k)
