@@ -78,8 +78,11 @@ def launch_ranks(n: int) -> int:
         procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve()), *sys.argv[1:]], env=e,
                                       stdout=None if r == 0 else subprocess.DEVNULL))  # fmt: skip
     rc = 0
-    for p in procs:
-        rc = rc or p.wait()
+    for r, p in enumerate(procs):  # stderr of every rank is inherited (visible); name the rank that failed
+        code = p.wait()
+        if code != 0:
+            print(f'bench.py: rank {r} of {n} exited with code {code}', file=sys.stderr, flush=True)
+        rc = rc or code
     return rc
 
 

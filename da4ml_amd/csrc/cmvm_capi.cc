@@ -5,6 +5,8 @@
 #include <cstdlib>
 #include <chrono>
 #include <cstdio>
+#include <pthread.h>
+
 #include <algorithm>
 #include <atomic>
 #include <cstring>
@@ -22,7 +24,29 @@ namespace {
 
 thread_local std::string g_err;
 thread_local int g_err_code = DA_OK;  // DA_ERR_* of the calling thread's last failure (da_last_error_code)
-std::mutex g_mutex;
+// The library lock.  fork(): taken before the fork and released on both sides, so that a child never inherits it locked by a
+// thread that does not exist there (its first call would hang); a thread that forks while it holds the lock itself -- from
+// inside the all-reduce callback -- keeps it through the fork.
+struct LibraryMutex {
+    std::mutex m;
+    static thread_local bool mine;
+    void lock() {
+        m.lock();
+        mine = true;
+    }
+    void unlock() {
+        mine = false;
+        m.unlock();
+    }
+    LibraryMutex() {
+        pthread_atfork([] { if (!mine) instance->m.lock(); }, [] { if (!mine) instance->m.unlock(); }, [] { if (!mine) instance->m.unlock(); });
+        instance = this;
+    }
+    static LibraryMutex *instance;
+};
+thread_local bool LibraryMutex::mine = false;
+LibraryMutex *LibraryMutex::instance = nullptr;
+LibraryMutex g_mutex;
 int g_device = 0;
 std::unique_ptr<da::gpu::HipBackend> g_backend;
 int g_backend_device = -1;
@@ -80,7 +104,7 @@ int da_last_error_code(void) { return g_err_code; }
 const char *da_version(void) { return "da4ml_hip 0.1 (gfx950)"; }
 int da_device_count(void) { return da::gpu::device_count(); }
 int da_set_device(int device) {
-    std::lock_guard<std::mutex> lk(g_mutex);
+    std::lock_guard<LibraryMutex> lk(g_mutex);
     if (device < 0 || device >= da::gpu::device_count()) {
         g_err = "invalid device index " + std::to_string(device);
         return g_err_code = DA_ERR_NO_DEVICE;
@@ -97,7 +121,7 @@ int da_cost_add(const float *q0, const float *q1, int64_t shift, int sub, int ad
 }
 
 int da_int_arr_to_csd(const int32_t *x, int64_t n, int8_t *out) {
-    std::lock_guard<std::mutex> lk(g_mutex);
+    std::lock_guard<LibraryMutex> lk(g_mutex);
     try {
         std::vector<int8_t> csd;
         int N = backend().int_to_csd(x, n, csd);
@@ -109,7 +133,7 @@ int da_int_arr_to_csd(const int32_t *x, int64_t n, int8_t *out) {
 }
 
 int da_csd_decompose(const float *kernel, int64_t n_in, int64_t n_out, int center, int8_t *csd, int8_t *shift0, int8_t *shift1) {
-    std::lock_guard<std::mutex> lk(g_mutex);
+    std::lock_guard<LibraryMutex> lk(g_mutex);
     try {
         std::vector<int8_t> c, a, b;
         int N = backend().csd_decompose(kernel, (int)n_in, (int)n_out, center != 0, c, a, b);
@@ -123,7 +147,7 @@ int da_csd_decompose(const float *kernel, int64_t n_in, int64_t n_out, int cente
 }
 
 int da_kernel_decompose(const float *kernel, int64_t n_in, int64_t n_out, int dc, float *m0, float *m1) {
-    std::lock_guard<std::mutex> lk(g_mutex);
+    std::lock_guard<LibraryMutex> lk(g_mutex);
     try {
         std::vector<float> a, b;
         da::kernel_decompose(backend(), kernel, (int)n_in, (int)n_out, dc, a, b);
@@ -139,7 +163,7 @@ int da_solve_batch(int count, const float *const *kernels, const int64_t *n_in, 
                    const char *method1, int hard_dc, int decompose_dc, const float *const *qintervals,
                    const float *const *latencies, int adder_size, int carry_size, int search_all_decompose_dc,
                    da_result **results) {
-    std::lock_guard<std::mutex> lk(g_mutex);
+    std::lock_guard<LibraryMutex> lk(g_mutex);
     try {
         std::vector<da::Problem> probs((size_t)count);
         for (int i = 0; i < count; ++i) {
@@ -194,7 +218,7 @@ static std::unique_ptr<da::ShardEngine> make_hip_shard(const da::ChainJob &job, 
 da_result *da_solve_sharded(const float *kernel, int64_t n_in, int64_t n_out, const char *method0, const char *method1, int hard_dc,
                             int decompose_dc, const float *qintervals, const float *latencies, int adder_size, int carry_size,
                             int search_all_decompose_dc, int rank, int world, da_allreduce_i32 allreduce, void *ctx, int64_t *stats3) {
-    std::lock_guard<std::mutex> lk(g_mutex);
+    std::lock_guard<LibraryMutex> lk(g_mutex);
     try {
         if (world < 1 || rank < 0 || rank >= world) throw std::invalid_argument("rank must be in [0, world)");
         if (world > 255) throw std::invalid_argument("at most 255 ranks (8-bit flag fields)");
@@ -279,7 +303,7 @@ void da_free(da_result *r) {
 }
 
 int da_timings(double *t, int reset) {
-    std::lock_guard<std::mutex> lk(g_mutex);
+    std::lock_guard<LibraryMutex> lk(g_mutex);
     try {
         da::gpu::HipBackend &be = backend();
         const da::gpu::GpuTimings &g = be.timings();
@@ -299,7 +323,7 @@ int da_timings(double *t, int reset) {
 }
 
 int da_engine_stats(double *out, int n) {
-    std::lock_guard<std::mutex> lk(g_mutex);
+    std::lock_guard<LibraryMutex> lk(g_mutex);
     try {
         const da::gpu::GpuTimings &g = backend().timings();
         const double v[16] = {g.select_bytes,      g.host_launch_ms,    (double)g.greedy_launches, g.wg_ticks_select, g.wg_ticks_update, g.wg_ticks_idle, g.wg_ticks_total,

@@ -2359,6 +2359,21 @@ struct DeviceBuffer {  // grow-only device allocation reused across calls
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// Events of one call, destroyed however the call ends (a HIP error or the termination guard of the greedy loop used to leak
+// the timing, window and sample events of the call -- up to 12 k of them).
+struct EventGuard {
+    std::vector<hipEvent_t> all;
+    hipEvent_t make(unsigned flags = 0) {
+        hipEvent_t e = nullptr;
+        HIP_CHECK(flags ? hipEventCreateWithFlags(&e, flags) : hipEventCreate(&e));
+        all.push_back(e);
+        return e;
+    }
+    ~EventGuard() {
+        for (hipEvent_t e : all) (void)hipEventDestroy(e);
+    }
+};
+
 struct Carver {  // bump allocator over the arena; first pass sizes, second pass assigns
     unsigned char *base;
     size_t off = 0;
@@ -2757,9 +2772,8 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
     // ---- 4. greedy loop: two kernels per iteration.  The chains are split into up to four groups, each advancing
     // in lockstep on its own stream, so that the one-block-per-chain select kernel of one group overlaps the update
     // kernel of the others.
-    hipEvent_t ev0, ev1;
-    HIP_CHECK(hipEventCreate(&ev0));
-    HIP_CHECK(hipEventCreate(&ev1));
+    EventGuard events;
+    hipEvent_t ev0 = events.make(), ev1 = events.make();
     HIP_CHECK(hipEventRecord(ev0, st));
     HIP_CHECK(hipStreamSynchronize(st));  // set-up done before the group streams start
     if (im.persistent) {
@@ -2877,12 +2891,22 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
     // after window w has been queued, so the queues never drain while the host decides whether to go on.
     hipEvent_t win_ev[2][Impl::MAX_LANES], copy_ev[2];
     for (int p = 0; p < 2; ++p) {
-        HIP_CHECK(hipEventCreateWithFlags(&copy_ev[p], hipEventDisableTiming));
-        for (size_t gi = 0; gi < groups.size(); ++gi) HIP_CHECK(hipEventCreateWithFlags(&win_ev[p][gi], hipEventDisableTiming));
+        copy_ev[p] = events.make(hipEventDisableTiming);
+        for (size_t gi = 0; gi < groups.size(); ++gi) win_ev[p][gi] = events.make(hipEventDisableTiming);
     }
     im.h_done[0] = im.h_done[1] = 0;
     long long window = 0;
     double host_launch_ms = 0;  // host time spent queueing launches (not waiting for the device)
+    struct DrainOnError {  // an exception between here and the end of the loop leaves launches queued: let them finish before the arena is reused
+        const std::vector<Group> &g;
+        hipStream_t poll;
+        bool armed = true;
+        ~DrainOnError() {
+            if (!armed) return;
+            for (const Group &gr : g) (void)hipStreamSynchronize(gr.stream);
+            (void)hipStreamSynchronize(poll);
+        }
+    } drain{groups, im.poll_stream};
     while (active > 0 && !im.persistent) {
         const auto t_q0 = std::chrono::steady_clock::now();
         if (launched_iters > iter_cap + 2 * poll_every) throw std::runtime_error("greedy loop did not terminate within its row capacity (internal error)");
@@ -2892,7 +2916,7 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
             const bool sample = gi == 0 && n_samples < MAX_SAMPLES;
             if (sample) {
                 for (auto &e : se) {
-                    HIP_CHECK(hipEventCreate(&e));
+                    e = events.make();
                     sample_ev.push_back(e);
                 }
                 ++n_samples;
@@ -2921,10 +2945,7 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
     }
     for (const Group &gr : groups) HIP_CHECK(hipStreamSynchronize(gr.stream));
     HIP_CHECK(hipStreamSynchronize(im.poll_stream));
-    for (int p = 0; p < 2; ++p) {
-        (void)hipEventDestroy(copy_ev[p]);
-        for (size_t gi = 0; gi < groups.size(); ++gi) (void)hipEventDestroy(win_ev[p][gi]);
-    }
+    drain.armed = false;
     HIP_CHECK(hipEventRecord(ev1, st));
 
     lap("greedy loop");
@@ -2954,9 +2975,6 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
     }
     im.timings.samples += n_samples;
     im.timings.sampled_chain_launches += (double)n_samples * (groups.empty() ? 0 : groups[0].count);
-    for (hipEvent_t e : sample_ev) (void)hipEventDestroy(e);
-    (void)hipEventDestroy(ev0);
-    (void)hipEventDestroy(ev1);
 
     bool need_retry = false;
     for (int s = 0; s < n; ++s) {
@@ -3215,7 +3233,7 @@ class HipShardEngine : public ShardEngine {
             }
         }
         push();
-        HIP_CHECK(hipMalloc(&d_done_, sizeof(unsigned int)));
+        d_done_ = static_cast<unsigned int *>(done_buf_.get(sizeof(unsigned int)));  // (a member buffer: released also when a later check of this constructor throws)
         HIP_CHECK(hipMemsetAsync(d_done_, 0, sizeof(unsigned int), st_));
         dim3 colgrid((n_loc_ + 3) / 4, 1);
         if (!g.wide)
@@ -3232,10 +3250,7 @@ class HipShardEngine : public ShardEngine {
         part_lds_ = align_up(2 * (size_t)n_loc_ * (g.wide ? 8 : 4) + 4 * 3 * (size_t)g.Kpad * 4 + (size_t)n_loc_ * 2, 16);
         HIP_CHECK(hipStreamSynchronize(st_));
     }
-    ~HipShardEngine() override {
-        (void)hipSetDevice(device_);
-        if (d_done_) (void)hipFree(d_done_);
-    }
+    ~HipShardEngine() override { (void)hipSetDevice(device_); }
     bool on_device() const override { return true; }
     int n_keys() const override { return geo_.K; }
     int32_t *init_counts(int64_t &count) override {
@@ -3371,6 +3386,7 @@ class HipShardEngine : public ShardEngine {
     ChainDev *dd_ = nullptr;
     Geometry geo_;
     DeviceBuffer io_, desc_, arena_;
+    DeviceBuffer done_buf_;
     unsigned int *d_done_ = nullptr;
     long long n_pairs_ = 0;
     int nuni_ = 0;
@@ -3391,9 +3407,8 @@ void HipBackend::column_distances(const int32_t *aug, int n_in, int W, int64_t *
     unsigned char *buf = static_cast<unsigned char *>(im.io_buf.get(a_bytes + 2 * d_bytes));
     HIP_CHECK(hipMemcpyAsync(buf, aug, (size_t)n_in * W * 4, hipMemcpyHostToDevice, st));
     auto *dd0 = reinterpret_cast<long long *>(buf + a_bytes), *dd1 = reinterpret_cast<long long *>(buf + a_bytes + d_bytes);
-    hipEvent_t e0, e1;
-    HIP_CHECK(hipEventCreate(&e0));
-    HIP_CHECK(hipEventCreate(&e1));
+    EventGuard events;
+    hipEvent_t e0 = events.make(), e1 = events.make();
     HIP_CHECK(hipEventRecord(e0, st));
     hipLaunchKernelGGL(k_col_dist, dim3((W + 15) / 16, (W + 15) / 16), dim3(16, 16), 0, st, reinterpret_cast<const int32_t *>(buf), n_in, W, dd0, dd1);
     HIP_CHECK(hipGetLastError());
@@ -3405,8 +3420,6 @@ void HipBackend::column_distances(const int32_t *aug, int n_in, int W, int64_t *
     HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
     im.timings.dist_ms += ms;
     im.timings.dist_calls += 1;
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
 }
 
 int HipBackend::int_to_csd(const int32_t *x, int64_t n, std::vector<int8_t> &csd) {

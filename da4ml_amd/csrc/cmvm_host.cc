@@ -18,6 +18,7 @@
 #include <memory>
 #include <mutex>
 #include <pthread.h>
+#include <sched.h>
 #include <unordered_map>
 #include <thread>
 
@@ -331,7 +332,12 @@ struct OpListStash {
     static constexpr size_t MAX_BYTES = (size_t)1 << 30, MAX_LISTS = 1024, MIN_KEEP = 4096;  // ops; smaller lists are not worth keeping
 };
 OpListStash &op_list_stash() {
-    static OpListStash *s = new OpListStash();  // leaked: results may be released during interpreter shutdown
+    // leaked: results may be released during interpreter shutdown.  fork(): the mutex is taken before the fork and released on
+    // both sides, so that a child never inherits it locked by a thread that does not exist there
+    static OpListStash *s = [] {
+        pthread_atfork([] { op_list_stash().mu.lock(); }, [] { op_list_stash().mu.unlock(); }, [] { op_list_stash().mu.unlock(); });
+        return new OpListStash();
+    }();
     return *s;
 }
 }  // namespace
@@ -522,12 +528,19 @@ namespace {
 class HostPool {
   public:
     static HostPool &get() {
+        // fork(): the creation mutex is held across the fork (never inherited locked); the child drops the parent's pool -- its
+        // threads do not exist there -- and starts its own on first use
         static std::once_flag once;
-        std::call_once(once, [] { pthread_atfork(nullptr, nullptr, [] { instance().store(nullptr); }); });
+        std::call_once(once, [] {
+            pthread_atfork([] { make_mu().lock(); }, [] { make_mu().unlock(); },
+                           [] {
+                               instance().store(nullptr);
+                               make_mu().unlock();
+                           });
+        });
         HostPool *p = instance().load();
         if (!p) {
-            static std::mutex make_mu;
-            std::lock_guard<std::mutex> lk(make_mu);
+            std::lock_guard<std::mutex> lk(make_mu());
             p = instance().load();
             if (!p) {
                 p = new HostPool();
@@ -556,9 +569,15 @@ class HostPool {
                 }
             }
         };
-        const int helpers = (int)std::min<size_t>(threads_.size(), n - 1);
+        const int helpers = (int)std::min<size_t>((size_t)cap_, n - 1);
         {
             std::lock_guard<std::mutex> lk(mu_);
+            // threads are started when a loop first needs them: a single small solve starts a handful, not 255
+            while ((int)threads_.size() < helpers) {
+                const int t = (int)threads_.size();
+                threads_.emplace_back([this, t] { worker(t); });
+                threads_.back().detach();
+            }
             body_ = &body;
             wanted_ = helpers;
             pending_ = helpers;
@@ -575,21 +594,33 @@ class HostPool {
         if (err) std::rethrow_exception(err);
         return true;
     }
+    int capacity() const { return cap_ + 1; }
 
   private:
     static std::atomic<HostPool *> &instance() {
         static std::atomic<HostPool *> p{nullptr};
         return p;
     }
+    static std::mutex &make_mu() {
+        static std::mutex *m = new std::mutex();
+        return *m;
+    }
     HostPool() {
+        // The cores THIS process may run on (one process per GPU: multi_gpu.init() gives every rank its slice of the host's
+        // cores, so eight ranks do not start eight pools of 256 threads), at most 256 -- the GPU box's host has 256 for the
+        // tree pieces of a 64-chain batch.
         unsigned hw = std::thread::hardware_concurrency();
-        int n = (int)std::max(1u, std::min(hw ? hw : 1u, 256u)) - 1;  // all cores of the GPU box's host (256) for the tree pieces
-        if (const char *e = std::getenv("DA4ML_HOST_THREADS")) n = std::max(1, std::min(1024, std::atoi(e))) - 1;  // test hook
-        for (int t = 0; t < n; ++t) threads_.emplace_back([this, t] { worker(t); });
-        for (auto &t : threads_) t.detach();
+        cpu_set_t set;
+        if (sched_getaffinity(0, sizeof set, &set) == 0 && CPU_COUNT(&set) > 0) hw = (unsigned)CPU_COUNT(&set);
+        cap_ = (int)std::max(1u, std::min(hw ? hw : 1u, 256u)) - 1;
+        if (const char *e = std::getenv("DA4ML_HOST_THREADS")) cap_ = std::max(1, std::min(1024, std::atoi(e))) - 1;  // cap / test hook
     }
     void worker(int index) {
         uint64_t seen = 0;
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            seen = epoch_ - 1;  // started inside run(), before the epoch of that loop was published: take part in it
+        }
         for (;;) {
             std::function<void()> *body = nullptr;
             {
@@ -611,7 +642,7 @@ class HostPool {
     std::vector<std::thread> threads_;
     std::function<void()> *body_ = nullptr;
     uint64_t epoch_ = 0;
-    int wanted_ = 0, pending_ = 0;
+    int cap_ = 0, wanted_ = 0, pending_ = 0;
 };
 
 template <class Fn> void parallel_for(size_t n, Fn &&fn) {

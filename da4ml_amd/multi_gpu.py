@@ -17,12 +17,28 @@ def env_rank() -> tuple[int, int, int]:
     return int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1)), int(os.environ.get('LOCAL_RANK', 0))
 
 
+def pin_rank_to_core_slice(local: int, local_world: int) -> list[int] | None:
+    """One process per GPU on one host: give local rank ``local`` of ``local_world`` its contiguous slice of the cores this
+    process may run on.  The library's host pool (adder trees, staging; ``csrc/cmvm_host.cc``) sizes itself from the affinity
+    mask, and the thread that queues the greedy loop's launches -- latency-critical: two launches per group and step -- is not
+    preempted by seven other ranks' pools: without this, eight ranks start eight pools of up to 256 threads on the same cores.
+    Affects the calling thread and every thread it starts afterwards; ``DA4ML_PIN_RANKS=0`` turns it off."""
+    if local_world <= 1 or os.environ.get('DA4ML_PIN_RANKS', '1') == '0' or not hasattr(os, 'sched_setaffinity'):
+        return None
+    cores = sorted(os.sched_getaffinity(0))
+    lo, hi = len(cores) * local // local_world, len(cores) * (local + 1) // local_world
+    mine = cores[lo:hi] or cores[local % len(cores) : local % len(cores) + 1]
+    os.sched_setaffinity(0, mine)
+    return mine
+
+
 def init(backend: str | None = None):
     """Initialise ``torch.distributed`` from the environment; returns (rank, world, local_rank, device)."""
+    rank, world, local = env_rank()
+    pin_rank_to_core_slice(local, int(os.environ.get('LOCAL_WORLD_SIZE', world)))  # before torch and the library start their threads
     import torch
     import torch.distributed as dist
 
-    rank, world, local = env_rank()
     use_gpu = torch.cuda.is_available()
     device = torch.device(f'cuda:{local}') if use_gpu else torch.device('cpu')
     if use_gpu:

@@ -271,3 +271,25 @@ def test_failed_collective_stops_the_sharded_solve(model, monkeypatch):
     monkeypatch.setattr(mg, 'init', lambda *a, **kw: (0, 1, 0, __import__('torch').device('cpu')))
     p = mg.solve_column_sharded(k, sharded_solver=model.solve_sharded, method0='wmc', method1='wmc', decompose_dc=-1, search_all_decompose_dc=False)
     assert np.all(p.kernel == k)
+
+
+def test_ranks_get_disjoint_core_slices(monkeypatch):
+    """one process per GPU on one host: local rank r of n runs on its own slice of the allowed cores (the host pool of the
+    library sizes itself from that mask), the slices are disjoint and cover the cores; DA4ML_PIN_RANKS=0 leaves the mask alone"""
+    import os
+
+    from da4ml_amd import multi_gpu as mg
+
+    allowed = sorted(os.sched_getaffinity(0))
+    if len(allowed) < 2:
+        pytest.skip('one core')
+    seen = []
+    monkeypatch.setattr(os, 'sched_setaffinity', lambda pid, cores: seen.append(list(cores)))
+    n = min(8, len(allowed))
+    for r in range(n):
+        mg.pin_rank_to_core_slice(r, n)
+    assert sorted(c for s in seen for c in s) == allowed and all(len(s) >= 1 for s in seen)
+    seen.clear()
+    assert mg.pin_rank_to_core_slice(0, 1) is None and not seen  # a single rank keeps every core
+    monkeypatch.setenv('DA4ML_PIN_RANKS', '0')
+    assert mg.pin_rank_to_core_slice(0, 4) is None and not seen
