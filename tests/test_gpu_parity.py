@@ -325,3 +325,40 @@ def test_repeated_solves_are_deterministic(hip, oracle):
         got = hip.solve_many([k for k, _ in cases], adder_size=1, carry_size=-1) + [hip.solve(big)]
         for i, (g, w) in enumerate(zip(got, want)):
             assert g == w, f'repetition {rep}, case {i}'
+
+
+def test_persistent_engine_opt_in(oracle):
+    """DA4ML_HIP_ENGINE=persistent: the whole greedy loop in one launch (k_greedy: owner workgroups + wave-level helpers homed per
+    XCD).  Not the default -- it is slower per step -- but it must stay exact: random option sets, a mixed
+    batch with both entry layouts, a 64x64 batch and the 128x128 chain of the reference-build record."""
+    import hashlib
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    rec = json.loads((Path(__file__).parent / 'golden' / 'large_chain_golden.json').read_text())['128x128_seed0_single_chain_ref']
+    code = (
+        "import sys, json, hashlib; sys.path.insert(0, '.'); sys.path.insert(0, 'tests')\n"
+        "from cases import int_matrix, random_case\nfrom da4ml_amd import _binary as hip\nfrom oracle.oracle import Oracle\n"
+        "o = Oracle('port'); bad = []\n"
+        "for s in range(40):\n"
+        "    k, opts, _ = random_case(s)\n"
+        "    if hip.solve(k, **opts) != o.solve(k, **opts): bad.append(s)\n"
+        "single = dict(method0='wmc', method1='wmc', decompose_dc=-1, search_all_decompose_dc=False)\n"
+        "ks = [int_matrix(s, 6 + s % 5, 4 + s % 7, -64, 64) for s in range(12)] + [int_matrix(40, 4, 5, -8192, 8192), int_matrix(41, 3, 300, -4, 4)]\n"
+        "ks += [int_matrix(100 + s, 64, 64, -128, 128) for s in range(8)]\n"
+        "got = hip.solve_many(ks, **single)\n"
+        "bad += [100 + i for i, k in enumerate(ks) if got[i] != o.solve(k, **single)]\n"
+        f"p = hip.solve(int_matrix(0, 128, 128, -128, 128), **json.loads({json.dumps(json.dumps(rec['opts']))}))\n"
+        "dump = json.loads(json.dumps(p, default=lambda x: x.to_dict()))\n"
+        "t = hip.timings()\n"
+        "print(json.dumps({'bad': bad, 'sha': hashlib.sha256(json.dumps(dump, separators=(',', ':')).encode()).hexdigest(), 'launches': t['greedy_launches'], 'by_helpers': t['greedy_chunks_by_helpers']}))\n"
+    )
+    env = dict(os.environ, DA4ML_HIP_ENGINE='persistent')
+    out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, cwd=str(Path(__file__).resolve().parent.parent), timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    r = json.loads(out.stdout.strip().splitlines()[-1])
+    assert r['bad'] == [] and r['sha'] == rec['sha256']
+    assert r['launches'] >= 40 and r['by_helpers'] > 0  # the persistent kernel ran, and helper wavefronts of other workgroups took chunks
