@@ -9,7 +9,7 @@ stage() { # name, timeout, command...
   tail -${TAIL:-6} $O/$n.log; echo "== $n rc=$rc"
   [ $rc -eq 0 ] || { echo "STOP at $n"; exit 1; }
 }
-export DA4ML_HIP_VERBOSE=1
+export DA4ML_HIP_VERBOSE=1 DA4ML_HIP_ENGINE=persistent   # the engine under test (the launch engine is the default)
 stage smoke 120 python __graft_entry__.py smoke
 stage c2 120 python tests/gpu_profile.py 64 8
 stage single 120 python tests/gpu_profile.py 256 1
