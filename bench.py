@@ -226,7 +226,9 @@ def cpu_baseline(n_in, n_out, opts, budget_s, batch, gpu_time_batch=None):
     cores = cpu_pool.host_cores()
     # one 256x256 chain of the reference holds its 64.7 M initial pairs (24 bytes each) plus the sort buffer: ~4 GB per process
     need_gb = 4.0 * (n_in * n_out / 65536.0) ** 2 + 0.5
-    workers = max(1, min(cores, int(cpu_pool.mem_available_gb() / need_gb)))  # every core the memory allows (seeds repeat beyond the batch)
+    # one process per chain of the batch, never more than half of the available memory allows at 1.5 x the estimate (a first attempt
+    # with "every core the memory allows" -- 200+ processes on the 256-core box -- took the box down)
+    workers = max(1, min(cores, batch, int(0.5 * cpu_pool.mem_available_gb() / (1.5 * need_gb))))
     method = opts.get('method0', 'wmc')
     # (1) a time-bounded prefix of a chain of the batch on every core, all cores busy at once
     samples, wall = cpu_pool.run_pool(cpu_pool.sample_worker, [(okind, n_in, n_out, i % batch, method, budget_s) for i in range(workers)], workers)
