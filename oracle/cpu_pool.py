@@ -80,6 +80,10 @@ def run_pool(fn, jobs, workers):
     """map ``fn`` over ``jobs`` on ``workers`` spawned processes; returns (results in job order, wall seconds of the map)"""
     import multiprocessing as mp
 
+    # the workers are single-threaded solvers: keep the numerical libraries they import from starting one thread per core each
+    # (64 processes x 256 BLAS threads survive on the 256-core box, 256 x 256 did not)
+    for var in ('OMP_NUM_THREADS', 'OPENBLAS_NUM_THREADS', 'MKL_NUM_THREADS', 'NUMEXPR_NUM_THREADS'):
+        os.environ.setdefault(var, '1')
     ctx = mp.get_context('spawn')
     with ctx.Pool(processes=workers) as pool:
         pool.map(_warm, range(workers))  # interpreter start-up and imports are not part of the timed map
