@@ -1,13 +1,13 @@
 #!/bin/bash
 # Run on the GPU box (via gpurun): bench line + rocprofv3 kernel stats + PMC counter passes -> gpurun_out/profiles_rNN/
-# usage: tools/collect_profiles.sh r02        (QUICK=1: bench line, kernel stats and the two HBM-traffic passes only)
+# usage: tools/collect_profiles.sh r02        (QUICK=1: bench line, kernel stats and the two HBM-traffic passes only; SKIP_BENCH=1: reuse gpurun_out/profiles_rNN/bench.json)
 set -u
 TAG=${1:-r02}
 OUT=gpurun_out/profiles_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 # 1. the driver's contract line (incl. the all-core CPU baseline and the replay of all 64 results)
-python bench.py --steps 2 --warmup 1 > $OUT/bench.json 2> $OUT/bench.err
+[ -n "${SKIP_BENCH:-}" ] && [ -s $OUT/bench.json ] || python bench.py --steps 2 --warmup 1 > $OUT/bench.json 2> $OUT/bench.err   # SKIP_BENCH=1: keep the line of an earlier call
 # 2. kernel trace + stats of the same workload (one step, no CPU leg, no verification)
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o c3 -- python bench.py --steps 1 --warmup 0 --cpu-seconds 0 --no-verify > $OUT/trace.log 2>&1
 cp $OUT/trace/c3_kernel_stats.csv $OUT/kernel_stats.csv 2>/dev/null
