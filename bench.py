@@ -88,16 +88,20 @@ def launch_ranks(n: int) -> int:
 
 # ------------------------------------------------------------------------------------------------ PMC-derived figures
 def source_digest() -> str:
-    """sha256 over the sources libda4ml_hip.so is built from: what a set of profiles must have been taken on to describe the
-    loaded library (tools/collect_profiles.sh stores it in profiles/rNN_pmc_meta.json)"""
+    """sha256 over what the greedy loop's KERNELS are compiled from -- the kernel source, the scalar code it shares with the host
+    and the compile flags: what a set of profiles must have been taken on to describe the loaded kernels
+    (tools/collect_profiles.sh stores it in profiles/rNN_pmc_meta.json).  Host-side files (C ABI, orchestration, transports) do
+    not enter: they do not change a kernel."""
     import hashlib
 
     h = hashlib.sha256()
-    files = sorted((ROOT / 'da4ml_amd' / 'csrc').glob('*')) + [ROOT / 'include' / 'da4ml_hip.h']
-    for f in files:
-        if f.suffix in ('.hip', '.cc', '.h') or f.name == 'Makefile':
-            h.update(f.name.encode())
-            h.update(f.read_bytes())
+    csrc = ROOT / 'da4ml_amd' / 'csrc'
+    for name in ('cmvm_engine.hip', 'cmvm_core.h'):
+        h.update(name.encode())
+        h.update((csrc / name).read_bytes())
+    for line in (csrc / 'Makefile').read_text().splitlines():
+        if line.split('?=')[0].strip() in ('ARCH', 'KERNARG', 'CXXFLAGS'):
+            h.update(line.encode())
     return h.hexdigest()
 
 

@@ -27,7 +27,7 @@ _i32p = np.ctypeslib.ndpointer(np.int32, flags='C_CONTIGUOUS')
 
 EXPORTS = (
     'da_last_error da_last_error_code da_version da_device_count da_set_device da_get_lsb_loc da_iceil_log2 da_cost_add da_int_arr_to_csd '
-    'da_csd_decompose da_kernel_decompose da_solve da_solve_batch da_solve_sharded da_comm_abort da_n_stages da_picked da_stage_info da_stage_copy '
+    'da_csd_decompose da_kernel_decompose da_solve da_solve_batch da_solve_sharded da_rccl_unique_id da_solve_sharded_rccl da_comm_abort da_n_stages da_picked da_stage_info da_stage_copy '
     'da_result_stats da_free da_timings da_engine_stats da_dais_run da_dais_last_error da_dais_run_on'
 ).split()
 
@@ -86,6 +86,10 @@ def lib():
     L.da_stage_copy.argtypes = [C.c_void_p, C.c_int, _i64p, _i64p, _i64p, _i64p, _i64p, _f32p]
     L.da_result_stats.argtypes = [C.c_void_p, _i64p]
     L.da_free.argtypes = [C.c_void_p]
+    L.da_rccl_unique_id.argtypes = [C.c_char_p]
+    L.da_solve_sharded_rccl.restype = C.c_void_p
+    L.da_solve_sharded_rccl.argtypes = [_f32p, C.c_int64, C.c_int64, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                        C.c_int, C.c_int, C.c_char_p, _i64p]
     L.da_timings.argtypes = [np.ctypeslib.ndpointer(np.float64, flags='C_CONTIGUOUS'), C.c_int]
     L.da_engine_stats.argtypes = [np.ctypeslib.ndpointer(np.float64, flags='C_CONTIGUOUS'), C.c_int]
     _lib = L
@@ -244,6 +248,35 @@ def solve_sharded(kernel, method0: str = 'wmc', method1: str = 'auto', hard_dc: 
     h = lib().da_solve_sharded(k, n_in, n_out, method0.encode(), method1.encode(), int(hard_dc), int(decompose_dc),
                                None if q is None else q.ctypes.data, None if l is None else l.ctypes.data, int(adder_size), int(carry_size),
                                int(bool(search_all_decompose_dc)), int(rank), int(world), C.cast(allreduce, C.c_void_p) if allreduce is not None else None, None, st)  # fmt: skip
+    if not h:
+        _raise(lib().da_last_error_code())
+    return _collect(h), dict(zip(('sharded_chains', 'greedy_steps', 'allreduce_calls'), st.tolist()))
+
+
+def rccl_unique_id() -> bytes:
+    """128-byte RCCL unique id (``ncclGetUniqueId``): rank 0 obtains it and hands it to every rank of a column-sharded solve."""
+    buf = C.create_string_buffer(128)
+    rc = lib().da_rccl_unique_id(buf)
+    if rc != 0:
+        _raise(rc)
+    return buf.raw
+
+
+def solve_sharded_rccl(kernel, unique_id: bytes, method0: str = 'wmc', method1: str = 'auto', hard_dc: int = -1, decompose_dc: int = -2, qintervals=None,
+                       latencies=None, adder_size: int = -1, carry_size: int = -1, search_all_decompose_dc: bool = True, rank: int = 0, world: int = 1):  # fmt: skip
+    """``solve_sharded`` over the library's own RCCL transport (``da_solve_sharded_rccl``): ``ncclAllReduce`` in place on the
+    library's HIP stream, no Python in the loop.  ``unique_id``: the 128 bytes rank 0 got from ``rccl_unique_id()``."""
+    k = _kernel(kernel)
+    if k.ndim != 2:
+        raise RuntimeError('csd_decompose only supports 2D arrays.')
+    if len(unique_id) != 128:
+        raise ValueError('unique_id must be the 128 bytes of rccl_unique_id()')
+    n_in, n_out = k.shape
+    q, l = _opt_arrays(qintervals, latencies, n_in)
+    st = np.zeros(3, np.int64)
+    h = lib().da_solve_sharded_rccl(k, n_in, n_out, method0.encode(), method1.encode(), int(hard_dc), int(decompose_dc),
+                                    None if q is None else q.ctypes.data, None if l is None else l.ctypes.data, int(adder_size), int(carry_size),
+                                    int(bool(search_all_decompose_dc)), int(rank), int(world), unique_id, st)  # fmt: skip
     if not h:
         _raise(lib().da_last_error_code())
     return _collect(h), dict(zip(('sharded_chains', 'greedy_steps', 'allreduce_calls'), st.tolist()))

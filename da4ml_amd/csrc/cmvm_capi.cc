@@ -18,6 +18,7 @@
 #include "../../include/da4ml_hip.h"
 #include "cmvm_gpu.h"
 #include "cmvm_host.h"
+#include "cmvm_rccl.h"
 #include "cmvm_shard.h"
 
 namespace {
@@ -215,6 +216,43 @@ static std::unique_ptr<da::ShardEngine> make_hip_shard(const da::ChainJob &job, 
     return static_cast<da::gpu::HipBackend *>(ctx)->make_shard_engine(job, c0, c1, capacity_scale);
 }
 
+// the RCCL transport as a ShardComm collective: ctx = the transport; a failed collective raises the abort flag (ShardComm::sum throws)
+static void rccl_allreduce_cb(void *ctx, void *buf, int64_t count, int on_device) {
+    if (!static_cast<da::gpu::RcclTransport *>(ctx)->allreduce(buf, count, on_device != 0)) g_comm_aborted.store(1);
+}
+
+int da_rccl_unique_id(void *id128) {
+    try {
+        if (!id128) throw std::invalid_argument("id128 must point to 128 bytes");
+        da::gpu::rccl_unique_id(id128);
+        return DA_OK;
+    } catch (const std::exception &e) {
+        return fail(e);
+    }
+}
+
+da_result *da_solve_sharded_rccl(const float *kernel, int64_t n_in, int64_t n_out, const char *method0, const char *method1, int hard_dc,
+                                 int decompose_dc, const float *qintervals, const float *latencies, int adder_size, int carry_size,
+                                 int search_all_decompose_dc, int rank, int world, const void *id128, int64_t *stats3) {
+    std::shared_ptr<da::gpu::RcclTransport> tr;
+    {
+        std::lock_guard<LibraryMutex> lk(g_mutex);
+        try {
+            if (world < 1 || rank < 0 || rank >= world) throw std::invalid_argument("rank must be in [0, world)");
+            if (!id128) throw std::invalid_argument("id128 (the 128-byte RCCL unique id of rank 0) must be given");
+            da::gpu::HipBackend &inner = backend();
+            tr = da::gpu::RcclTransport::open(id128, rank, world, g_device, inner.stream());
+        } catch (const std::exception &e) {
+            fail(e);
+            return nullptr;
+        }
+    }
+    da_result *r = da_solve_sharded(kernel, n_in, n_out, method0, method1, hard_dc, decompose_dc, qintervals, latencies, adder_size, carry_size,
+                                    search_all_decompose_dc, rank, world, rccl_allreduce_cb, tr.get(), stats3);
+    if (!r && tr->last_error()[0]) g_err += std::string(" [") + tr->last_error() + "]";
+    return r;
+}
+
 da_result *da_solve_sharded(const float *kernel, int64_t n_in, int64_t n_out, const char *method0, const char *method1, int hard_dc,
                             int decompose_dc, const float *qintervals, const float *latencies, int adder_size, int carry_size,
                             int search_all_decompose_dc, int rank, int world, da_allreduce_i32 allreduce, void *ctx, int64_t *stats3) {
@@ -249,6 +287,7 @@ da_result *da_solve_sharded(const float *kernel, int64_t n_in, int64_t n_out, co
         comm.aborted = &g_comm_aborted;
         da::ShardedBackend be(inner, comm, make_hip_shard, &inner);
         be.force_single = std::getenv("DA4ML_SHARD_FORCE") != nullptr;
+        be.force_comm(std::getenv("DA4ML_SHARD_FORCE_COMM") != nullptr);  // call the collective with one rank too (measurement of the transport)
         std::vector<da::ChainStats> stats;
         std::vector<da::PipeResult> res = da::solve_batch(be, {p}, &stats);
         if (stats3) {

@@ -1,0 +1,151 @@
+// cmvm_rccl.cc -- see cmvm_rccl.h.  The five RCCL entry points used are resolved with dlsym from librccl.so (ROCm's NCCL:
+// `ncclGetUniqueId`, `ncclCommInitRank`, `ncclAllReduce`, `ncclCommDestroy`, `ncclGetErrorString`); their prototypes are the
+// published NCCL API, restated here so that neither the RCCL headers nor the library are needed to build.
+
+#include "cmvm_rccl.h"
+
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+
+namespace da {
+namespace gpu {
+namespace {
+
+constexpr int ID_BYTES = 128;  // NCCL_UNIQUE_ID_BYTES
+struct UniqueId {
+    char internal[ID_BYTES];
+};
+using Comm = void *;                  // ncclComm_t
+constexpr int NCCL_INT32 = 2, NCCL_SUM = 0;  // ncclDataType_t ncclInt32, ncclRedOp_t ncclSum
+
+struct Api {
+    int (*get_unique_id)(UniqueId *) = nullptr;
+    int (*comm_init_rank)(Comm *, int, UniqueId, int) = nullptr;
+    int (*all_reduce)(const void *, void *, size_t, int, int, Comm, hipStream_t) = nullptr;
+    int (*comm_destroy)(Comm) = nullptr;
+    const char *(*error_string)(int) = nullptr;
+};
+
+const Api &api() {
+    static Api a;
+    static std::once_flag once;
+    static std::string err;
+    std::call_once(once, [] {
+        void *h = nullptr;
+        for (const char *name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+            h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (h) break;
+        }
+        if (!h) {
+            err = std::string("librccl.so cannot be loaded: ") + (dlerror() ? dlerror() : "not found");
+            return;
+        }
+        auto sym = [&](const char *n) {
+            void *p = dlsym(h, n);
+            if (!p && err.empty()) err = std::string("librccl.so lacks ") + n;
+            return p;
+        };
+        a.get_unique_id = reinterpret_cast<decltype(a.get_unique_id)>(sym("ncclGetUniqueId"));
+        a.comm_init_rank = reinterpret_cast<decltype(a.comm_init_rank)>(sym("ncclCommInitRank"));
+        a.all_reduce = reinterpret_cast<decltype(a.all_reduce)>(sym("ncclAllReduce"));
+        a.comm_destroy = reinterpret_cast<decltype(a.comm_destroy)>(sym("ncclCommDestroy"));
+        a.error_string = reinterpret_cast<decltype(a.error_string)>(sym("ncclGetErrorString"));
+    });
+    if (!err.empty()) throw std::runtime_error(err);
+    return a;
+}
+
+std::string nccl_message(const char *what, int rc) {
+    const Api &a = api();
+    return std::string(what) + ": " + (a.error_string ? a.error_string(rc) : "RCCL error") + " (" + std::to_string(rc) + ")";
+}
+
+class Transport : public RcclTransport {
+  public:
+    Transport(Comm comm, int device, hipStream_t stream) : comm_(comm), device_(device), stream_(stream) {}
+    ~Transport() override {
+        // the communicator lives as long as the process uses its id (cache below); destroying communicators during interpreter
+        // shutdown can hang in the network teardown, so it is left to process exit
+        if (stage_) (void)hipFree(stage_);
+    }
+    bool allreduce(void *buf, int64_t count, bool on_device) override {
+        const Api &a = api();
+        if (count <= 0) return true;
+        if (on_device) {
+            const int rc = a.all_reduce(buf, buf, (size_t)count, NCCL_INT32, NCCL_SUM, comm_, stream_);
+            ++dev_calls_;
+            if (rc != 0) return fail(nccl_message("ncclAllReduce", rc));
+            return true;  // stream-ordered: the kernels that consume `buf` are queued behind it on the same stream
+        }
+        const size_t bytes = (size_t)count * 4;
+        if (bytes > stage_bytes_) {
+            if (stage_) (void)hipFree(stage_);
+            stage_ = nullptr;
+            stage_bytes_ = 0;
+            if (hipMalloc(&stage_, bytes + bytes / 2 + 4096) != hipSuccess) return fail("hipMalloc of the staging buffer failed");
+            stage_bytes_ = bytes + bytes / 2 + 4096;
+        }
+        if (hipMemcpyAsync(stage_, buf, bytes, hipMemcpyHostToDevice, stream_) != hipSuccess) return fail("staging copy failed");
+        const int rc = a.all_reduce(stage_, stage_, (size_t)count, NCCL_INT32, NCCL_SUM, comm_, stream_);
+        ++host_calls_;
+        if (rc != 0) return fail(nccl_message("ncclAllReduce", rc));
+        if (hipMemcpyAsync(buf, stage_, bytes, hipMemcpyDeviceToHost, stream_) != hipSuccess || hipStreamSynchronize(stream_) != hipSuccess)
+            return fail("staging copy back failed");
+        return true;
+    }
+    const char *last_error() const override { return err_.c_str(); }
+    long long device_calls() const override { return dev_calls_; }
+    long long host_calls() const override { return host_calls_; }
+
+  private:
+    bool fail(std::string m) {
+        err_ = std::move(m);
+        return false;
+    }
+    Comm comm_;
+    int device_;
+    hipStream_t stream_;
+    void *stage_ = nullptr;
+    size_t stage_bytes_ = 0;
+    long long dev_calls_ = 0, host_calls_ = 0;
+    std::string err_;
+};
+
+}  // namespace
+
+void rccl_unique_id(void *out128) {
+    UniqueId id;
+    std::memset(&id, 0, sizeof id);
+    const int rc = api().get_unique_id(&id);
+    if (rc != 0) throw std::runtime_error(nccl_message("ncclGetUniqueId", rc));
+    std::memcpy(out128, id.internal, ID_BYTES);
+}
+
+std::shared_ptr<RcclTransport> RcclTransport::open(const void *id128, int rank, int world, int device, void *stream) {
+    // one communicator per (unique id, rank, device): creating one costs tens of milliseconds and a rendezvous of all ranks
+    static std::mutex mu;
+    static std::map<std::string, std::shared_ptr<RcclTransport>> cache;
+    std::string key(static_cast<const char *>(id128), ID_BYTES);
+    key += ":" + std::to_string(rank) + ":" + std::to_string(world) + ":" + std::to_string(device) + ":" + std::to_string(reinterpret_cast<uintptr_t>(stream));
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = cache.find(key);
+    if (it != cache.end()) return it->second;
+    if (hipSetDevice(device) != hipSuccess) throw std::runtime_error("hipSetDevice failed");
+    UniqueId id;
+    std::memcpy(id.internal, id128, ID_BYTES);
+    Comm comm = nullptr;
+    const int rc = api().comm_init_rank(&comm, world, id, rank);
+    if (rc != 0) throw std::runtime_error(nccl_message("ncclCommInitRank", rc));
+    auto t = std::shared_ptr<RcclTransport>(new Transport(comm, device, static_cast<hipStream_t>(stream)));
+    cache.emplace(std::move(key), t);
+    return t;
+}
+
+}  // namespace gpu
+}  // namespace da

@@ -39,8 +39,9 @@ struct ShardComm {
     // set by the callback's owner when a collective failed (the callback itself returns nothing and must not unwind through
     // this code): the chain stops at once instead of going on with a buffer that was not reduced
     std::atomic<int> *aborted = nullptr;
+    bool force = false;  // test / measurement aid: call the collective with a single rank too (an all-reduce over one rank)
     void sum(void *buf, int64_t count, bool on_device) {
-        if (world > 1 && count > 0) allreduce(ctx, buf, count, on_device ? 1 : 0);
+        if ((world > 1 || force) && allreduce && count > 0) allreduce(ctx, buf, count, on_device ? 1 : 0);
         if (aborted && aborted->exchange(0)) throw std::runtime_error("the all-reduce callback reported a failed collective");
         ++calls;
         elements += count;
@@ -102,6 +103,7 @@ class ShardedBackend : public Backend {
     }
     int int_to_csd(const int32_t *x, int64_t n, std::vector<int8_t> &csd) override { return inner_.int_to_csd(x, n, csd); }
     const ShardComm &comm() const { return comm_; }
+    void force_comm(bool on) { comm_.force = on; }
     long long sharded_chains = 0, sharded_steps = 0, capacity_retries = 0;
     bool force_single = false;  // test aid: run the sharded phases with a single rank too (the exchanges are no-ops)
 

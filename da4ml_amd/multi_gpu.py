@@ -332,7 +332,7 @@ def make_allreduce_callback(device, abort=None):
 
 def solve_column_sharded(kernel, method0: str = 'wmc', method1: str = 'auto', hard_dc: int = -1, decompose_dc: int = -2, qintervals=None,
                          latencies=None, adder_size: int = -1, carry_size: int = -1, search_all_decompose_dc: bool = True, sharded_solver=None,
-                         return_stats: bool = False):  # fmt: skip
+                         return_stats: bool = False, transport: str = 'callback'):  # fmt: skip
     """One ``solve`` whose greedy chains are sharded over the output COLUMNS of their matrices (BASELINE config C4,
     SURVEY.md section 8e(2); ``csrc/cmvm_shard.h``): rank g holds the digits of columns [g n_out / W, (g+1) n_out / W), the
     pair table is replicated, every greedy step exchanges two all-reduce(sum) slabs (RCCL over xGMI on GPUs).  Every rank
@@ -340,8 +340,35 @@ def solve_column_sharded(kernel, method0: str = 'wmc', method1: str = 'auto', ha
 
     Bound by the latency of ~2 collectives per greedy step (4 10^4 per 256x256 chain): it does not scale; the layout that
     does is ``solve_many_sharded``.  ``sharded_solver`` defaults to the HIP engine (``_binary.solve_sharded``); the CPU
-    tests inject the sequential engine model."""
+    tests inject the sequential engine model.
+
+    ``transport``: ``'callback'`` -- the collective is ``torch.distributed.all_reduce`` called back from the library (any
+    backend; a host synchronisation per exchange); ``'rccl'`` -- the library's own RCCL transport (``csrc/cmvm_rccl.*``):
+    ``ncclAllReduce`` in place on the library's stream, stream-ordered with its kernels, no Python in the loop; rank 0's
+    RCCL unique id reaches the ranks through one ``torch.distributed.broadcast``."""
     rank, world, local, device = init()
+    if transport == 'rccl':
+        import numpy as np
+        import torch
+        import torch.distributed as dist
+
+        from . import _binary
+
+        if _binary.device_count() > 0:
+            _binary.set_device(local % _binary.device_count())
+        raw = _binary.rccl_unique_id() if rank == 0 else bytes(128)
+        if world > 1:
+            on_gpu = dist.get_backend() == 'nccl'
+            t = torch.from_numpy(np.frombuffer(raw, np.uint8).copy())
+            t = t.to(device) if on_gpu else t
+            dist.broadcast(t, src=0)
+            raw = t.cpu().numpy().tobytes()
+        pipe, stats = _binary.solve_sharded_rccl(kernel, raw, method0=method0, method1=method1, hard_dc=hard_dc, decompose_dc=decompose_dc, qintervals=qintervals,
+                                                 latencies=latencies, adder_size=adder_size, carry_size=carry_size, search_all_decompose_dc=search_all_decompose_dc,
+                                                 rank=rank, world=world)  # fmt: skip
+        return (pipe, stats) if return_stats else pipe
+    if transport != 'callback':
+        raise ValueError(f"transport must be 'callback' or 'rccl', not {transport!r}")
     if sharded_solver is None:
         from . import _binary
 

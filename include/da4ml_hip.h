@@ -88,6 +88,16 @@ typedef void (*da_allreduce_i32)(void *ctx, void *buf, int64_t count, int on_dev
 da_result *da_solve_sharded(const float *kernel, int64_t n_in, int64_t n_out, const char *method0, const char *method1, int hard_dc,
                             int decompose_dc, const float *qintervals, const float *latencies, int adder_size, int carry_size,
                             int search_all_decompose_dc, int rank, int world, da_allreduce_i32 allreduce, void *ctx, int64_t *stats3);
+/* The same with the library's own RCCL transport (csrc/cmvm_rccl.*): `ncclAllReduce` in place on the library's HIP stream,
+ * stream-ordered with the kernels that produce and consume the exchange buffers -- no callback, no host synchronisation per
+ * exchange.  librccl.so is opened at run time (no link-time dependency).  Rank 0 obtains the 128-byte unique id
+ * (da_rccl_unique_id = ncclGetUniqueId) and hands it to every rank by its own means (da4ml_amd.multi_gpu broadcasts it through
+ * torch.distributed); every rank then calls da_solve_sharded_rccl with identical arguments; the communicator of an id is kept
+ * for further calls. */
+int da_rccl_unique_id(void *id128);
+da_result *da_solve_sharded_rccl(const float *kernel, int64_t n_in, int64_t n_out, const char *method0, const char *method1, int hard_dc,
+                                 int decompose_dc, const float *qintervals, const float *latencies, int adder_size, int carry_size,
+                                 int search_all_decompose_dc, int rank, int world, const void *id128, int64_t *stats3);
 /* To be called by the all-reduce callback's owner when a collective failed (the callback returns nothing and must not unwind
  * through the library): the running da_solve_sharded stops at the next exchange and fails with a runtime error instead of
  * continuing with a buffer that was not reduced. */

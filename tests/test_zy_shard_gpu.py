@@ -80,3 +80,41 @@ def test_two_ranks_share_the_gpu_over_gloo():
     for r in res:
         assert all(r['same']) and len(r['same']) == 3, r
     assert res[0]['steps'] == res[1]['steps'] > 500
+
+
+RCCL_ONE = r'''
+import os, sys, json
+os.environ["DA4ML_SHARD_FORCE"] = "1"        # run the sharded phases with one rank ...
+os.environ["DA4ML_SHARD_FORCE_COMM"] = "1"   # ... and call the collective all the same: an all-reduce over one rank
+sys.path.insert(0, os.environ["DA_ROOT"]); sys.path.insert(0, os.path.join(os.environ["DA_ROOT"], "tests"))
+from da4ml_amd import _binary as hip
+from da4ml_amd import multi_gpu as mg
+from oracle.oracle import Oracle
+from cases import int_matrix, random_case
+O = Oracle("port")
+uid = hip.rccl_unique_id()
+cases = [(int_matrix(0, 16, 16, -128, 128), {}), (int_matrix(1, 48, 40, -128, 128), dict(method0="wmc", method1="wmc", decompose_dc=-1, search_all_decompose_dc=False)),
+         (int_matrix(2, 9, 20, -8, 8), dict(adder_size=1, carry_size=-1))]
+cases += [random_case(s)[:2] for s in (1003, 1012, 1030)]
+same, calls = [], 0
+for k, kw in cases:
+    p, st = hip.solve_sharded_rccl(k, uid, rank=0, world=1, **kw)
+    same.append(bool(p == O.solve(k, **kw)))
+    calls += st["allreduce_calls"]
+k, kw = cases[1]
+p = mg.solve_column_sharded(k, transport="rccl", **kw)   # the user-facing entry (one rank: no process group needed)
+same.append(bool(p == O.solve(k, **kw)))
+print(json.dumps({"same": same, "calls": calls}), flush=True)
+'''
+
+
+def test_rccl_transport_one_rank():
+    """The library's own RCCL transport (csrc/cmvm_rccl.*: librccl.so opened at run time, ncclCommInitRank, ncclAllReduce in place on
+    the library's stream): one rank on this one-GPU box, the collective called for every exchange all the same -- communicator
+    set-up, the stream-ordered device path and the host-staged path all run, results equal the oracle.  (Several ranks need one
+    GPU each: RCCL refuses two ranks on one device; the exchange protocol itself is covered by the gloo tests.)"""
+    env = dict(os.environ, DA_ROOT=str(ROOT))
+    out = subprocess.run([sys.executable, '-c', RCCL_ONE], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    r = json.loads(out.stdout.strip().splitlines()[-1])
+    assert r['same'] == [True] * 7 and r['calls'] > 100
