@@ -37,11 +37,33 @@ const Api &api() {
     static std::once_flag once;
     static std::string err;
     std::call_once(once, [] {
+        // The RCCL that belongs to the HIP runtime THIS library runs on: librccl.so from the directory of the libamdhip64.so that
+        // provides hipStreamSynchronize here.  A process may hold another pair (PyTorch ships its own HIP runtime and RCCL): a communicator
+        // of that copy cannot work on this library's streams ("unhandled cuda error" from ncclCommInitRank, measured).  RTLD_LOCAL:
+        // the copy's symbols must not become visible to the other one (opened RTLD_GLOBAL before torch initialised its own, the
+        // process ended in `double free or corruption` at exit).
         void *h = nullptr;
-        for (const char *name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
-            h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-            if (h) break;
+        {
+            Dl_info info;
+            std::memset(&info, 0, sizeof info);
+            hipError_t (*probe)(hipStream_t) = &hipStreamSynchronize;  // a function of the HIP runtime this library is bound to
+            if (dladdr(reinterpret_cast<const void *>(probe), &info) && info.dli_fname) {
+                std::string dir(info.dli_fname);
+                const size_t slash = dir.rfind('/');
+                if (slash != std::string::npos) {
+                    dir.resize(slash + 1);
+                    for (const char *name : {"librccl.so", "librccl.so.1"}) {
+                        h = dlopen((dir + name).c_str(), RTLD_NOW | RTLD_LOCAL);
+                        if (h) break;
+                    }
+                }
+            }
         }
+        if (!h)
+            for (const char *name : {"/opt/rocm/lib/librccl.so", "librccl.so", "librccl.so.1"}) {
+                h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+                if (h) break;
+            }
         if (!h) {
             err = std::string("librccl.so cannot be loaded: ") + (dlerror() ? dlerror() : "not found");
             return;
@@ -68,7 +90,7 @@ std::string nccl_message(const char *what, int rc) {
 
 class Transport : public RcclTransport {
   public:
-    Transport(Comm comm, int device, hipStream_t stream) : comm_(comm), device_(device), stream_(stream) {}
+    Transport(Comm comm, hipStream_t stream) : comm_(comm), stream_(stream) {}
     ~Transport() override {
         // the communicator lives as long as the process uses its id (cache below); destroying communicators during interpreter
         // shutdown can hang in the network teardown, so it is left to process exit
@@ -109,7 +131,6 @@ class Transport : public RcclTransport {
         return false;
     }
     Comm comm_;
-    int device_;
     hipStream_t stream_;
     void *stage_ = nullptr;
     size_t stage_bytes_ = 0;
@@ -129,8 +150,10 @@ void rccl_unique_id(void *out128) {
 
 std::shared_ptr<RcclTransport> RcclTransport::open(const void *id128, int rank, int world, int device, void *stream) {
     // one communicator per (unique id, rank, device): creating one costs tens of milliseconds and a rendezvous of all ranks
-    static std::mutex mu;
-    static std::map<std::string, std::shared_ptr<RcclTransport>> cache;
+    // (leaked on purpose: at process exit the HIP runtime and RCCL are torn down in an order this library does not control, and a
+    // communicator or staging buffer released then is released twice)
+    static std::mutex &mu = *new std::mutex();
+    static std::map<std::string, std::shared_ptr<RcclTransport>> &cache = *new std::map<std::string, std::shared_ptr<RcclTransport>>();
     std::string key(static_cast<const char *>(id128), ID_BYTES);
     key += ":" + std::to_string(rank) + ":" + std::to_string(world) + ":" + std::to_string(device) + ":" + std::to_string(reinterpret_cast<uintptr_t>(stream));
     std::lock_guard<std::mutex> lk(mu);
@@ -142,7 +165,7 @@ std::shared_ptr<RcclTransport> RcclTransport::open(const void *id128, int rank, 
     Comm comm = nullptr;
     const int rc = api().comm_init_rank(&comm, world, id, rank);
     if (rc != 0) throw std::runtime_error(nccl_message("ncclCommInitRank", rc));
-    auto t = std::shared_ptr<RcclTransport>(new Transport(comm, device, static_cast<hipStream_t>(stream)));
+    auto t = std::shared_ptr<RcclTransport>(new Transport(comm, static_cast<hipStream_t>(stream)));
     cache.emplace(std::move(key), t);
     return t;
 }

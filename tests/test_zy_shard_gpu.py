@@ -116,5 +116,5 @@ def test_rccl_transport_one_rank():
     env = dict(os.environ, DA_ROOT=str(ROOT))
     out = subprocess.run([sys.executable, '-c', RCCL_ONE], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
-    r = json.loads(out.stdout.strip().splitlines()[-1])
+    r = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1])  # (RCCL prints a version banner on stdout)
     assert r['same'] == [True] * 7 and r['calls'] > 100
