@@ -216,6 +216,11 @@ static std::unique_ptr<da::ShardEngine> make_hip_shard(const da::ChainJob &job, 
     return static_cast<da::gpu::HipBackend *>(ctx)->make_shard_engine(job, c0, c1, capacity_scale);
 }
 
+static da_result *solve_sharded_impl(const float *kernel, int64_t n_in, int64_t n_out, const char *method0, const char *method1, int hard_dc,
+                                     int decompose_dc, const float *qintervals, const float *latencies, int adder_size, int carry_size,
+                                     int search_all_decompose_dc, int rank, int world, da_allreduce_i32 allreduce, void *ctx, int64_t *stats3,
+                                     bool stream_ordered);
+
 // the RCCL transport as a ShardComm collective: ctx = the transport; a failed collective raises the abort flag (ShardComm::sum throws)
 static void rccl_allreduce_cb(void *ctx, void *buf, int64_t count, int on_device) {
     if (!static_cast<da::gpu::RcclTransport *>(ctx)->allreduce(buf, count, on_device != 0)) g_comm_aborted.store(1);
@@ -247,15 +252,18 @@ da_result *da_solve_sharded_rccl(const float *kernel, int64_t n_in, int64_t n_ou
             return nullptr;
         }
     }
-    da_result *r = da_solve_sharded(kernel, n_in, n_out, method0, method1, hard_dc, decompose_dc, qintervals, latencies, adder_size, carry_size,
-                                    search_all_decompose_dc, rank, world, rccl_allreduce_cb, tr.get(), stats3);
+    da_result *r = solve_sharded_impl(kernel, n_in, n_out, method0, method1, hard_dc, decompose_dc, qintervals, latencies, adder_size, carry_size,
+                                      search_all_decompose_dc, rank, world, rccl_allreduce_cb, tr.get(), stats3, true);
     if (!r && tr->last_error()[0]) g_err += std::string(" [") + tr->last_error() + "]";
     return r;
 }
 
-da_result *da_solve_sharded(const float *kernel, int64_t n_in, int64_t n_out, const char *method0, const char *method1, int hard_dc,
-                            int decompose_dc, const float *qintervals, const float *latencies, int adder_size, int carry_size,
-                            int search_all_decompose_dc, int rank, int world, da_allreduce_i32 allreduce, void *ctx, int64_t *stats3) {
+// stream_ordered: the collective is queued on the backend's own stream (the RCCL transport), so the engine hands over device
+// buffers without completing its kernels first
+static da_result *solve_sharded_impl(const float *kernel, int64_t n_in, int64_t n_out, const char *method0, const char *method1, int hard_dc,
+                                     int decompose_dc, const float *qintervals, const float *latencies, int adder_size, int carry_size,
+                                     int search_all_decompose_dc, int rank, int world, da_allreduce_i32 allreduce, void *ctx, int64_t *stats3,
+                                     bool stream_ordered) {
     std::lock_guard<LibraryMutex> lk(g_mutex);
     try {
         if (world < 1 || rank < 0 || rank >= world) throw std::invalid_argument("rank must be in [0, world)");
@@ -285,6 +293,7 @@ da_result *da_solve_sharded(const float *kernel, int64_t n_in, int64_t n_out, co
         comm.ctx = ctx;
         g_comm_aborted.store(0);
         comm.aborted = &g_comm_aborted;
+        comm.stream_ordered = stream_ordered || std::getenv("DA4ML_SHARD_STREAM_ORDERED") != nullptr;  // (the variable: test hook for transports that do nothing)
         da::ShardedBackend be(inner, comm, make_hip_shard, &inner);
         be.force_single = std::getenv("DA4ML_SHARD_FORCE") != nullptr;
         be.force_comm(std::getenv("DA4ML_SHARD_FORCE_COMM") != nullptr);  // call the collective with one rank too (measurement of the transport)
@@ -300,6 +309,13 @@ da_result *da_solve_sharded(const float *kernel, int64_t n_in, int64_t n_out, co
         fail(e);
         return nullptr;
     }
+}
+
+da_result *da_solve_sharded(const float *kernel, int64_t n_in, int64_t n_out, const char *method0, const char *method1, int hard_dc,
+                            int decompose_dc, const float *qintervals, const float *latencies, int adder_size, int carry_size,
+                            int search_all_decompose_dc, int rank, int world, da_allreduce_i32 allreduce, void *ctx, int64_t *stats3) {
+    return solve_sharded_impl(kernel, n_in, n_out, method0, method1, hard_dc, decompose_dc, qintervals, latencies, adder_size, carry_size,
+                              search_all_decompose_dc, rank, world, allreduce, ctx, stats3, false);
 }
 
 int da_n_stages(const da_result *r) { return (int)r->pipe.stages.size(); }

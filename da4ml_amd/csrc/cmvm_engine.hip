@@ -742,7 +742,25 @@ template <class Cell, bool SHARDED = false> __device__ __forceinline__ int selec
     if constexpr (SHARDED) pin_sgpr(cs_slab, cs_flags);
     ctx_finish(c);
     const int n_out = c.n_out, Kpad = c.Kpad, nb = c.n_bits;
-    if (was_done) return 1;
+    // column-sharded chain: a rank whose chain stops (finished, or an error) still hands out the flag buffer of the step -- zero
+    // flags and the status trailer {1, capacity error?, other error?} (cmvm_shard.h) -- written here, on the device: the host does
+    // not read the descriptor back between the steps
+    auto shard_stop = [&](int err) {
+        if constexpr (SHARDED) {
+            const int fw = (n_rows0 + 3) / 4;  // rows before this step
+            for (int w = threadIdx.x; w < fw; w += SEL_THREADS) cs_flags[w] = 0;
+            if (threadIdx.x == 0) {
+                const bool cap = err == E_ROW_CAPACITY || err == E_TABLE_CAPACITY || err == E_LIST_CAPACITY;
+                cs_flags[fw] = 1;
+                cs_flags[fw + 1] = cap ? 1 : 0;
+                cs_flags[fw + 2] = err != E_OK && !cap ? 1 : 0;
+            }
+        }
+    };
+    if (was_done) {
+        shard_stop(had_error);
+        return 1;
+    }
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // dynamic LDS carve: B's list | special-pair counters | per-matched-column scratch | column -> position in B | claim bitmap
     Entry *s_bent = reinterpret_cast<Entry *>(smem);                                  // [n_out] entries of row B (updated in place)
@@ -775,6 +793,7 @@ template <class Cell, bool SHARDED = false> __device__ __forceinline__ int selec
             g->n_partners = 0;
             atomicAdd(n_done, 1u);
         }
+        shard_stop(had_error);
         return 1;
     }
 
@@ -1018,6 +1037,7 @@ template <class Cell, bool SHARDED = false> __device__ __forceinline__ int selec
             g->n_partners = 0;
             atomicAdd(n_done, 1u);
         }
+        shard_stop(best_rank != 0 ? E_ROW_CAPACITY : E_OK);
         return 1;
     }
     const uint32_t A = (uint32_t)((best_tie >> 7) & 0xFFFFFFu), B = (uint32_t)(best_tie >> 31);
@@ -1049,6 +1069,7 @@ template <class Cell, bool SHARDED = false> __device__ __forceinline__ int selec
             g->n_partners = 0;
             atomicAdd(n_done, 1u);
         }
+        shard_stop(E_LIST_CAPACITY);
         return 1;
     }
     DA_GLOBAL Entry *rlA = rl + refA.x, *rlB = rl + refB.x, *rlN = rl + offN;
@@ -3271,38 +3292,42 @@ class HipShardEngine : public ShardEngine {
             hipLaunchKernelGGL(k_cs_init_table<uint64_t>, grid, dim3(256), 0, st_, dd_);
         HIP_CHECK(hipGetLastError());
     }
+    void set_stream_ordered(bool on) override { stream_ordered_ = on; }
+    // The host reads NOTHING back between the kernels of a step except, once per step, the summed status trailer and the size
+    // of the partner union (one synchronisation): the rows before a step are n_in + the steps taken, and a chain that stops
+    // writes its zero flags and trailer on the device (select_body, shard_stop).  With a stream-ordered transport (the library's
+    // RCCL transport: collectives queued on this stream) that is the only synchronisation of a step; a callback transport is
+    // handed completed buffers, i.e. one synchronisation in front of each of its two calls.
     void select(int32_t *&flags, int64_t &fcount) override {
-        if (!d_.done) {
+        fw_ = flag_words(job_.n_in + (int)steps_);  // rows before this step
+        if (!stopped_) {
             if (!geo_.wide)
                 hipLaunchKernelGGL((k_iter_select<uint32_t, true>), dim3(1), dim3(SEL_THREADS), sel_lds_, st_, dd_, d_done_);
             else
                 hipLaunchKernelGGL((k_iter_select<uint64_t, true>), dim3(1), dim3(SEL_THREADS), sel_lds_, st_, dd_, d_done_);
-            pull();
-        }
-        // rows before this step: the new row's id where the step was taken, the unchanged row count where the chain has stopped
-        fw_ = flag_words(d_.done ? d_.n_rows : (int)d_.Nw);
-        if (d_.done) {  // finished or failed: zero flags and the trailer {1, capacity error?, other error?} -- the rank still takes part in the exchange
-            trailer_[0] = 1;
-            trailer_[1] = is_capacity_error(d_.error) ? 1 : 0;
-            trailer_[2] = d_.error != E_OK && !is_capacity_error(d_.error) ? 1 : 0;
+            HIP_CHECK(hipGetLastError());
+        } else {  // (not reached by ShardedBackend, which leaves the loop with the step that stopped; kept well-defined)
+            const int32_t tr[SHARD_TRAILER] = {1, 0, 0};
             HIP_CHECK(hipMemsetAsync(d_.cs_flags, 0, (size_t)fw_ * 4, st_));
-            HIP_CHECK(hipMemcpyAsync(d_.cs_flags + fw_, trailer_, sizeof trailer_, hipMemcpyHostToDevice, st_));
+            HIP_CHECK(hipMemcpyAsync(d_.cs_flags + fw_, tr, sizeof tr, hipMemcpyHostToDevice, st_));
             sync();
         }
+        if (!stream_ordered_) sync();
         flags = d_.cs_flags;
         fcount = fw_ + SHARD_TRAILER;
     }
     int32_t *partial(int64_t &scount, int32_t status[SHARD_TRAILER]) override {
         HIP_CHECK(hipMemcpyAsync(trailer_, d_.cs_flags + fw_, sizeof trailer_, hipMemcpyDeviceToHost, st_));  // the summed status, with the union's size
         int nuni = 0;
-        if (!d_.done) {
-            hipLaunchKernelGGL(k_cs_union, dim3(1), dim3(1024), 0, st_, dd_);
-            HIP_CHECK(hipMemcpyAsync(&nuni, &dd_->cs_nuni, sizeof(int), hipMemcpyDeviceToHost, st_));
-        }
+        hipLaunchKernelGGL(k_cs_union, dim3(1), dim3(1024), 0, st_, dd_);  // (on summed flags that are all zero when every rank has stopped: an empty union)
+        HIP_CHECK(hipMemcpyAsync(&nuni, &dd_->cs_nuni, sizeof(int), hipMemcpyDeviceToHost, st_));
         sync();
         for (int q = 0; q < SHARD_TRAILER; ++q) status[q] = trailer_[q];
         scount = 0;
-        if (status[0] != 0) return nullptr;
+        if (status[0] != 0) {
+            stopped_ = true;
+            return nullptr;
+        }
         nuni_ = nuni;
         if (nuni > 0) {
             const dim3 grid((unsigned)((nuni + 3) / 4));
@@ -3311,7 +3336,7 @@ class HipShardEngine : public ShardEngine {
             else
                 hipLaunchKernelGGL(k_cs_partial<uint64_t>, grid, dim3(256), part_lds_, st_, dd_);
         }
-        sync();
+        if (!stream_ordered_) sync();
         scount = (int64_t)(6 + 3 * (int64_t)nuni) * geo_.K;
         return d_.cs_slab;
     }
@@ -3322,6 +3347,7 @@ class HipShardEngine : public ShardEngine {
         else
             hipLaunchKernelGGL(k_cs_apply<uint64_t>, grid, dim3(256), 0, st_, dd_);
         HIP_CHECK(hipGetLastError());
+        ++steps_;
     }
     void finish(ChainOut &o) override {
         dim3 colgrid((n_loc_ + 3) / 4, 1);
@@ -3378,6 +3404,8 @@ class HipShardEngine : public ShardEngine {
     hipStream_t st_;
     StepLog2Host step_tab_;
     int64_t fw_ = 0;                      // flag words of the current step (the status trailer follows them)
+    long long steps_ = 0;                 // greedy steps applied so far (rows = n_in + steps_)
+    bool stopped_ = false, stream_ordered_ = false;
     int32_t trailer_[SHARD_TRAILER] = {0, 0, 0};
     int device_;
     ChainJob job_;

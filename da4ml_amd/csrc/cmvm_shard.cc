@@ -31,6 +31,7 @@ void ShardedBackend::run_one(const ChainJob &job, ChainOut &out) {
         // capacities, at most three times.  The decision comes from the SUMMED status words, so every rank takes it together.
         eng = make_(job, c0, c1, scale, ctx_);
         const bool dev = eng->on_device();
+        eng->set_stream_ordered(comm_.stream_ordered);
 
         // initial pair counts: partial over the own columns, summed over the ranks
         int64_t count = 0;

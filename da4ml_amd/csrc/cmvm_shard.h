@@ -39,6 +39,7 @@ struct ShardComm {
     // set by the callback's owner when a collective failed (the callback itself returns nothing and must not unwind through
     // this code): the chain stops at once instead of going on with a buffer that was not reduced
     std::atomic<int> *aborted = nullptr;
+    bool stream_ordered = false;  // device buffers are reduced on the engine's stream (no completed-buffer contract needed)
     bool force = false;  // test / measurement aid: call the collective with a single rank too (an all-reduce over one rank)
     void sum(void *buf, int64_t count, bool on_device) {
         if ((world > 1 || force) && allreduce && count > 0) allreduce(ctx, buf, count, on_device ? 1 : 0);
@@ -82,6 +83,9 @@ class ShardEngine {
     // status[0] != 0 (somebody has stopped) nothing is computed and nullptr is returned.
     virtual int32_t *partial(int64_t &slab_count, int32_t status[SHARD_TRAILER]) = 0;
     virtual void apply() = 0;  // phase 3: the summed slab into the table
+    // the collectives are queued on the engine's own stream (the library's RCCL transport): the engine need not complete its
+    // kernels before handing a device buffer to ShardComm::sum
+    virtual void set_stream_ordered(bool) {}
     // own columns of the finished chain (col_start covers the own columns only; everything row-related is global)
     virtual void finish(ChainOut &own) = 0;
 };
