@@ -1,13 +1,15 @@
 #!/bin/bash
 # Run on the GPU box (via gpurun): bench line + rocprofv3 kernel stats + PMC counter passes -> gpurun_out/profiles_rNN/
-# usage: tools/collect_profiles.sh r02        (QUICK=1: bench line, kernel stats and the two HBM-traffic passes only; SKIP_BENCH=1: reuse gpurun_out/profiles_rNN/bench.json)
+# usage: tools/collect_profiles.sh r02        (QUICK=1: bench line, kernel stats and the two HBM-traffic passes only; SKIP_BENCH=1: reuse gpurun_out/profiles_rNN/bench.json;
+#        PMC_ONLY=1: kernel stats and all PMC passes, nothing else -- then copy the summaries into profiles/ and run bench.py, so that the line is
+#        written with counters of the sources it measures)
 set -u
 TAG=${1:-r02}
 OUT=gpurun_out/profiles_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 # 1. the driver's contract line (incl. the all-core CPU baseline and the replay of all 64 results)
-[ -n "${SKIP_BENCH:-}" ] && [ -s $OUT/bench.json ] || python bench.py --steps 2 --warmup 1 > $OUT/bench.json 2> $OUT/bench.err   # SKIP_BENCH=1: keep the line of an earlier call
+[ -n "${PMC_ONLY:-}" ] || { [ -n "${SKIP_BENCH:-}" ] && [ -s $OUT/bench.json ]; } || python bench.py --steps 2 --warmup 1 > $OUT/bench.json 2> $OUT/bench.err   # SKIP_BENCH=1: keep the line of an earlier call
 # 2. kernel trace + stats of the same workload (one step, no CPU leg, no verification)
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o c3 -- python bench.py --steps 1 --warmup 0 --cpu-seconds 0 --no-verify > $OUT/trace.log 2>&1
 cp $OUT/trace/c3_kernel_stats.csv $OUT/kernel_stats.csv 2>/dev/null
@@ -27,7 +29,7 @@ for SET in "${SETS[@]}"; do
   python tools/summarise_pmc.py $OUT/pmc_$NAME > $OUT/pmc_$NAME.summary.txt 2>&1
   rm -rf $OUT/pmc_$NAME
 done
-[ -n "${QUICK:-}" ] && { ls -la $OUT; exit 0; }
+[ -n "${QUICK:-}${PMC_ONLY:-}" ] && { ls -la $OUT; exit 0; }
 # 4. the other workloads: 64x64 batch, end-to-end model compile (C5), column-sharded chain (one GPU: phases forced, exchanges no-ops)
 timeout 300 python bench.py --workload c2_64x64_int8_batch64_single_chain --steps 5 --warmup 1 --cpu-seconds 0 > $OUT/bench_c2.json 2> $OUT/bench_c2.err
 timeout 600 python bench.py --workload c5_model_batch --steps 3 --warmup 1 > $OUT/bench_c5.json 2> $OUT/bench_c5.err
