@@ -118,3 +118,15 @@ def test_rccl_transport_one_rank():
     assert out.returncode == 0, out.stderr[-3000:]
     r = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1])  # (RCCL prints a version banner on stdout)
     assert r['same'] == [True] * 7 and r['calls'] > 100
+
+
+def test_torch_nccl_paths_one_rank():
+    """tools/nccl_world1_check.py: the torch.distributed `nccl` (= RCCL) paths of the N-rank bench and of the callback transport, as far
+    as one GPU reaches -- process group, max / sum over ranks and barrier on device tensors, the DEVICE-buffer branch of the all-reduce
+    callback (every exchange of a 48x48 chain forced through dist.all_reduce on the library's buffers), the library's own transport
+    beside it; both results equal the unsharded solve."""
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT')}
+    out = subprocess.run([sys.executable, str(ROOT / 'tools' / 'nccl_world1_check.py')], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    r = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1])
+    assert r['ok'] and r['backend'] == 'nccl' and r['callback']['stats']['allreduce_calls'] > 100, r

@@ -8,7 +8,13 @@ import sys
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ.update(RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT='29519')
+os.environ.update(RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1')
+if 'MASTER_PORT' not in os.environ:  # a free port of this host
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        os.environ['MASTER_PORT'] = str(sk.getsockname()[1])
 os.environ['DA4ML_SHARD_FORCE'] = '1'  # sharded phases although there is one rank
 os.environ['DA4ML_SHARD_FORCE_COMM'] = '1'  # ... and every exchange really calls the collective
 
