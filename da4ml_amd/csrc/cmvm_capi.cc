@@ -381,9 +381,7 @@ int da_engine_stats(double *out, int n) {
     std::lock_guard<LibraryMutex> lk(g_mutex);
     try {
         const da::gpu::GpuTimings &g = backend().timings();
-        const double v[16] = {g.select_bytes,      g.host_launch_ms,    (double)g.greedy_launches, g.wg_ticks_select, g.wg_ticks_update, g.wg_ticks_idle, g.wg_ticks_total,
-                              g.helper_ticks_busy, g.helper_ticks_total, g.tasks_select,            g.tasks_update,    g.tasks_helper,    g.polls,         g.workgroups,
-                              0.0,                 0.0};
+        const double v[16] = {g.select_bytes, g.host_launch_ms, g.steps_chain_launches, g.fused_steps, g.handoff_steps, g.tpp_bytes, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
         const int m = n < 16 ? (n < 0 ? 0 : n) : 16;
         for (int i = 0; i < m; ++i) out[i] = v[i];
         return m;

@@ -150,10 +150,10 @@ int da_dais_run_on(const int32_t *program, int64_t n_words, const double *inputs
  * count-block bytes (2K per touched block), partner-cell bytes -- accumulated since the last reset */
 int da_timings(double *t, int reset);
 /* Further engine counters, same accumulation and reset as da_timings (call BEFORE a resetting da_timings); writes min(n, 16) values:
- * out[0] algorithmic bytes of k_iter_select (device-counted), out[1] host ms spent queueing greedy-loop
- * launches, out[2] launches of the persistent engine (DA4ML_HIP_ENGINE=persistent), out[3..6] its owner-workgroup ticks (select,
- * own chunks, waiting, total; 100 MHz nominal), out[7..8] helper-wave ticks (busy, total), out[9] steps, out[10] update chunks,
- * out[11] of which by helpers, out[12] polls of the scouts, out[13] workgroups that reported; returns the number written */
+ * out[0] algorithmic bytes of the selection steps (k_steps / k_iter_select; device-counted), out[1] host ms
+ * spent queueing greedy-loop launches, out[2] chains x launches of k_steps, out[3] greedy steps whose update k_steps applied itself,
+ * out[4] steps it handed to k_iter_update, out[5] algorithmic bytes of the in-kernel updates, out[6..15] reserved (0); returns the
+ * number written */
 int da_engine_stats(double *out, int n);
 
 #ifdef __cplusplus

@@ -220,6 +220,7 @@ template <class T, class U, class V> inline T atomicCAS(T *p, U cmp, V v) {
 #define __hip_atomic_load(p, order, scope) __atomic_load_n((p), __ATOMIC_RELAXED)
 #define __hip_atomic_store(p, v, order, scope) __atomic_store_n((p), (v), __ATOMIC_RELAXED)
 #define __hip_atomic_fetch_add(p, v, order, scope) atomicAdd((p), (v))
+#define __hip_atomic_fetch_max(p, v, order, scope) atomicMax((p), (v))
 
 // ------------------------------------------------------------------------------------------------ runtime API
 typedef int hipError_t;

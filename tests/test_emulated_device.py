@@ -57,6 +57,27 @@ def test_batched_chains(emu):
     assert r['bad'] == [] and r['chains'] >= 13
 
 
+@pytest.mark.parametrize('env', [
+    {'DA4ML_HIP_FUSE': '0'},
+    {'DA4ML_HIP_FUSE': '1'},
+    {'DA4ML_HIP_FUSE': '64'},
+    {'DA4ML_HIP_FUSE_M': '2', 'DA4ML_HIP_FUSE_NP': '12'},
+    {'DA4ML_HIP_FUSE_M': '100', 'DA4ML_HIP_FUSE_NP': '1000000'},
+], ids=['pair', 'steps1', 'steps64', 'mixed', 'all_fused'])
+def test_step_engine_settings(emu, env):
+    """k_steps -- several greedy steps per launch, the update applied by the selecting workgroup itself, thread per partner row,
+    table probed through its control bytes -- under every setting of its knobs, next to the kernel pair it replaces for narrow
+    chains (DA4ML_HIP_FUSE=0): all equal the oracle.  (The emulated build stages 16 partner ids in LDS, so both id paths run.)"""
+    r = emu('steps', env=env)
+    assert r['bad'] == []
+    if env.get('DA4ML_HIP_FUSE') == '0':
+        assert r['fused'] == 0 and r['handoffs'] == 0
+    elif env.get('DA4ML_HIP_FUSE_M') == '100':
+        assert r['fused'] > 0.9 * r['iterations']
+    else:
+        assert r['fused'] > 0 and r['handoffs'] > 0
+
+
 def test_wide_host_pool(emu):
     """the host thread pool as on the 256-core GPU box: 200 threads, of which those beyond the first 63 are woken for wide loops
     only (here: 14 chains x 8 column ranges of the adder trees)"""

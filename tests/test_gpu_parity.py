@@ -327,10 +327,18 @@ def test_repeated_solves_are_deterministic(hip, oracle):
             assert g == w, f'repetition {rep}, case {i}'
 
 
-def test_persistent_engine_opt_in(oracle):
-    """DA4ML_HIP_ENGINE=persistent: the whole greedy loop in one launch (k_greedy: owner workgroups + wave-level helpers homed per
-    XCD).  Not the default -- it is slower per step -- but it must stay exact: random option sets, a mixed
-    batch with both entry layouts, a 64x64 batch and the 128x128 chain of the reference-build record."""
+@pytest.mark.parametrize('env', [
+    {'DA4ML_HIP_FUSE': '0'},                                                    # the (k_iter_select, k_iter_update) pair for every step
+    {'DA4ML_HIP_FUSE': '1'},                                                    # k_steps, one step per launch
+    {'DA4ML_HIP_FUSE': '64'},                                                   # up to 64 steps per launch
+    {'DA4ML_HIP_FUSE_M': '2', 'DA4ML_HIP_FUSE_NP': '48'},                       # fused steps and hand-offs interleaved
+    {'DA4ML_HIP_FUSE_M': '100', 'DA4ML_HIP_FUSE_NP': '1000000'},                # every step updated inside k_steps (thread per partner row)
+], ids=['pair', 'steps1', 'steps64', 'mixed', 'all_fused'])
+def test_step_engine_settings(oracle, env):
+    """k_steps (several greedy steps per launch, updates applied by the selecting workgroup itself, thread per partner row) against
+    the kernel pair it replaces for narrow chains: whatever the steps per launch and wherever the line between in-kernel updates
+    and steps handed to k_iter_update is drawn, results equal the oracle -- random option sets, a mixed batch with both entry
+    layouts, a 64x64 batch and the 128x128 chain of the reference-build record."""
     import hashlib
     import json
     import os
@@ -354,11 +362,15 @@ def test_persistent_engine_opt_in(oracle):
         f"p = hip.solve(int_matrix(0, 128, 128, -128, 128), **json.loads({json.dumps(json.dumps(rec['opts']))}))\n"
         "dump = json.loads(json.dumps(p, default=lambda x: x.to_dict()))\n"
         "t = hip.timings()\n"
-        "print(json.dumps({'bad': bad, 'sha': hashlib.sha256(json.dumps(dump, separators=(',', ':')).encode()).hexdigest(), 'launches': t['greedy_launches'], 'by_helpers': t['greedy_chunks_by_helpers']}))\n"
+        "print(json.dumps({'bad': bad, 'sha': hashlib.sha256(json.dumps(dump, separators=(',', ':')).encode()).hexdigest(), 'fused': t['fused_steps'], 'handoffs': t['handoff_steps']}))\n"
     )
-    env = dict(os.environ, DA4ML_HIP_ENGINE='persistent')
-    out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, cwd=str(Path(__file__).resolve().parent.parent), timeout=600)
+    out = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, **env), capture_output=True, text=True, cwd=str(Path(__file__).resolve().parent.parent), timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
     r = json.loads(out.stdout.strip().splitlines()[-1])
     assert r['bad'] == [] and r['sha'] == rec['sha256']
-    assert r['launches'] >= 40 and r['by_helpers'] > 0  # the persistent kernel ran, and helper wavefronts of other workgroups took chunks
+    if env.get('DA4ML_HIP_FUSE') == '0':
+        assert r['fused'] == 0 and r['handoffs'] == 0
+    elif env.get('DA4ML_HIP_FUSE_M') == '100':  # (the host still caps the columns per in-kernel update by what the 7-bit pair counters hold)
+        assert r['fused'] > 1000
+    else:
+        assert r['fused'] > 0 and r['handoffs'] > 0
