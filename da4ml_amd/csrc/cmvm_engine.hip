@@ -229,7 +229,7 @@ struct ChainDev {
     uint8_t *hctl;        // [C] control bytes: 0 never used | 1 + tag tombstone | 5..255 fingerprint of the slot's key
     void *ccell;          // [n_out][rcap] column-major cells (nullptr: chain not stepped by k_steps)
     int cell_bytes;       // sizeof(Cell) of the chain's layout
-    int fuse_max_m, fuse_max_np;  // k_steps applies a step's update itself when it substitutes <= fuse_max_m columns and has <= fuse_max_np partner rows
+    int fuse_max_m, fuse_max_np, fuse_max_nh;  // k_steps applies a step's update itself when it substitutes <= fuse_max_m columns, has <= fuse_max_np partner rows and <= fuse_max_nh of them own or gain a count block
     int pb_log2;
     unsigned long long *ub;
     unsigned long long *gtie;  // [n_groups] full tie word of the group's best entry (valid while the group is clean)
@@ -451,7 +451,7 @@ __device__ int table_find_from(const Ctx &c, unsigned long long key, uint32_t h,
     const uint32_t b0 = (h & ~(BUCKET - 1)) + first_bucket * BUCKET;
     for (uint32_t w = 0; w < c.windows + 1; ++w) {
         uint32_t s = (b0 + w * WAVE + lane) & c.cmask;
-        unsigned long long kk = ld_key(&c.hkey[s]);
+        unsigned long long kk = c.hctl ? ld_key(&c.hkey[s]) : c.hkey[s];  // (k_steps: past the L1, see ld_key)
         unsigned long long hit = __ballot(kk == key);
         if (hit) return (int)((b0 + w * WAVE + (__ffsll((long long)hit) - 1)) & c.cmask);
         if (__ballot(kk == KEY_EMPTY)) return -1;
@@ -465,7 +465,7 @@ __device__ int table_claim(const Ctx &c, unsigned long long key, uint32_t h) {
     const uint32_t b0 = h & ~(BUCKET - 1);
     for (uint32_t w = 0; w < c.windows + 1; ++w) {
         uint32_t s = (b0 + w * WAVE + lane) & c.cmask;
-        unsigned long long kk = ld_key(&c.hkey[s]);
+        unsigned long long kk = c.hctl ? ld_key(&c.hkey[s]) : c.hkey[s];
         unsigned long long avail = __ballot(kk == KEY_EMPTY || (kk >= KEY_TOMB_LO && kk != c.tomb));
         while (avail) {
             int l = __ffsll((long long)avail) - 1;
@@ -474,7 +474,7 @@ __device__ int table_claim(const Ctx &c, unsigned long long key, uint32_t h) {
             if (lane == l) {
                 ok = atomicCAS(gen(&c.hkey[s]), kk, key) == kk;
                 if (ok && kk == KEY_EMPTY) atomicAdd(&c.g->n_used, 1u);
-                if (ok) c.hctl[s] = (uint8_t)ctl_fp((uint32_t)key, (uint32_t)(key >> 32));
+                if (ok && c.hctl) c.hctl[s] = (uint8_t)ctl_fp((uint32_t)key, (uint32_t)(key >> 32));
             }
             ok = __shfl(ok, l);
             if (ok) return (int)((b0 + w * WAVE + l) & c.cmask);
@@ -544,7 +544,7 @@ __device__ __forceinline__ void block_commit(const Ctx &c, int slot, unsigned lo
     if (!alive) {
         c.hrank[slot] = 0;
         c.hkey[slot] = c.tomb;
-        c.hctl[slot] = ctl_of_tomb(c.tomb);
+        if (c.hctl) c.hctl[slot] = ctl_of_tomb(c.tomb);
         atomicSub(&c.g->n_live, 1u);
         if (h.rank) group_note(c, slot, w_old, 0ull);
         return;
@@ -661,7 +661,7 @@ __global__ void __launch_bounds__(256) k_init_state(ChainDev *chains) {
     fill16(ch.ub, sizeof(unsigned long long) * (size_t)ch.n_groups, 0u, t0, stride);
     fill16(ch.gdirty, (size_t)ch.n_groups, 0x01010101u, t0, stride);
     fill16(ch.colbits, sizeof(uint32_t) * (size_t)ch.n_out * ch.cb_words, 0u, t0, stride);
-    fill16(ch.hctl, (size_t)ch.C, 0u, t0, stride);
+    if (ch.hctl) fill16(ch.hctl, (size_t)ch.C, 0u, t0, stride);
     if (ch.ccell) fill16(ch.ccell, (size_t)ch.n_out * (size_t)ch.rcap * (size_t)ch.cell_bytes, 0u, t0, stride);
 }
 
@@ -1776,13 +1776,15 @@ __device__ __forceinline__ da_i4 ld_ctl(const Ctx &c, uint32_t bucket_base) { re
 // bucket: full search), CAND_NONE = the key is not in the table.
 constexpr uint32_t CAND_SLOW = 16, CAND_NONE = 17;
 __device__ __forceinline__ uint32_t ctl_candidate(const da_i4 &ct, uint32_t fp) {
+    // lowest set bit of ctl_eq = first matching byte; selects instead of branches (the threads of a wave disagree all the time)
     const uint32_t m0 = ctl_eq((uint32_t)ct.x, fp), m1 = ctl_eq((uint32_t)ct.y, fp), m2 = ctl_eq((uint32_t)ct.z, fp), m3 = ctl_eq((uint32_t)ct.w, fp);
-    if (m0) return (uint32_t)ctz32(m0) >> 3;
-    if (m1) return 4u + ((uint32_t)ctz32(m1) >> 3);
-    if (m2) return 8u + ((uint32_t)ctz32(m2) >> 3);
-    if (m3) return 12u + ((uint32_t)ctz32(m3) >> 3);
     const uint32_t e = ctl_eq((uint32_t)ct.x, 0u) | ctl_eq((uint32_t)ct.y, 0u) | ctl_eq((uint32_t)ct.z, 0u) | ctl_eq((uint32_t)ct.w, 0u);
-    return e ? CAND_NONE : CAND_SLOW;
+    uint32_t cand = e ? CAND_NONE : CAND_SLOW;
+    cand = m3 ? 12u + ((uint32_t)ctz32(m3 | 0x80000000u) >> 3) : cand;  // (the bit that is or-ed in keeps the count defined for m = 0; it is the highest one)
+    cand = m2 ? 8u + ((uint32_t)ctz32(m2 | 0x80000000u) >> 3) : cand;
+    cand = m1 ? 4u + ((uint32_t)ctz32(m1 | 0x80000000u) >> 3) : cand;
+    cand = m0 ? ((uint32_t)ctz32(m0 | 0x80000000u) >> 3) : cand;
+    return cand;
 }
 // item of a step's HEAVY list (partner rows that own a count block with A or B, or gain one with the new row):
 // row:24 | candidate of (A, row):5 | candidate of (B, row):5 | a count with the new row reached 2:1
@@ -1824,8 +1826,8 @@ __device__ __forceinline__ void group_apply(const Ctx &c, int slot, unsigned lon
 // the control bytes), so the key check, the payload lines and the row's cells in the substituted columns (column-major array) all
 // leave in ONE round trip.  s_cnt = this wave's counters [QN][3][Kpad]; item(i) = the i-th item.
 template <class Cell, class ItemFn>
-__device__ __forceinline__ void update_items(const Ctx &c, ItemFn item, int first, int stride, int n_items, uint32_t A, uint32_t B, uint32_t Nw, int m, size_t rcap,
-                                             const DA_GLOBAL Cell *cc, const int *s_col, const Cell *s_mA, const Cell *s_mB, uint32_t *s_cnt, const RowInfo &rnew,
+__device__ __forceinline__ void update_items(const Ctx &c, ItemFn item, int first, int stride, int n_items, uint32_t A, uint32_t B, uint32_t Nw, int m,
+                                             const DA_GLOBAL Cell *cc, const uint32_t *s_cbase, const Cell *s_mA, const Cell *s_mB, uint32_t *s_cnt, const RowInfo &rnew,
                                              unsigned int &found, unsigned int &inserts) {
     constexpr int QCW = sizeof(Cell) == 4 ? 2 : 4;
     const int nb = c.n_bits, Kpad = c.Kpad, K = c.K, KW = Kpad / 2;
@@ -1855,7 +1857,7 @@ __device__ __forceinline__ void update_items(const Ctx &c, ItemFn item, int firs
             wA[u] = (sA >= 0 && j < KW) ? reinterpret_cast<const DA_GLOBAL uint32_t *>(blk_ptr(c, sA) + 16)[j] : 0u;
             wB[u] = (sB >= 0 && j < KW) ? reinterpret_cast<const DA_GLOBAL uint32_t *>(blk_ptr(c, sB) + 16)[j] : 0u;
         }
-        const Cell x = (valid && l < m) ? cc[(size_t)s_col[l < m ? l : 0] * rcap + pr] : (Cell)0;  // m <= 16: one substituted column per lane
+        const Cell x = (valid && l < m) ? cc[s_cbase[l < m ? l : 0] + pr] : (Cell)0;  // m <= 16: one substituted column per lane (s_cbase: start of the column in the column-major cells)
         for (int k = l; k < 3 * Kpad; k += QG) dA[k] = 0;  // while the loads are in flight
         load_fence();
         if (sA >= 0 && kA != keyA) sA = SLOT_SLOW;  // a fingerprint collision: search the key (rare)
@@ -1917,8 +1919,9 @@ template <class Cell> __device__ __forceinline__ void steps_body(ChainDev *g, un
     using O = CellOps<Cell>;
     using F = RowFmt<Cell>;
     using Entry = typename F::Entry;
-    // ---- ONE scalar round trip: every descriptor field the launch needs, pinned before the first branch
-    int was_done = g->done, had_error = g->error, iter = g->iter, n_groups = g->n_groups, lcap = g->lcap, max_m = g->fuse_max_m, max_np = g->fuse_max_np;
+    // ---- ONE scalar round trip: the descriptor fields every step needs, pinned before the first branch.  (What only a handed-over
+    // step needs -- the hand-off arrays -- is read from the descriptor there: fewer live scalar registers in the loop.)
+    int was_done = g->done, had_error = g->error, iter = g->iter, n_groups = g->n_groups, lcap = g->lcap, max_m = g->fuse_max_m, max_np = g->fuse_max_np, max_nh = g->fuse_max_nh;
     int n_rows = g->n_rows, rcap = g->rcap, cbw = g->cb_words, adder_size = g->adder_size, carry_size = g->carry_size;
     uint32_t offN = g->rl_used, rl_cap = g->rl_cap, n_live0 = g->n_live, live_peak0 = g->live_peak;
     const uint32_t *step_mant = g->step_mant;
@@ -1929,23 +1932,21 @@ template <class Cell> __device__ __forceinline__ void steps_body(ChainDev *g, un
     DA_GLOBAL unsigned long long *gtie_arr = (DA_GLOBAL unsigned long long *)g->gtie;
     DA_GLOBAL da_u2 *rowoff = (DA_GLOBAL da_u2 *)g->rowoff;
     DA_GLOBAL Entry *rl = (DA_GLOBAL Entry *)g->rlist;
-    DA_GLOBAL Cell *mA = (DA_GLOBAL Cell *)g->mA, *mB = (DA_GLOBAL Cell *)g->mB;
-    DA_GLOBAL int *mcol = (DA_GLOBAL int *)g->mcol;
     DA_GLOBAL unsigned long long *collist = (DA_GLOBAL unsigned long long *)g->collist;
-    DA_GLOBAL uint16_t *cmap = (DA_GLOBAL uint16_t *)g->cmap;
     DA_GLOBAL uint32_t *colbits = (DA_GLOBAL uint32_t *)g->colbits;
     DA_GLOBAL uint32_t *pl_ids = (DA_GLOBAL uint32_t *)g->pl_ids;
     DA_GLOBAL unsigned long long *plist = (DA_GLOBAL unsigned long long *)g->plist;
     DA_GLOBAL da_i4 *picks = (DA_GLOBAL da_i4 *)g->picks;
     DA_GLOBAL Cell *ccell = (DA_GLOBAL Cell *)g->ccell;
-    pin_sgpr(was_done, had_error, iter, n_groups, lcap, max_m, max_np, n_rows, rcap, cbw, adder_size, carry_size, offN, rl_cap, n_live0, live_peak0, step_mant, step_tab, n_step_mant);
+    pin_sgpr(was_done, had_error, iter, n_groups, lcap, max_m, max_np, max_nh, n_rows, rcap, cbw, adder_size, carry_size, offN, rl_cap, n_live0, live_peak0, step_mant, step_tab, n_step_mant);
     pin_sgpr(c.n_out, c.n_bits, c.K, c.Kpad, c.method, c.gs_log2, c.pb_log2, c.cmask, c.windows, c.hkey, c.hrank, c.hblk, c.ub, c.gdirty, c.hctl, c.rows);
-    pin_sgpr(collen, gtie_arr, rowoff, rl, mA, mB, mcol, collist, cmap, colbits, pl_ids, plist, picks, ccell);
+    pin_sgpr(collen, gtie_arr, rowoff, rl, collist, colbits, pl_ids, plist, picks, ccell);
     ctx_finish(c);
     if (was_done) return;
     const int n_out = c.n_out, Kpad = c.Kpad, nb = c.n_bits;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // dynamic LDS carve: group bounds | stored tie words | B's list | consumed digits of A and B | special-pair counters | per-column scratch | dirty flags
+    // dynamic LDS carve: group bounds | stored tie words | B's list | consumed digits of A and B | special-pair counters | per-column scratch |
+    // pair counters of the heavy rows | dirty flags
     unsigned long long *l_ub = reinterpret_cast<unsigned long long *>(smem);         // [n_groups]
     unsigned long long *l_gt = l_ub + n_groups;                                       // [n_groups]
     Entry *s_bent = reinterpret_cast<Entry *>(l_gt + n_groups);                      // [n_out] entries of row B (updated in place)
@@ -1954,13 +1955,13 @@ template <class Cell> __device__ __forceinline__ void steps_body(ChainDev *g, un
     uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_mB + n_out);                    // [6][Kpad]
     int *s_len = reinterpret_cast<int *>(s_cnt + 6 * Kpad);                           // [n_out] pre-append list length of every substituted column
     int *s_col = s_len + n_out;                                                       // [n_out] substituted columns
-    int *s_bpos = s_col + n_out;                                                      // [n_out] 1 + position of a column in B's list, 0 = absent
+    int *s_bpos = s_col + n_out;                                                      // [n_out] 1 + position of a column in B's list, 0 = absent (all zero between the steps)
     int *s_clen = s_bpos + n_out;                                                     // [n_out] list length of every column (kept current across the steps)
-    int *s_cm = s_clen + n_out;                                                       // [n_out] 1 + index among the substituted columns, 0 = not substituted
+    uint32_t *s_cbase = reinterpret_cast<uint32_t *>(s_clen + n_out);                // [n_out] substituted column * rcap: start of the column in the column-major cells
     constexpr int NW = SEL_THREADS / WAVE;
-    uint32_t *s_ucnt = reinterpret_cast<uint32_t *>(s_cm + n_out);                   // [NW][QN][3][Kpad] pair counters of the heavy rows (update_items)
+    uint32_t *s_ucnt = s_cbase + n_out;                                              // [NW][QN][3][Kpad] pair counters of the heavy rows (update_items)
     uint8_t *l_dirty = reinterpret_cast<uint8_t *>(s_ucnt + (size_t)NW * QN * 3 * Kpad);  // [n_groups]
-    __shared__ unsigned long long s_red_tie[NW], s_floor0, s_floor;
+    __shared__ unsigned long long s_red_tie[NW], s_wfl[NW], s_floor;
     __shared__ uint32_t s_red_rank[NW];
     __shared__ int s_np, s_nh, s_part[NW];
     __shared__ unsigned int s_matches;
@@ -1992,35 +1993,34 @@ template <class Cell> __device__ __forceinline__ void steps_body(ChainDev *g, un
         l_gt[q] = gtv;
         l_dirty[q] = dv;
     }
-    for (int j = tid; j < n_out; j += SEL_THREADS) s_clen[j] = collen[j];
+    for (int j = tid; j < n_out; j += SEL_THREADS) {
+        s_clen[j] = collen[j];
+        s_bpos[j] = 0;
+    }
     if ((adder_size >= 0 || carry_size >= 0) && tid < (int)(sizeof(Log2Table) / 4)) reinterpret_cast<uint32_t *>(&s_log2)[tid] = reinterpret_cast<const uint32_t *>(&c_log2)[tid];
     if (tid < SS_N) s_stat[tid] = 0ull;
     if (tid == 0 && n_live0 > live_peak0) g->live_peak = n_live0;
     c.l_ub = (DA_LDS unsigned long long *)l_ub;
     c.l_dirty = (DA_LDS uint8_t *)l_dirty;
-    int m = 0, np = 0;
+    int m = 0, np = 0, nh = 0;
     uint32_t A = 0, B = 0, Nw = 0;
+    const int GPW = (n_groups + NW - 1) / NW;  // groups per wave, <= 4 * WAVE
 
     for (int step = 0; step < max_steps; ++step) {
-        // every store of the previous step (and of the prologue) is acknowledged and visible to the whole workgroup
         SEL_TIMER_DECL
         SEL_TIMER_MARK(0)
+        // every store of the previous step (and of the prologue) is acknowledged, then visible to the whole workgroup
         DA_DRAIN_VMEM();
         __syncthreads();
-        c.tomb = KEY_TOMB - (unsigned long long)((2 * iter) & 3);
-        // ---------------- (1) selection: as k_iter_select, with the bounds in LDS
-        if (tid == 0) {
+        if (tid == 0) {  // counters of the step (everybody has finished reading the previous step's values; the next barrier precedes their first use)
             s_np = 0;
             s_nh = 0;
             s_matches = 0;
-            s_floor0 = 0;
+            s_floor = 0;
         }
-        for (int j = tid; j < n_out; j += SEL_THREADS) {
-            s_cm[j] = 0;
-            s_bpos[j] = 0;
-        }
-        const int GPW = (n_groups + NW - 1) / NW;  // groups per wave, <= 4 * WAVE
-        unsigned long long ubr[4], gtr[4];
+        c.tomb = KEY_TOMB - (unsigned long long)((2 * iter) & 3);
+        // ---------------- (1) selection: as k_iter_select, with the bounds in LDS.  Wave w owns the groups [w GPW, (w + 1) GPW).
+        unsigned long long ubr[4];
         int dr[4];  // 0 clean on entry, 1 dirty, 2 verified in this step, 3 absent
         {
             unsigned long long cl = 0;
@@ -2030,13 +2030,11 @@ template <class Cell> __device__ __forceinline__ void steps_body(ChainDev *g, un
                 const bool in = lane + u * WAVE < GPW && q < n_groups;
                 const int qc = in ? q : 0;
                 ubr[u] = in ? l_ub[qc] : 0ull;
-                gtr[u] = l_gt[qc];
                 dr[u] = in ? (l_dirty[qc] ? 1 : 0) : 3;
                 if (dr[u] == 0) cl = max(cl, ubr[u]);
             }
-            __syncthreads();  // s_floor0 initialised
             cl = wave_max_u64(cl);
-            if (lane == 0 && cl) atomicMax(&s_floor0, cl);
+            if (lane == 0) s_wfl[wid] = cl;
         }
         __syncthreads();
         SEL_TIMER_MARK(1)
@@ -2045,24 +2043,27 @@ template <class Cell> __device__ __forceinline__ void steps_body(ChainDev *g, un
         RowInfo cand_ra, cand_rb;
         da_u2 cand_refA, cand_refB;
         {
-            const unsigned long long floor0 = s_floor0;
-            if (tid == 0) s_floor = floor0;
-            __syncthreads();
+            // the best clean bound: a floor of the answer (s_floor, zero at this point, collects the bounds the waves verify)
+            const unsigned long long floor0 = wave_max_u64(lane < NW ? s_wfl[lane] : 0ull);
             uint32_t wrank = 0;
             unsigned long long wtie = 0;
             unsigned int rescans = 0;
+            // groups that were clean on entry and tie the floor: their stored tie word decides
             unsigned long long clean_tie = 0;
             bool clean_any = false;
             if (floor0) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
                     if (dr[u] == 0 && ubr[u] == floor0) {
-                        clean_tie = gtr[u] > clean_tie ? gtr[u] : clean_tie;
+                        const unsigned long long gtv = l_gt[wid * GPW + lane + u * WAVE];
+                        clean_tie = gtv > clean_tie ? gtv : clean_tie;
                         clean_any = true;
                     }
             }
             while (true) {
-                const unsigned long long fl = __hip_atomic_load(&s_floor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                // the wave's highest dirty group is re-read while its (possibly stale) bound still reaches the rising floor
+                const unsigned long long flv = __hip_atomic_load(&s_floor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const unsigned long long fl = flv > floor0 ? flv : floor0;
                 unsigned long long top = 0;
                 int top_u = 0;
 #pragma unroll
@@ -2073,107 +2074,73 @@ template <class Cell> __device__ __forceinline__ void steps_body(ChainDev *g, un
                     }
                 const unsigned long long wtop = wave_max_u64(top);
                 if (wtop == 0 || wtop < fl) break;
-                int owner[2], own_u[2];
-                owner[0] = __ffsll((long long)__ballot(top == wtop)) - 1;
-                own_u[0] = __builtin_amdgcn_readlane(top_u, owner[0]);
-                unsigned long long top2 = 0;
-                int top2_u = 0;
+                const int owner = __ffsll((long long)__ballot(top == wtop)) - 1;
+                const int own_u = __builtin_amdgcn_readlane(top_u, owner);
+                const uint32_t grp = (uint32_t)(wid * GPW + owner + own_u * WAVE), base = grp << c.gs_log2;
+                uint32_t rk[8], grank = 0;
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    if (dr[u] == 1 && !(lane == owner[0] && u == own_u[0]) && ubr[u] > top2) {
-                        top2 = ubr[u];
-                        top2_u = u;
-                    }
-                const unsigned long long wtop2 = wave_max_u64(top2);
-                const int n_re = (wtop2 != 0 && wtop2 >= fl) ? 2 : 1;
-                owner[1] = n_re == 2 ? __ffsll((long long)__ballot(top2 == wtop2)) - 1 : 0;
-                own_u[1] = n_re == 2 ? __builtin_amdgcn_readlane(top2_u, owner[1]) : 0;
-                uint32_t grp[2], base[2], rk[2][8], grank[2] = {0, 0};
-                unsigned long long gt[2] = {0, 0};
-#pragma unroll
-                for (int r = 0; r < 2; ++r) {
-                    grp[r] = (uint32_t)(wid * GPW + owner[r] + own_u[r] * WAVE);
-                    base[r] = grp[r] * gs;
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const int o = lane + u * WAVE;
-                        rk[r][u] = (r < n_re && o < gs) ? c.hrank[base[r] + o] : 0u;
-                    }
+                for (int u = 0; u < 8; ++u) {
+                    const int o = lane + u * WAVE;
+                    rk[u] = o < gs ? c.hrank[base + (uint32_t)o] : 0u;
                 }
 #pragma unroll
-                for (int r = 0; r < 2; ++r) {
-                    if (r < n_re) {
+                for (int u = 0; u < 8; ++u) grank = max(grank, rk[u]);
+                for (int o = lane + 8 * WAVE; o < gs; o += WAVE) grank = max(grank, c.hrank[base + (uint32_t)o]);
+                grank = wave_max_u32(grank);
+                // the slots that hold the group's top rank: key and best-key index of ALL of them are fetched before the first is looked at
+                unsigned long long kk[8], gt = 0;
+                uint32_t bi[8];
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) grank[r] = max(grank[r], rk[r][u]);
-                        for (int o = lane + 8 * WAVE; o < gs; o += WAVE) grank[r] = max(grank[r], c.hrank[base[r] + o]);
+                for (int u = 0; u < 8; ++u) {
+                    const int o = lane + u * WAVE;
+                    kk[u] = 0;
+                    bi[u] = 0;
+                    if (grank && o < gs && rk[u] == grank) {
+                        kk[u] = ld_key(&c.hkey[base + (uint32_t)o]);
+                        bi[u] = load_best_idx(c, base + (uint32_t)o);
                     }
-                    grank[r] = wave_max_u32(grank[r]);
                 }
-                unsigned long long kk[2][8];
-                uint32_t bi[2][8];
-#pragma unroll
-                for (int r = 0; r < 2; ++r)
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const int o = lane + u * WAVE;
-                        kk[r][u] = 0;
-                        bi[r][u] = 0;
-                        if (grank[r] && o < gs && rk[r][u] == grank[r]) {
-                            kk[r][u] = ld_key(&c.hkey[base[r] + o]);
-                            bi[r][u] = load_best_idx(c, base[r] + o);
-                        }
-                    }
                 load_fence();
 #pragma unroll
-                for (int r = 0; r < 2; ++r)
+                for (int u = 0; u < 8; ++u) pin_vgpr(kk[u], bi[u]);
+                if (grank) {
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) pin_vgpr(kk[r][u], bi[r][u]);
-#pragma unroll
-                for (int r = 0; r < 2; ++r) {
-                    if (grank[r]) {
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) {
-                            const int o = lane + u * WAVE;
-                            if (o < gs && rk[r][u] == grank[r]) {
-                                const unsigned long long tw = tie_word((uint32_t)kk[r][u], (uint32_t)(kk[r][u] >> 32), (int)bi[r][u]);
-                                gt[r] = tw > gt[r] ? tw : gt[r];
-                            }
+                    for (int u = 0; u < 8; ++u) {
+                        const int o = lane + u * WAVE;
+                        if (o < gs && rk[u] == grank) {
+                            const unsigned long long tw = tie_word((uint32_t)kk[u], (uint32_t)(kk[u] >> 32), (int)bi[u]);
+                            gt = tw > gt ? tw : gt;
                         }
-                        for (int o = lane + 8 * WAVE; o < gs; o += WAVE)
-                            if (c.hrank[base[r] + o] == grank[r]) {
-                                const unsigned long long k2 = ld_key(&c.hkey[base[r] + o]);
-                                const unsigned long long tw = tie_word((uint32_t)k2, (uint32_t)(k2 >> 32), (int)load_best_idx(c, base[r] + o));
-                                gt[r] = tw > gt[r] ? tw : gt[r];
-                            }
                     }
-                }
-#pragma unroll
-                for (int r = 0; r < 2; ++r) {
-                    gt[r] = wave_max_u64(gt[r]);
-                    if (r < n_re) {
-                        const unsigned long long exact = grank[r] ? bound_word(grank[r], gt[r]) : 0ull;
-                        if (lane == owner[r]) {  // nobody writes the table during the selection: bound and tie are exact, the group is clean again
-#pragma unroll
-                            for (int u = 0; u < 4; ++u)
-                                if (u == own_u[r]) {
-                                    ubr[u] = exact;
-                                    dr[u] = 2;
-                                }
-                            l_ub[grp[r]] = exact;
-                            l_gt[grp[r]] = gt[r];
-                            l_dirty[grp[r]] = 0;
-                            c.ub[grp[r]] = exact;
-                            gtie_arr[grp[r]] = gt[r];
-                            c.gdirty[grp[r]] = 0;
-                            if (exact) atomicMax(&s_floor, exact);
+                    for (int o = lane + 8 * WAVE; o < gs; o += WAVE)
+                        if (c.hrank[base + (uint32_t)o] == grank) {
+                            const unsigned long long k2 = ld_key(&c.hkey[base + (uint32_t)o]);
+                            const unsigned long long tw = tie_word((uint32_t)k2, (uint32_t)(k2 >> 32), (int)load_best_idx(c, base + (uint32_t)o));
+                            gt = tw > gt ? tw : gt;
                         }
-                        if (grank[r] > wrank || (grank[r] == wrank && gt[r] > wtie)) {
-                            wrank = grank[r];
-                            wtie = gt[r];
-                        }
-                        ++rescans;
-                    }
                 }
+                gt = wave_max_u64(gt);
+                const unsigned long long exact = grank ? bound_word(grank, gt) : 0ull;
+                if (lane == owner) {  // nobody writes the table during the selection: bound and tie are exact, the group is clean again
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (u == own_u) {
+                            ubr[u] = exact;
+                            dr[u] = 2;
+                        }
+                    l_ub[grp] = exact;
+                    l_gt[grp] = gt;
+                    l_dirty[grp] = 0;
+                    c.ub[grp] = exact;
+                    gtie_arr[grp] = gt;
+                    c.gdirty[grp] = 0;
+                    if (exact) atomicMax(&s_floor, exact);
+                }
+                if (grank > wrank || (grank == wrank && gt > wtie)) {
+                    wrank = grank;
+                    wtie = gt;
+                }
+                ++rescans;
                 lds_fence();
             }
             if (floor0) {
@@ -2314,20 +2281,21 @@ template <class Cell> __device__ __forceinline__ void steps_body(ChainDev *g, un
             }
             if (hit) {
                 const int at = m + wbase + __popcll(bal & ((1ull << lane) - 1));
+                const uint32_t cbase = colA * (uint32_t)rcap;
                 rlA[t] = F::pack(colA, na);
                 if (!same) s_bent[pos - 1] = F::pack(colA, nbv);
                 rlN[at] = F::pack(colA, ma);
                 s_mA[at] = ma;
                 s_mB[at] = mb;
-                s_cm[colA] = at + 1;
+                s_cbase[at] = cbase;
                 {  // row bitmaps of this column: the new row enters, a row whose cell just lost its last digit leaves
-                    DA_GLOBAL uint32_t *cb = colbits + (size_t)colA * cbw;
+                    DA_GLOBAL uint32_t *cb = colbits + colA * (uint32_t)cbw;
                     atomicOr(gen(&cb[Nw >> 5]), 1u << (Nw & 31));
                     if (na == 0) atomicAnd(gen(&cb[A >> 5]), ~(1u << (A & 31)));
                     if (!same && nbv == 0) atomicAnd(gen(&cb[B >> 5]), ~(1u << (B & 31)));
                 }
                 {  // column-major copy of the three cells
-                    DA_GLOBAL Cell *cc = ccell + (size_t)colA * (size_t)rcap;
+                    DA_GLOBAL Cell *cc = ccell + cbase;
                     cc[A] = na;
                     if (!same) cc[B] = nbv;
                     cc[Nw] = ma;
@@ -2348,11 +2316,12 @@ template <class Cell> __device__ __forceinline__ void steps_body(ChainDev *g, un
             __syncthreads();  // s_part is reused by the next chunk; s_bent updates visible to pass 2
         }
         if (my_matches) atomicAdd(&s_matches, my_matches);
-        // pass 2: B's list back to memory, self pairs of what is left of B
+        // pass 2: B's list back to memory, self pairs of what is left of B; the column -> position map returns to all zero
         if (!same)
             for (int t = tid; t < lenB; t += SEL_THREADS) {
                 const Entry e = s_bent[t];
                 rlB[t] = e;
+                s_bpos[F::col(e)] = 0;
                 const Cell nbv = F::cell(e);
                 if (nbv) for_pairs_self<Cell>(nbv, nb, [&](int k) { atomicAdd(&cBB[k], 1u); });
             }
@@ -2381,7 +2350,7 @@ template <class Cell> __device__ __forceinline__ void steps_body(ChainDev *g, un
                 const int w = wb + lane;
                 uint32_t bits = 0;
                 if (w < nwords) {
-                    for (int k = 0; k < m; ++k) bits |= ld_l2_u32(&cb[(size_t)s_col[k] * cbw + w]);  // the bitmaps are modified by atomics: read past the L1
+                    for (int k = 0; k < m; ++k) bits |= ld_l2_u32(&cb[(uint32_t)s_col[k] * (uint32_t)cbw + (uint32_t)w]);  // the bitmaps are modified by atomics: read past the L1
                     if ((int)(A >> 5) == w) bits &= ~(1u << (A & 31));
                     if ((int)(B >> 5) == w) bits &= ~(1u << (B & 31));
                     if ((int)(Nw >> 5) == w) bits &= ~(1u << (Nw & 31));
@@ -2444,40 +2413,14 @@ template <class Cell> __device__ __forceinline__ void steps_body(ChainDev *g, un
             atomicAdd(&s_stat[SS_SELBYTES], 48ull + 2ull * eb * (unsigned)(lenA + (same ? 0 : lenB)) + 4ull * (unsigned)m * nwords + 4ull * (unsigned)np +
                                                 (unsigned)m * (eb + 8ull + 12ull + 3ull * cbts) + 6ull * (16ull + 4ull * (unsigned)c.K) + 32ull);
         }
-        if (m > max_m || np > max_np) {
-            // ---- the step's update is handed to k_iter_update, as k_iter_select would: consumed digits, substituted columns, column
-            // map, partner list with list references
-            for (int j = tid; j < n_out; j += SEL_THREADS) cmap[j] = (uint16_t)s_cm[j];
-            for (int k = tid; k < m; k += SEL_THREADS) {
-                mcol[k] = s_col[k];
-                mA[k] = s_mA[k];
-                mB[k] = s_mB[k];
-            }
-            for (int t = tid; t < np; t += 2 * SEL_THREADS) {
-                const int t2 = t + SEL_THREADS;
-                const bool has2 = t2 < np;
-                const uint32_t r1 = t < IDS_LDS ? s_ids[t] : pl_ids[t];
-                const uint32_t r2 = !has2 ? r1 : t2 < IDS_LDS ? s_ids[t2] : pl_ids[t2];
-                const da_u2 ro1 = rowoff[r1], ro2 = rowoff[r2];
-                load_fence();
-                plist[t] = ref_pack(r1, ro1.y, ro1.x);
-                if (has2) plist[t2] = ref_pack(r2, ro2.y, ro2.x);
-            }
-            if (tid == 0) atomicAdd(&s_stat[SS_SELBYTES], 2ull * (unsigned)n_out + (unsigned)m * (4ull + 2ull * cbts) + 16ull * (unsigned)np);
-            status = 2;
-            offN += (uint32_t)m;
-            n_rows += 1;
-            iter += 1;
-            break;
-        }
+        const bool too_fat = m > max_m || np > max_np;
         // ---------------- (5) the update.  Phase A, THREAD PER PARTNER ROW: control bytes of the two buckets the row's blocks with A
         // and B would live in, and its cells in the substituted columns -- one round trip; a row that owns no such block and gains
         // none with the new row (nearly all of them, late in a chain) is finished.  The others go to the heavy list.
-        {
-            Ctx cu = c;
-            cu.tomb = KEY_TOMB - (unsigned long long)((2 * iter + 1) & 3);
-            const DA_GLOBAL Cell *cc = ccell;
-            const size_t rcs = (size_t)rcap;
+        Ctx cu = c;
+        cu.tomb = KEY_TOMB - (unsigned long long)((2 * iter + 1) & 3);
+        const DA_GLOBAL Cell *cc = ccell;
+        if (!too_fat) {
             for (int t0 = wid * WAVE; t0 < np; t0 += SEL_THREADS) {  // wave-uniform trip count
                 const int t = t0 + lane;
                 const bool valid = t < np;
@@ -2488,7 +2431,7 @@ template <class Cell> __device__ __forceinline__ void steps_body(ChainDev *g, un
                 const da_i4 ctB = ld_ctl(cu, (hash_pair(lB, hB) & ~(BUCKET - 1)) & cu.cmask);
                 Cell x[TPP_CH];
 #pragma unroll
-                for (int u = 0; u < TPP_CH; ++u) x[u] = cc[(size_t)s_col[u < m ? u : 0] * rcs + r];
+                for (int u = 0; u < TPP_CH; ++u) x[u] = cc[s_cbase[u < m ? u : 0] + r];
                 load_fence();
                 const uint32_t ca = ctl_candidate(ctA, ctl_fp(lA, hA)), cb = same ? CAND_NONE : ctl_candidate(ctB, ctl_fp(lB, hB));
                 // does a key of the pair (row, new row) reach a count of 2?  two saturating bit planes: seen once / seen twice
@@ -2496,7 +2439,7 @@ template <class Cell> __device__ __forceinline__ void steps_body(ChainDev *g, un
                 for (int k0 = 0; k0 < m; k0 += TPP_CH) {
                     if (k0) {
 #pragma unroll
-                        for (int u = 0; u < TPP_CH; ++u) x[u] = cc[(size_t)s_col[k0 + u < m ? k0 + u : 0] * rcs + r];
+                        for (int u = 0; u < TPP_CH; ++u) x[u] = cc[s_cbase[k0 + u < m ? k0 + u : 0] + r];
                     }
 #pragma unroll
                     for (int u = 0; u < TPP_CH; ++u) {
@@ -2522,30 +2465,80 @@ template <class Cell> __device__ __forceinline__ void steps_body(ChainDev *g, un
                         if (at < IDS_LDS)
                             s_items[at] = it;
                         else
-                            plist[at] = it;  // (the partner list of k_iter_update: unused in a step that is updated here)
+                            plist[at] = it;  // (the partner list of k_iter_update: rewritten below if the step is handed over)
                     }
                 }
             }
             DA_DRAIN_VMEM();
             __syncthreads();
-            SEL_TIMER_MARK(6)
-            // Phase B: the heavy rows, a 16-lane group each (update_items)
-            const int nh = s_nh;
-            if (nh) {
-                const RowInfo rnew = s_new;
-                unsigned int found = 0, inserts = 0;
-                update_items<Cell>(cu, [&](int i) { return i < IDS_LDS ? s_items[i] : plist[i]; }, wid * QN, NW * QN, nh, A, B, Nw, m, rcs, cc, s_col, s_mA, s_mB,
-                                   s_ucnt + (size_t)wid * QN * 3 * Kpad, rnew, found, inserts);
-                if (lane == 0 && (found | inserts)) {
-                    if (found) atomicAdd(&s_stat[SS_FOUND], (unsigned long long)found);
-                    if (inserts) atomicAdd(&s_stat[SS_INSERTS], (unsigned long long)inserts);
+            nh = s_nh;
+        }
+        SEL_TIMER_MARK(6)
+        if (too_fat || nh > max_nh) {
+            // ---- the step's update is handed to k_iter_update, as k_iter_select would: consumed digits, substituted columns, column
+            // map, partner list with list references -- of the heavy rows only if the filter ran (the others have nothing to update)
+            DA_GLOBAL Cell *mA = (DA_GLOBAL Cell *)g->mA, *mB = (DA_GLOBAL Cell *)g->mB;
+            DA_GLOBAL int *mcol = (DA_GLOBAL int *)g->mcol;
+            DA_GLOBAL uint16_t *cmap = (DA_GLOBAL uint16_t *)g->cmap;
+            for (int j = tid; j < n_out; j += SEL_THREADS) cmap[j] = 0;
+            const int nl = too_fat ? np : nh;
+            unsigned long long ref1 = 0, ref2 = 0;  // (a heavy item and its list reference share the slot in plist: read all, barrier, write)
+            const int t1 = tid, t2 = tid + SEL_THREADS;
+            auto row_of = [&](int t) -> uint32_t {
+                if (too_fat) return t < IDS_LDS ? s_ids[t] : pl_ids[t];
+                return (uint32_t)(t < IDS_LDS ? s_items[t] : plist[t]) & 0xFFFFFFu;
+            };
+            if (nl <= 2 * SEL_THREADS) {
+                const uint32_t r1 = t1 < nl ? row_of(t1) : 0u, r2 = t2 < nl ? row_of(t2) : 0u;
+                const da_u2 ro1 = rowoff[r1], ro2 = rowoff[r2];
+                load_fence();
+                ref1 = ref_pack(r1, ro1.y, ro1.x);
+                ref2 = ref_pack(r2, ro2.y, ro2.x);
+            }
+            DA_DRAIN_VMEM();
+            __syncthreads();  // cmap zeroed (acknowledged: other threads write its entries next); every heavy item read
+            for (int k = tid; k < m; k += SEL_THREADS) {
+                mcol[k] = s_col[k];
+                mA[k] = s_mA[k];
+                mB[k] = s_mB[k];
+                cmap[s_col[k]] = (uint16_t)(k + 1);
+            }
+            if (nl <= 2 * SEL_THREADS) {
+                if (t1 < nl) plist[t1] = ref1;
+                if (t2 < nl) plist[t2] = ref2;
+            } else {  // (only an unfiltered list can be this long: its ids are in s_ids / pl_ids, not in plist)
+                for (int t = tid; t < nl; t += SEL_THREADS) {
+                    const uint32_t r1 = row_of(t);
+                    const da_u2 ro1 = rowoff[r1];
+                    plist[t] = ref_pack(r1, ro1.y, ro1.x);
                 }
             }
             if (tid == 0) {
-                atomicAdd(&s_stat[SS_FUSED], 1ull);
-                // algorithmic bytes of the in-kernel update: per partner row two control-byte buckets and m cells; per heavy row its item
-                atomicAdd(&s_stat[SS_TPPBYTES], (unsigned long long)np * (32ull + cbts * (unsigned)m) + 16ull * (unsigned)nh);
+                atomicAdd(&s_stat[SS_SELBYTES], 2ull * (unsigned)n_out + (unsigned)m * (4ull + 2ull * cbts) + 16ull * (unsigned)nl);
+                if (!too_fat) atomicAdd(&s_stat[SS_TPPBYTES], (unsigned long long)np * (32ull + cbts * (unsigned)m) + 16ull * (unsigned)nh);
             }
+            np = nl;
+            status = 2;
+            offN += (uint32_t)m;
+            n_rows += 1;
+            iter += 1;
+            break;
+        }
+        // Phase B: the heavy rows, a 16-lane group each (update_items)
+        if (nh) {
+            const RowInfo rnew = s_new;
+            unsigned int found = 0, inserts = 0;
+            update_items<Cell>(cu, [&](int i) { return i < IDS_LDS ? s_items[i] : plist[i]; }, wid * QN, NW * QN, nh, A, B, Nw, m, cc, s_cbase, s_mA, s_mB,
+                               s_ucnt + (size_t)wid * QN * 3 * Kpad, rnew, found, inserts);
+            if (lane == 0 && (found | inserts)) {
+                if (found) atomicAdd(&s_stat[SS_FOUND], (unsigned long long)found);
+                if (inserts) atomicAdd(&s_stat[SS_INSERTS], (unsigned long long)inserts);
+            }
+        }
+        if (tid == 0) {
+            atomicAdd(&s_stat[SS_FUSED], 1ull);
+            // algorithmic bytes of the in-kernel update: per partner row two control-byte buckets and m cells; per heavy row its item
+            atomicAdd(&s_stat[SS_TPPBYTES], (unsigned long long)np * (32ull + cbts * (unsigned)m) + 16ull * (unsigned)nh);
         }
 #ifdef DA_PHASE_TIMERS
         __syncthreads();  // the update of all heavy rows has been issued
@@ -2558,6 +2551,7 @@ template <class Cell> __device__ __forceinline__ void steps_body(ChainDev *g, un
         n_rows += 1;
         iter += 1;
         np = 0;
+        nh = 0;
     }
     // ---- the launch ends: mutable chain state and statistics back into the descriptor (read by the next launch, by k_iter_update
     // if a step was handed over, and by the host at the end of the chain)
@@ -3013,11 +3007,14 @@ struct HipBackend::Impl {
     hipStream_t poll_stream = nullptr;
     GpuTimings timings;
     double table_scale = 1.0;  // grows on E_TABLE_CAPACITY retries
-    // greedy loop of the narrow chains: k_steps runs up to `fuse_steps` greedy steps per launch in one workgroup per chain and
-    // applies a step's update itself unless the step substitutes more than fuse_max_m columns or has more than fuse_max_np partner
-    // rows (then k_iter_update, launched after every k_steps, does it).  fuse_steps = 0: the (k_iter_select, k_iter_update) pair
-    // per step, as for wide chains.
-    int fuse_steps = 8, fuse_max_m = 8, fuse_max_np = 2048;
+    // greedy loop of the narrow chains.  fuse_steps = 0 (default): the (k_iter_select, k_iter_update) pair per step, as for wide
+    // chains.  fuse_steps = K > 0 (DA4ML_HIP_FUSE, opt-in): k_steps runs up to K greedy steps per launch in one workgroup per chain
+    // and applies a step's update itself unless the step substitutes more than fuse_max_m columns, has more than fuse_max_np partner
+    // rows or more than fuse_max_nh of them own / gain a count block (then k_iter_update, launched after every k_steps, does it).
+    // Exact (GPU parity suite under all settings), but SLOWER on MI355X -- 29 against 27 us per step for one 256x256 chain, worse in
+    // batches and on small problems (profiles/r04_step_engine.txt): one CU's instruction issue is the bound of a step that is not
+    // spread over the chip, DESIGN.md section 9.  Kept as the measured answer, not as the product path.
+    int fuse_steps = 0, fuse_max_m = 8, fuse_max_np = 2048, fuse_max_nh = 96;
 };
 
 HipBackend::HipBackend(int device) : impl_(new Impl) {
@@ -3033,6 +3030,7 @@ HipBackend::HipBackend(int device) : impl_(new Impl) {
     if (const char *e = std::getenv("DA4ML_HIP_FUSE")) impl_->fuse_steps = std::max(0, std::min(4096, std::atoi(e)));
     if (const char *e = std::getenv("DA4ML_HIP_FUSE_M")) impl_->fuse_max_m = std::max(0, std::atoi(e));
     if (const char *e = std::getenv("DA4ML_HIP_FUSE_NP")) impl_->fuse_max_np = std::max(0, std::atoi(e));
+    if (const char *e = std::getenv("DA4ML_HIP_FUSE_NH")) impl_->fuse_max_nh = std::max(0, std::atoi(e));
     HIP_CHECK(hipMalloc(&impl_->d_done, sizeof(unsigned int)));
     HIP_CHECK(hipHostMalloc(&impl_->h_done, 2 * sizeof(unsigned int), hipHostMallocDefault));
     HIP_CHECK(hipStreamCreateWithFlags(&impl_->poll_stream, hipStreamNonBlocking));
@@ -3075,7 +3073,7 @@ size_t carve_chain(unsigned char *base, const ChainJob &job, const Geometry &g, 
     d.hkey = c.take<unsigned long long>(g.C);
     d.hrank = c.take<uint32_t>(g.C);
     d.hblk = c.take<unsigned char>((size_t)g.C << g.pb_log2);
-    d.hctl = c.take<uint8_t>(g.C);
+    d.hctl = g.fuse ? c.take<uint8_t>(g.C) : nullptr;
     d.ccell = g.fuse ? c.take<unsigned char>(n_out * (size_t)g.rcap * cell) : nullptr;
     d.cell_bytes = (int)cell;
     d.ub = c.take<unsigned long long>(g.n_groups);
@@ -3268,7 +3266,8 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
         d.done = (jobs[i].method == M_DUMMY || jobs[i].method < 0) ? 1 : 0;
         d.cb_words = (g.rcap + 31) / 32;
         d.fuse_max_m = std::min(im.fuse_max_m, QG);  // update_items: one substituted column per lane of a 16-lane group
-        d.fuse_max_np = im.fuse_max_np;
+        d.fuse_max_np = std::min(im.fuse_max_np, 2 * SEL_THREADS);  // a filtered hand-off rewrites the heavy list in place: two items per thread
+        d.fuse_max_nh = im.fuse_max_nh;
     }
     // -log2f tables of non-power-of-two input steps (rare: the tracer's `variable * 3`), by the host libm; they stay alive until
     // the set-up stream has been synchronised below
@@ -3748,7 +3747,6 @@ class HipShardEngine : public ShardEngine {
         HIP_CHECK(hipMemsetAsync(d_.stamp, 0, sizeof(uint32_t) * (size_t)g.rcap, st_));
         HIP_CHECK(hipMemsetAsync(d_.hkey, 0xFF, sizeof(unsigned long long) * (size_t)g.C, st_));
         HIP_CHECK(hipMemsetAsync(d_.hrank, 0, sizeof(uint32_t) * (size_t)g.C, st_));
-        HIP_CHECK(hipMemsetAsync(d_.hctl, 0, (size_t)g.C, st_));
         HIP_CHECK(hipMemsetAsync(d_.ub, 0, sizeof(unsigned long long) * (size_t)g.n_groups, st_));
         HIP_CHECK(hipMemsetAsync(d_.gdirty, 1, (size_t)g.n_groups, st_));
         d_.cb_words = (g.rcap + 31) / 32;

@@ -61,9 +61,10 @@ def test_batched_chains(emu):
     {'DA4ML_HIP_FUSE': '0'},
     {'DA4ML_HIP_FUSE': '1'},
     {'DA4ML_HIP_FUSE': '64'},
-    {'DA4ML_HIP_FUSE_M': '2', 'DA4ML_HIP_FUSE_NP': '12'},
-    {'DA4ML_HIP_FUSE_M': '100', 'DA4ML_HIP_FUSE_NP': '1000000'},
-], ids=['pair', 'steps1', 'steps64', 'mixed', 'all_fused'])
+    {'DA4ML_HIP_FUSE': '8', 'DA4ML_HIP_FUSE_M': '2', 'DA4ML_HIP_FUSE_NP': '12'},
+    {'DA4ML_HIP_FUSE': '8', 'DA4ML_HIP_FUSE_NH': '3'},
+    {'DA4ML_HIP_FUSE': '8', 'DA4ML_HIP_FUSE_M': '100', 'DA4ML_HIP_FUSE_NP': '1000000', 'DA4ML_HIP_FUSE_NH': '1000000'},
+], ids=['pair', 'steps1', 'steps64', 'mixed', 'filtered_handoff', 'all_fused'])
 def test_step_engine_settings(emu, env):
     """k_steps -- several greedy steps per launch, the update applied by the selecting workgroup itself, thread per partner row,
     table probed through its control bytes -- under every setting of its knobs, next to the kernel pair it replaces for narrow

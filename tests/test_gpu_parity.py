@@ -331,9 +331,10 @@ def test_repeated_solves_are_deterministic(hip, oracle):
     {'DA4ML_HIP_FUSE': '0'},                                                    # the (k_iter_select, k_iter_update) pair for every step
     {'DA4ML_HIP_FUSE': '1'},                                                    # k_steps, one step per launch
     {'DA4ML_HIP_FUSE': '64'},                                                   # up to 64 steps per launch
-    {'DA4ML_HIP_FUSE_M': '2', 'DA4ML_HIP_FUSE_NP': '48'},                       # fused steps and hand-offs interleaved
-    {'DA4ML_HIP_FUSE_M': '100', 'DA4ML_HIP_FUSE_NP': '1000000'},                # every step updated inside k_steps (thread per partner row)
-], ids=['pair', 'steps1', 'steps64', 'mixed', 'all_fused'])
+    {'DA4ML_HIP_FUSE': '8', 'DA4ML_HIP_FUSE_M': '2', 'DA4ML_HIP_FUSE_NP': '48'},                       # fused steps and hand-offs interleaved
+    {'DA4ML_HIP_FUSE': '8', 'DA4ML_HIP_FUSE_NH': '3'},                          # the filter runs, then nearly every step hands its heavy rows to k_iter_update
+    {'DA4ML_HIP_FUSE': '8', 'DA4ML_HIP_FUSE_M': '100', 'DA4ML_HIP_FUSE_NP': '1000000', 'DA4ML_HIP_FUSE_NH': '1000000'},  # every step the kernel can take is updated inside k_steps
+], ids=['pair', 'steps1', 'steps64', 'mixed', 'filtered_handoff', 'all_fused'])
 def test_step_engine_settings(oracle, env):
     """k_steps (several greedy steps per launch, updates applied by the selecting workgroup itself, thread per partner row) against
     the kernel pair it replaces for narrow chains: whatever the steps per launch and wherever the line between in-kernel updates
@@ -370,7 +371,7 @@ def test_step_engine_settings(oracle, env):
     assert r['bad'] == [] and r['sha'] == rec['sha256']
     if env.get('DA4ML_HIP_FUSE') == '0':
         assert r['fused'] == 0 and r['handoffs'] == 0
-    elif env.get('DA4ML_HIP_FUSE_M') == '100':  # (the host still caps the columns per in-kernel update by what the 7-bit pair counters hold)
+    elif env.get('DA4ML_HIP_FUSE_M') == '100':  # (the host still caps the substituted columns per in-kernel update at 16, one per lane of a group)
         assert r['fused'] > 1000
     else:
         assert r['fused'] > 0 and r['handoffs'] > 0
