@@ -27,7 +27,7 @@ _i32p = np.ctypeslib.ndpointer(np.int32, flags='C_CONTIGUOUS')
 
 EXPORTS = (
     'da_last_error da_last_error_code da_version da_device_count da_set_device da_get_lsb_loc da_iceil_log2 da_cost_add da_int_arr_to_csd '
-    'da_csd_decompose da_kernel_decompose da_solve da_solve_batch da_solve_sharded da_rccl_unique_id da_solve_sharded_rccl da_comm_abort da_n_stages da_picked da_stage_info da_stage_copy '
+    'da_csd_decompose da_kernel_decompose da_solve da_solve_batch da_solve_sharded da_rccl_unique_id da_rccl_shutdown da_solve_sharded_rccl da_comm_abort da_n_stages da_picked da_stage_info da_stage_copy '
     'da_result_stats da_free da_timings da_engine_stats da_dais_run da_dais_last_error da_dais_run_on'
 ).split()
 
@@ -87,6 +87,8 @@ def lib():
     L.da_result_stats.argtypes = [C.c_void_p, _i64p]
     L.da_free.argtypes = [C.c_void_p]
     L.da_rccl_unique_id.argtypes = [C.c_char_p]
+    L.da_rccl_shutdown.restype = C.c_int
+    L.da_rccl_shutdown.argtypes = []
     L.da_solve_sharded_rccl.restype = C.c_void_p
     L.da_solve_sharded_rccl.argtypes = [_f32p, C.c_int64, C.c_int64, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                         C.c_int, C.c_int, C.c_char_p, _i64p]
@@ -260,6 +262,15 @@ def rccl_unique_id() -> bytes:
     if rc != 0:
         _raise(rc)
     return buf.raw
+
+
+def rccl_shutdown() -> int:
+    """Destroy the RCCL communicators the library keeps (one per unique id it was handed) and free their staging buffers;
+    returns how many there were.  Every rank calls it, with no solve running and the process group still alive."""
+    n = lib().da_rccl_shutdown()
+    if n < 0:
+        _raise(1)
+    return n
 
 
 def solve_sharded_rccl(kernel, unique_id: bytes, method0: str = 'wmc', method1: str = 'auto', hard_dc: int = -1, decompose_dc: int = -2, qintervals=None,

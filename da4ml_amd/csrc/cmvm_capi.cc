@@ -12,6 +12,7 @@
 #include <cstring>
 #include <memory>
 #include <mutex>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -25,9 +26,12 @@ namespace {
 
 thread_local std::string g_err;
 thread_local int g_err_code = DA_OK;  // DA_ERR_* of the calling thread's last failure (da_last_error_code)
-// The library lock.  fork(): taken before the fork and released on both sides, so that a child never inherits it locked by a
-// thread that does not exist there (its first call would hang); a thread that forks while it holds the lock itself -- from
-// inside the all-reduce callback -- keeps it through the fork.
+// The library lock, held for a whole solve.  fork(): the CHILD gets a fresh, unlocked mutex (the thread that may have held the
+// parent's does not exist there; its first call would hang on an inherited locked one).  Nothing is taken in the parent: a
+// prepare handler that waited for the lock would stall fork() for a whole solve -- minutes -- and, called from a Python thread,
+// would do so holding the GIL, which the all-reduce callback of a sharded solve running in another thread needs: a deadlock.
+// A fork while ANOTHER thread is inside a solve leaves the child with library state caught mid-update: unsupported (as is any use
+// of a HIP context in a forked child); forking between solves, or from inside the all-reduce callback, is fine.
 struct LibraryMutex {
     std::mutex m;
     static thread_local bool mine;
@@ -40,7 +44,10 @@ struct LibraryMutex {
         m.unlock();
     }
     LibraryMutex() {
-        pthread_atfork([] { if (!mine) instance->m.lock(); }, [] { if (!mine) instance->m.unlock(); }, [] { if (!mine) instance->m.unlock(); });
+        pthread_atfork(nullptr, nullptr, [] {
+            if (!mine) new (&instance->m) std::mutex();  // (the inherited one may be locked by a thread that was not copied; it is never
+                                                         // destroyed.  Held by the forking thread itself: it exists in the child and goes on holding it)
+        });
         instance = this;
     }
     static LibraryMutex *instance;
@@ -74,21 +81,17 @@ int fail(const std::exception &e) {
 
 // Steps the latency model has no logarithm for are refused up front: non-positive, NaN / infinite and subnormal ones (the
 // reference computes -log2 of whatever it is given; a result with infinite or NaN latencies is of no use to anybody).  Steps
-// that are not powers of two are accepted (StepLog2, cmvm_core.h) up to STEP_MANTS distinct mantissas per matrix.
+// that are not powers of two are accepted, any number of them (StepLog2, cmvm_core.h: one table row per distinct mantissa).
 void check_dyadic_steps(const float *q, int64_t n_in) {
     if (!q) return;
-    std::vector<uint32_t> mants;
     for (int64_t i = 0; i < n_in; ++i) {
         float lo = q[3 * i], hi = q[3 * i + 1], st = q[3 * i + 2];
         if (lo == 0.0f && hi == 0.0f) continue;  // constant-zero input: its digits are dropped, the step is never used
         uint32_t b;
         std::memcpy(&b, &st, 4);
-        const uint32_t e = (b >> 23) & 0xFF, m = b & 0x7FFFFFu;
+        const uint32_t e = (b >> 23) & 0xFF;
         if ((b >> 31) || e == 0 || e == 255) throw std::invalid_argument("qintervals[" + std::to_string(i) + "].step must be a positive normal number");
-        if (m && std::find(mants.begin(), mants.end(), m) == mants.end()) mants.push_back(m);
     }
-    if ((int)mants.size() > da::STEP_MANTS)
-        throw std::invalid_argument("more than " + std::to_string(da::STEP_MANTS) + " distinct non-power-of-two quantisation steps in one matrix are not supported");
 }
 
 }  // namespace
@@ -233,6 +236,16 @@ int da_rccl_unique_id(void *id128) {
         return DA_OK;
     } catch (const std::exception &e) {
         return fail(e);
+    }
+}
+
+int da_rccl_shutdown(void) {
+    std::lock_guard<LibraryMutex> lk(g_mutex);
+    try {
+        return da::gpu::rccl_shutdown();
+    } catch (const std::exception &e) {
+        fail(e);
+        return -1;
     }
 }
 

@@ -31,8 +31,9 @@ enum ChainError : int {
     E_ROW_CAPACITY = 1,    // more greedy iterations than the row arena holds
     E_TABLE_CAPACITY = 2,  // pair-block table arena too small
     E_LIST_CAPACITY = 3,   // a column row-list overflowed (cannot happen with the exact bound; guarded anyway)
-    E_FLOAT_DOMAIN = 4,    // the latency model met a step it has no logarithm for (subnormal / non-positive, or more than STEP_MANTS distinct non-power-of-two mantissas)
+    E_FLOAT_DOMAIN = 4,    // the latency model met a step it has no logarithm for (subnormal / non-positive)
     E_COUNT_OVERFLOW = 5,  // a pair count exceeded 16 bits
+    E_REMOTE_ERROR = 6,    // column-sharded chain: another rank failed with something other than a capacity error, or the ranks fell out of step -- not worth a retry
 };
 
 struct RowInfo {  // quantised interval + latency of one row (reference Op.qint / Op.latency)
@@ -346,10 +347,10 @@ DA_HD float ceil_log2f_emul(float x, const Log2Table &tab, int &domain_err) {
 }
 // -std::log2(step) (state_opr.cc:57).  A power of two is read off the exponent.  Any other step gets the HOST libm's value from a
 // table: every row's step is an input step times a power of two (qint_add keeps min(step0, step1 * 2^shift)), so only the
-// mantissas of the input steps ever occur; for each of them (at most STEP_MANTS per chain) the host tabulates
-// -log2f(mantissa * 2^(e - 127)) for all 254 normal exponents with its own std::log2 -- exact by construction, no libm
-// re-implementation on the device.
-constexpr int STEP_MANTS = 8;
+// mantissas of the input steps ever occur; for each of them the host tabulates -log2f(mantissa * 2^(e - 127)) for all 254
+// normal exponents with its own std::log2 -- exact by construction, no libm re-implementation on the device.  (One table row per
+// distinct mantissa, as many as the inputs have: the look-up is a linear search, and matrices with more than a handful of
+// different odd step mantissas do not come out of the tracer.)
 struct StepLog2 {
     int n;                 // distinct non-power-of-two step mantissas of the chain's inputs
     const uint32_t *mant;  // [n] their 23 mantissa bits

@@ -388,7 +388,7 @@ struct Ctx {
 // control byte of a tombstone written with `tomb` / fingerprint of a row pair (5..255; independent of the slot hash)
 __device__ __forceinline__ uint8_t ctl_of_tomb(unsigned long long tomb) { return (uint8_t)(1u + (uint32_t)(KEY_TOMB - tomb)); }
 __device__ __forceinline__ uint32_t ctl_fp(uint32_t lo, uint32_t hi) { return 5u + (((((lo * 0xC2B2AE35u) ^ (hi * 0x27D4EB2Fu)) >> 24) * 251u) >> 8); }
-constexpr uint32_t CTL_FREE_BELOW = 5;  // control bytes below this value mark a slot without a live key
+
 // launch_id: 2 * iteration for k_iter_select, 2 * iteration + 1 for k_iter_update (only the low two bits are used)
 __device__ __forceinline__ Ctx make_ctx_raw(ChainDev *g, int launch_id) {
     Ctx c;
@@ -1830,7 +1830,7 @@ __device__ __forceinline__ void update_items(const Ctx &c, ItemFn item, int firs
                                              const DA_GLOBAL Cell *cc, const uint32_t *s_cbase, const Cell *s_mA, const Cell *s_mB, uint32_t *s_cnt, const RowInfo &rnew,
                                              unsigned int &found, unsigned int &inserts) {
     constexpr int QCW = sizeof(Cell) == 4 ? 2 : 4;
-    const int nb = c.n_bits, Kpad = c.Kpad, K = c.K, KW = Kpad / 2;
+    const int nb = c.n_bits, Kpad = c.Kpad, KW = Kpad / 2;
     const int lane = lane_id();
     const int q = lane >> 4, l = lane & (QG - 1), qsh = q * QG;
     const bool same = A == B;
@@ -3055,6 +3055,7 @@ namespace {
 struct Geometry {
     bool wide;  // 64-bit cells and 16-byte list entries (more than 12 digits or more than 256 columns)
     bool fuse;  // stepped by k_steps (several greedy steps per launch, updates inside the kernel): gets the column-major cells
+    int n_mant = 0;  // distinct non-power-of-two step mantissas of the inputs (StepLog2): rows of the -log2f table
     int n_bits, K, Kpad, rcap, lcap, gs_log2, n_groups, pk_cap, pb_log2;
     uint32_t C, rl_cap;
 };
@@ -3095,8 +3096,8 @@ size_t carve_chain(unsigned char *base, const ChainJob &job, const Geometry &g, 
     d.pk_row = c.take<uint32_t>((size_t)g.pk_cap);
     d.pk_cell = c.take<unsigned long long>((size_t)g.pk_cap);
     d.pk_lat = c.take<float>(g.rcap);
-    d.step_mant = c.take<uint32_t>(STEP_MANTS);  // filled only when an input step is not a power of two (StepLog2)
-    d.step_tab = c.take<float>((size_t)STEP_MANTS * 256);
+    d.step_mant = c.take<uint32_t>((size_t)std::max(g.n_mant, 1));  // filled only when an input step is not a power of two (StepLog2)
+    d.step_tab = c.take<float>((size_t)std::max(g.n_mant, 1) * 256);
     return align_up(c.off, 256);
 }
 
@@ -3187,6 +3188,12 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
 
     lap("upload + k_prepare");
     // ---- 2. geometry and arena
+    // -log2f tables of non-power-of-two input steps (rare: the tracer's `variable * 3`), by the host libm, one row per distinct
+    // mantissa -- as many as the inputs have (the reference takes log2 of any step, state_opr.cc:57); they stay alive until the
+    // set-up stream has been synchronised below
+    std::vector<StepLog2Host> step_tabs(n);
+    for (int i = 0; i < n; ++i)
+        if (jobs[i].adder_size >= 0 || jobs[i].carry_size >= 0) step_tabs[i].build(jobs[i].qints, jobs[i].n_in);  // (latency model off: steps are never looked at)
     std::vector<Geometry> geo(n);
     std::vector<size_t> a_off(n);
     size_t arena_bytes = 0;
@@ -3197,6 +3204,7 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
         if (g.n_bits > 30) throw std::runtime_error("kernel needs more than 30 CSD digits per entry (the reference overflows int32 there); unsupported");
         g.wide = g.n_bits > 12 || jobs[i].n_out > 256;  // the narrow list entry is col:8 | minus:12 | plus:12
         g.fuse = !g.wide && im.fuse_steps > 0;          // k_steps (instantiated for the narrow layout)
+        g.n_mant = (int)step_tabs[i].mant.size();
         g.K = key_count(g.n_bits);
         g.Kpad = (g.K + 7) & ~7;  // count words (two u16 each) in whole 16-byte quads
         g.pb_log2 = 5;  // payload line of a pair block: 16-byte header + Kpad u16 counts, padded to a power of two
@@ -3269,12 +3277,7 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
         d.fuse_max_np = std::min(im.fuse_max_np, 2 * SEL_THREADS);  // a filtered hand-off rewrites the heavy list in place: two items per thread
         d.fuse_max_nh = im.fuse_max_nh;
     }
-    // -log2f tables of non-power-of-two input steps (rare: the tracer's `variable * 3`), by the host libm; they stay alive until
-    // the set-up stream has been synchronised below
-    std::vector<StepLog2Host> step_tabs(n);
     for (int i = 0; i < n; ++i) {
-        if (jobs[i].adder_size < 0 && jobs[i].carry_size < 0) continue;  // the latency model is off: steps are never looked at
-        step_tabs[i].build(jobs[i].qints, jobs[i].n_in);
         desc[i].n_step_mant = (int)step_tabs[i].mant.size();
         if (desc[i].n_step_mant) {
             HIP_CHECK(hipMemcpyAsync(const_cast<uint32_t *>(desc[i].step_mant), step_tabs[i].mant.data(), step_tabs[i].mant.size() * 4, hipMemcpyHostToDevice, st));
@@ -3693,6 +3696,8 @@ class HipShardEngine : public ShardEngine {
         if (g.n_bits > 30) throw std::runtime_error("kernel needs more than 30 CSD digits per entry; unsupported");
         g.wide = g.n_bits > 12 || n_loc_ > 256;
         g.fuse = false;  // the column-sharded chain steps with k_iter_select<SHARDED>
+        if (job.adder_size >= 0 || job.carry_size >= 0) step_tab_.build(job.qints, job.n_in);  // -log2f of non-power-of-two input steps (StepLog2), as in run_chains
+        g.n_mant = (int)step_tab_.mant.size();
         g.K = key_count(g.n_bits);
         g.Kpad = (g.K + 7) & ~7;
         g.pb_log2 = 5;
@@ -3751,8 +3756,7 @@ class HipShardEngine : public ShardEngine {
         HIP_CHECK(hipMemsetAsync(d_.gdirty, 1, (size_t)g.n_groups, st_));
         d_.cb_words = (g.rcap + 31) / 32;
         HIP_CHECK(hipMemsetAsync(d_.colbits, 0, sizeof(uint32_t) * (size_t)n_loc_ * d_.cb_words, st_));
-        if (job.adder_size >= 0 || job.carry_size >= 0) {  // -log2f of non-power-of-two input steps (StepLog2), as in run_chains
-            step_tab_.build(job.qints, job.n_in);
+        {
             d_.n_step_mant = (int)step_tab_.mant.size();
             if (d_.n_step_mant) {
                 HIP_CHECK(hipMemcpyAsync(const_cast<uint32_t *>(d_.step_mant), step_tab_.mant.data(), step_tab_.mant.size() * 4, hipMemcpyHostToDevice, st_));

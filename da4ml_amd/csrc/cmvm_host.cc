@@ -86,7 +86,7 @@ void StepLog2Host::build(const QInt *q, int n_in) {
         if (q[i].lo == 0.0f && q[i].hi == 0.0f) continue;
         const uint32_t b = f2u(q[i].step), m = b & 0x7FFFFFu, e = (b >> 23) & 0xFFu;
         if ((b >> 31) || m == 0 || e == 0 || e == 255) continue;
-        if (std::find(mant.begin(), mant.end(), m) != mant.end() || (int)mant.size() >= STEP_MANTS) continue;
+        if (std::find(mant.begin(), mant.end(), m) != mant.end()) continue;
         mant.push_back(m);
     }
     tab.assign(mant.size() * 256, 0.0f);
@@ -381,6 +381,7 @@ void recycle_op_list(std::vector<OpRec> &&ops) {
 // Part 1 (one thread per chain): input and greedy-pick op records, sizes and ids of the per-column adder trees.
 // Part 2 (any thread, any order, disjoint column ranges): the trees, written straight into their final places.
 StageResult finalize_prepare(const ChainJob &job, const ChainOut &out, std::vector<int64_t> &first_op) {
+    if (out.error == E_REMOTE_ERROR) throw std::runtime_error("column-sharded CMVM chain failed on another rank (not a capacity error), or the ranks fell out of step");
     if (out.error != E_OK) throw std::runtime_error("CMVM chain failed on the device (error " + std::to_string(out.error) + ")");
     StageResult r;
     r.n_in = job.n_in;

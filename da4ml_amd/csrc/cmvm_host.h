@@ -101,8 +101,7 @@ void cost_add(const QInt &a, const QInt &b, int64_t shift, bool sub, int adder_s
 Log2Table measure_log2_table();
 // -log2f of the non-power-of-two input steps of a chain, by the local libm (StepLog2 in cmvm_core.h): distinct mantissas of
 // the inputs' steps (constant-zero inputs skipped: their step is never used) and, per mantissa, 256 values indexed by the
-// biased exponent.  More than STEP_MANTS distinct mantissas: the surplus is left out and the chain reports E_FLOAT_DOMAIN if
-// such a step reaches the latency model.
+// biased exponent -- one row per distinct mantissa, however many the inputs have.
 struct StepLog2Host {
     std::vector<uint32_t> mant;
     std::vector<float> tab;

@@ -93,12 +93,22 @@ class Transport : public RcclTransport {
     Transport(Comm comm, hipStream_t stream) : comm_(comm), stream_(stream) {}
     ~Transport() override {
         // the communicator lives as long as the process uses its id (cache below); destroying communicators during interpreter
-        // shutdown can hang in the network teardown, so it is left to process exit
+        // shutdown can hang in the network teardown, so it is left to process exit -- or to an explicit rccl_shutdown() while the
+        // process group is still alive
         if (stage_) (void)hipFree(stage_);
+    }
+    // explicit release (rccl_shutdown): the communicator is destroyed, the transport refuses further use
+    void destroy() {
+        if (comm_) (void)api().comm_destroy(comm_);
+        comm_ = nullptr;
+        if (stage_) (void)hipFree(stage_);
+        stage_ = nullptr;
+        stage_bytes_ = 0;
     }
     bool allreduce(void *buf, int64_t count, bool on_device) override {
         const Api &a = api();
         if (count <= 0) return true;
+        if (!comm_) return fail("the RCCL communicator was shut down (rccl_shutdown)");
         if (on_device) {
             const int rc = a.all_reduce(buf, buf, (size_t)count, NCCL_INT32, NCCL_SUM, comm_, stream_);
             ++dev_calls_;
@@ -148,12 +158,33 @@ void rccl_unique_id(void *out128) {
     std::memcpy(out128, id.internal, ID_BYTES);
 }
 
-std::shared_ptr<RcclTransport> RcclTransport::open(const void *id128, int rank, int world, int device, void *stream) {
-    // one communicator per (unique id, rank, device): creating one costs tens of milliseconds and a rendezvous of all ranks
-    // (leaked on purpose: at process exit the HIP runtime and RCCL are torn down in an order this library does not control, and a
-    // communicator or staging buffer released then is released twice)
+namespace {
+// one communicator per (unique id, rank, device): creating one costs tens of milliseconds and a rendezvous of all ranks.  Callers
+// re-use ONE id per process group (da4ml_amd.multi_gpu caches the broadcast id), so the cache holds one entry per group; without an
+// explicit rccl_shutdown() the entries are leaked on purpose: at process exit the HIP runtime and RCCL are torn down in an order this
+// library does not control, and a communicator or staging buffer released then is released twice.
+std::mutex &cache_mutex() {
     static std::mutex &mu = *new std::mutex();
+    return mu;
+}
+std::map<std::string, std::shared_ptr<RcclTransport>> &comm_cache() {
     static std::map<std::string, std::shared_ptr<RcclTransport>> &cache = *new std::map<std::string, std::shared_ptr<RcclTransport>>();
+    return cache;
+}
+}  // namespace
+
+int rccl_shutdown() {
+    std::lock_guard<std::mutex> lk(cache_mutex());
+    auto &cache = comm_cache();
+    const int n = (int)cache.size();
+    for (auto &kv : cache) static_cast<Transport *>(kv.second.get())->destroy();
+    cache.clear();
+    return n;
+}
+
+std::shared_ptr<RcclTransport> RcclTransport::open(const void *id128, int rank, int world, int device, void *stream) {
+    std::mutex &mu = cache_mutex();
+    auto &cache = comm_cache();
     std::string key(static_cast<const char *>(id128), ID_BYTES);
     key += ":" + std::to_string(rank) + ":" + std::to_string(world) + ":" + std::to_string(device) + ":" + std::to_string(reinterpret_cast<uintptr_t>(stream));
     std::lock_guard<std::mutex> lk(mu);

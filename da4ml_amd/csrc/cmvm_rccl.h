@@ -31,6 +31,9 @@ class RcclTransport {
 
 // 128 bytes for rank 0 to hand to every rank (ncclGetUniqueId)
 void rccl_unique_id(void *out128);
+// destroys every cached communicator (ncclCommDestroy) and frees its staging buffer; returns how many there were.  Collective in
+// effect: every rank calls it, while the process group is still alive and no solve is running.
+int rccl_shutdown();
 
 }  // namespace gpu
 }  // namespace da

@@ -67,7 +67,10 @@ void ShardedBackend::run_one(const ChainJob &job, ChainOut &out) {
     eng->finish(own);
     out = ChainOut{};
     if (failed) {  // known to every rank from the same summed words: nobody enters the merge exchanges
-        out.error = own.error ? own.error : (status[1] ? E_TABLE_CAPACITY : E_LIST_CAPACITY);
+        // this rank's own error if it has one; else what the summed status says about the others: a rank with a non-capacity error, or ranks
+        // out of step (fewer than `world` stopped together) -> E_REMOTE_ERROR, which no caller retries; only a pure capacity failure (the
+        // retries above are used up) is reported as one
+        out.error = own.error ? own.error : (status[2] != 0 || status[0] != comm_.world) ? E_REMOTE_ERROR : E_TABLE_CAPACITY;
         out.n_bits = own.n_bits;
         return;
     }

@@ -17,6 +17,11 @@ def env_rank() -> tuple[int, int, int]:
     return int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1)), int(os.environ.get('LOCAL_RANK', 0))
 
 
+_rccl_ids: dict = {}  # (world, rank, device) -> the RCCL unique id of the process group (solve_column_sharded(transport='rccl'))
+_unpinned_cores: list[int] | None = None  # affinity mask of the process before pin_rank_to_core_slice first narrowed it
+_pinned_as: tuple | None = None          # (local rank, local world, cores) of the pinning in force
+
+
 def pin_rank_to_core_slice(local: int, local_world: int) -> list[int] | None:
     """One process per GPU on one host: give local rank ``local`` of ``local_world`` its contiguous slice of the cores this
     process may run on.  The library's host pool (adder trees, staging; ``csrc/cmvm_host.cc``) sizes itself from the affinity
@@ -25,10 +30,19 @@ def pin_rank_to_core_slice(local: int, local_world: int) -> list[int] | None:
     Affects the calling thread and every thread it starts afterwards; ``DA4ML_PIN_RANKS=0`` turns it off."""
     if local_world <= 1 or os.environ.get('DA4ML_PIN_RANKS', '1') == '0' or not hasattr(os, 'sched_setaffinity'):
         return None
-    cores = sorted(os.sched_getaffinity(0))
+    # Idempotent: init() runs from every sharded solve.  The slice is always cut from the mask the process had BEFORE its first
+    # pinning (slicing the already narrowed mask again would leave 1 / local_world of it per call: 32, 4, 1 cores ...), and a
+    # repeated call with the same arguments is a no-op.
+    global _unpinned_cores, _pinned_as
+    if _unpinned_cores is None:
+        _unpinned_cores = sorted(os.sched_getaffinity(0))
+    if _pinned_as is not None and _pinned_as[:2] == (local, local_world):
+        return _pinned_as[2]
+    cores = _unpinned_cores
     lo, hi = len(cores) * local // local_world, len(cores) * (local + 1) // local_world
     mine = cores[lo:hi] or cores[local % len(cores) : local % len(cores) + 1]
     os.sched_setaffinity(0, mine)
+    _pinned_as = (local, local_world, mine)
     return mine
 
 
@@ -57,6 +71,11 @@ def shutdown():
     exception'), which a launcher reports as a failed job."""
     import torch.distributed as dist
 
+    if _rccl_ids:  # communicators of the library's own RCCL transport: destroyed while the group is alive (every rank gets here)
+        from . import _binary
+
+        _rccl_ids.clear()
+        _binary.rccl_shutdown()
     if dist.is_available() and dist.is_initialized():
         try:
             dist.barrier()
@@ -356,13 +375,20 @@ def solve_column_sharded(kernel, method0: str = 'wmc', method1: str = 'auto', ha
 
         if _binary.device_count() > 0:
             _binary.set_device(local % _binary.device_count())
-        raw = _binary.rccl_unique_id() if rank == 0 else bytes(128)
-        if world > 1:
-            on_gpu = dist.get_backend() == 'nccl'
-            t = torch.from_numpy(np.frombuffer(raw, np.uint8).copy())
-            t = t.to(device) if on_gpu else t
-            dist.broadcast(t, src=0)
-            raw = t.cpu().numpy().tobytes()
+        # ONE unique id per process group, broadcast once and re-used by every later solve: the library keeps the communicator
+        # of an id (ncclCommInitRank costs tens of milliseconds and a rendezvous of all ranks), so a fresh id per call would
+        # build and keep a new communicator each time.  Every rank takes the same branch: they all call in the same order.
+        key = (world, dist.get_rank() if world > 1 else 0, str(device))
+        raw = _rccl_ids.get(key)
+        if raw is None:
+            raw = _binary.rccl_unique_id() if rank == 0 else bytes(128)
+            if world > 1:
+                on_gpu = dist.get_backend() == 'nccl'
+                t = torch.from_numpy(np.frombuffer(raw, np.uint8).copy())
+                t = t.to(device) if on_gpu else t
+                dist.broadcast(t, src=0)
+                raw = t.cpu().numpy().tobytes()
+            _rccl_ids[key] = raw
         pipe, stats = _binary.solve_sharded_rccl(kernel, raw, method0=method0, method1=method1, hard_dc=hard_dc, decompose_dc=decompose_dc, qintervals=qintervals,
                                                  latencies=latencies, adder_size=adder_size, carry_size=carry_size, search_all_decompose_dc=search_all_decompose_dc,
                                                  rank=rank, world=world)  # fmt: skip

@@ -59,7 +59,9 @@ int da_kernel_decompose(const float *kernel, int64_t n_in, int64_t n_out, int dc
 
 /* ---- solve ------------------------------------------------------------------------------------------------ */
 /* cmvm_bin.solve (bindings.cc:184-225,235-248 -> api.cc:147-250).  `qintervals` is float32 [n_in,3] or NULL
- * (default (-128,127,1)), `latencies` float32 [n_in] or NULL (default 0).  Steps must be powers of two. */
+ * (default (-128,127,1)), `latencies` float32 [n_in] or NULL (default 0).  Steps must be positive normal numbers (DA_ERR_VALUE
+ * otherwise); they need not be powers of two (the latency model reads -log2f of any other step from a table the host builds with
+ * its own libm, one row per distinct mantissa). */
 da_result *da_solve(const float *kernel, int64_t n_in, int64_t n_out, const char *method0, const char *method1, int hard_dc,
                     int decompose_dc, const float *qintervals, const float *latencies, int adder_size, int carry_size,
                     int search_all_decompose_dc);
@@ -92,9 +94,12 @@ da_result *da_solve_sharded(const float *kernel, int64_t n_in, int64_t n_out, co
  * stream-ordered with the kernels that produce and consume the exchange buffers -- no callback, no host synchronisation per
  * exchange.  librccl.so is opened at run time (no link-time dependency).  Rank 0 obtains the 128-byte unique id
  * (da_rccl_unique_id = ncclGetUniqueId) and hands it to every rank by its own means (da4ml_amd.multi_gpu broadcasts it through
- * torch.distributed); every rank then calls da_solve_sharded_rccl with identical arguments; the communicator of an id is kept
- * for further calls. */
+ * torch.distributed); every rank then calls da_solve_sharded_rccl with identical arguments.  The communicator of an id is kept
+ * for further calls -- callers hand the SAME id to every solve of a process group (a fresh id per call would build, and keep, a
+ * new communicator each time); da_rccl_shutdown destroys the kept communicators (ncclCommDestroy; every rank calls it, no solve
+ * running, the process group still alive) and returns their number, -1 on error. */
 int da_rccl_unique_id(void *id128);
+int da_rccl_shutdown(void);
 da_result *da_solve_sharded_rccl(const float *kernel, int64_t n_in, int64_t n_out, const char *method0, const char *method1, int hard_dc,
                                  int decompose_dc, const float *qintervals, const float *latencies, int adder_size, int carry_size,
                                  int search_all_decompose_dc, int rank, int world, const void *id128, int64_t *stats3);

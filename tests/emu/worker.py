@@ -44,6 +44,12 @@ def odd_steps(lo, hi):
         k, opts = odd_step_case(seed)
         if hip.solve(k, **opts) != o.solve(k, **opts):
             bad.append(seed)
+    # 40 different non-power-of-two step mantissas in one matrix: one table row each (the reference takes -log2 of any step)
+    k = np.random.default_rng(5).integers(-16, 16, (40, 6)).astype(np.float32)
+    q = [(-8.0 * (1.0 + 0.017 * (i + 1)), 8.0 * (1.0 + 0.017 * (i + 1)), 1.0 + 0.017 * (i + 1)) for i in range(40)]
+    for j, opts in enumerate((dict(adder_size=1, carry_size=-1), dict(adder_size=4, carry_size=8), {})):
+        if hip.solve(k, qintervals=q, **opts) != o.solve(k, qintervals=q, **opts):
+            bad.append(1000 + j)
     out(bad=bad, n=hi - lo)
 
 
@@ -112,7 +118,24 @@ def fork_after_use():
     if pid == 0:
         os._exit(0 if hip.solve_many(ks, **SINGLE) == a else 3)
     _, st = os.waitpid(pid, 0)
-    out(child=os.WEXITSTATUS(st), parent=hip.solve_many(ks, **SINGLE) == a)
+    # fork() while ANOTHER thread is inside a solve returns at once (the library takes no lock around the fork: a prepare handler that
+    # waited for the solve-long library lock would stall here for the whole solve -- holding the GIL)
+    import threading
+    import time
+
+    big = [int_matrix(s, 28, 28, -128, 128) for s in range(3)]
+    busy = threading.Thread(target=lambda: hip.solve_many(big, **SINGLE))
+    busy.start()
+    time.sleep(0.3)
+    in_solve = busy.is_alive()
+    t0 = time.time()
+    pid2 = os.fork()
+    if pid2 == 0:
+        os._exit(0)
+    fork_seconds = time.time() - t0
+    os.waitpid(pid2, 0)
+    busy.join()
+    out(child=os.WEXITSTATUS(st), parent=hip.solve_many(ks, **SINGLE) == a, fork_during_solve_ok=bool(in_solve and fork_seconds < 0.25))
 
 
 def retry():

@@ -87,7 +87,7 @@ def test_wide_host_pool(emu):
 
 
 def test_fork_after_use(emu):
-    assert emu('fork', timeout=120) == {'child': 0, 'parent': True}
+    assert emu('fork', timeout=300) == {'child': 0, 'parent': True, 'fork_during_solve_ok': True}
 
 
 def test_capacity_retry(emu):

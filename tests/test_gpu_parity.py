@@ -134,8 +134,16 @@ def test_errors(hip):
     for bad_step in (0.0, -0.5, float('nan'), float('inf'), 1e-40):  # no logarithm the latency model could use
         with pytest.raises(ValueError):
             hip.solve(np.eye(3, dtype=np.float32), qintervals=[(-1.0, 1.0, bad_step)] * 3)
-    with pytest.raises(ValueError, match='distinct'):  # more than STEP_MANTS = 8 different non-power-of-two mantissas
-        hip.solve(np.ones((9, 2), dtype=np.float32), qintervals=[(-8.0, 8.0, 1.0 + 0.1 * (i + 1)) for i in range(9)])
+
+
+def test_many_distinct_step_mantissas(hip, oracle):
+    """the reference takes -log2 of ANY step (state_opr.cc:57): a matrix whose inputs have 40 different non-power-of-two step
+    mantissas (one table row each, StepLog2) -- latency model on and off"""
+    rng = np.random.default_rng(5)
+    k = rng.integers(-16, 16, (40, 6)).astype(np.float32)
+    q = [(-8.0 * (1.0 + 0.017 * (i + 1)), 8.0 * (1.0 + 0.017 * (i + 1)), 1.0 + 0.017 * (i + 1)) for i in range(40)]
+    for opts in (dict(adder_size=1, carry_size=-1), dict(adder_size=4, carry_size=8), {}):
+        assert hip.solve(k, qintervals=q, **opts) == oracle.solve(k, qintervals=q, **opts), opts
 
 
 def test_capacity_retry(oracle):

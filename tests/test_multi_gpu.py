@@ -284,11 +284,33 @@ def test_ranks_get_disjoint_core_slices(monkeypatch):
     if len(allowed) < 2:
         pytest.skip('one core')
     seen = []
+    monkeypatch.setattr(mg, '_unpinned_cores', None)  # (module state of the idempotence: restored when the test ends)
+    monkeypatch.setattr(mg, '_pinned_as', None)
     monkeypatch.setattr(os, 'sched_setaffinity', lambda pid, cores: seen.append(list(cores)))
     n = min(8, len(allowed))
     for r in range(n):
         mg.pin_rank_to_core_slice(r, n)
     assert sorted(c for s in seen for c in s) == allowed and all(len(s) >= 1 for s in seen)
+    seen.clear()
+    # idempotent (init() runs from every sharded solve): with a REAL narrowing of the mask in between, repeated calls return the same
+    # slice of the ORIGINAL mask -- the slice is not sliced again
+    monkeypatch.setattr(mg, '_unpinned_cores', None)
+    monkeypatch.setattr(mg, '_pinned_as', None)
+    current = list(allowed)
+    monkeypatch.setattr(os, 'sched_getaffinity', lambda pid: set(current))
+
+    def narrow(pid, cores):
+        current[:] = list(cores)
+        seen.append(list(cores))
+
+    monkeypatch.setattr(os, 'sched_setaffinity', narrow)
+    first = mg.pin_rank_to_core_slice(1, 2)
+    assert first == allowed[len(allowed) // 2 :] and current == first
+    assert mg.pin_rank_to_core_slice(1, 2) == first and mg.pin_rank_to_core_slice(1, 2) == first and len(seen) == 1
+    assert mg.pin_rank_to_core_slice(0, 2) == allowed[: len(allowed) // 2]  # (other arguments: cut from the original mask again)
+    monkeypatch.setattr(os, 'sched_setaffinity', lambda pid, cores: seen.append(list(cores)))
+    monkeypatch.setattr(mg, '_unpinned_cores', None)
+    monkeypatch.setattr(mg, '_pinned_as', None)
     seen.clear()
     assert mg.pin_rank_to_core_slice(0, 1) is None and not seen  # a single rank keeps every core
     monkeypatch.setenv('DA4ML_PIN_RANKS', '0')

@@ -102,9 +102,22 @@ for k, kw in cases:
     same.append(bool(p == O.solve(k, **kw)))
     calls += st["allreduce_calls"]
 k, kw = cases[1]
+n_ids, fresh_id = [0], hip.rccl_unique_id
+def counted_id():
+    n_ids[0] += 1
+    return fresh_id()
+hip.rccl_unique_id = counted_id
 p = mg.solve_column_sharded(k, transport="rccl", **kw)   # the user-facing entry (one rank: no process group needed)
 same.append(bool(p == O.solve(k, **kw)))
-print(json.dumps({"same": same, "calls": calls}), flush=True)
+p = mg.solve_column_sharded(k, transport="rccl", **kw)   # again: the group's unique id -- and with it the communicator -- is re-used
+same.append(bool(p == O.solve(k, **kw)))
+ids_before = n_ids[0]
+mg._rccl_ids.clear()
+closed = hip.rccl_shutdown()                             # the communicator of `uid` and the one of the group
+p = mg.solve_column_sharded(k, transport="rccl", **kw)   # a new id, a new communicator
+same.append(bool(p == O.solve(k, **kw)))
+mg.shutdown()                                            # destroys it (no process group to tear down here)
+print(json.dumps({"same": same, "calls": calls, "ids_before_shutdown": ids_before, "ids": n_ids[0], "closed": closed, "left": hip.rccl_shutdown()}), flush=True)
 '''
 
 
@@ -117,7 +130,9 @@ def test_rccl_transport_one_rank():
     out = subprocess.run([sys.executable, '-c', RCCL_ONE], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
     r = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1])  # (RCCL prints a version banner on stdout)
-    assert r['same'] == [True] * 7 and r['calls'] > 100
+    assert r['same'] == [True] * 9 and r['calls'] > 100
+    # one unique id (and one communicator) per process group however many solves; da_rccl_shutdown destroys what the library kept
+    assert r['ids_before_shutdown'] == 1 and r['ids'] == 2 and r['closed'] == 2 and r['left'] == 0
 
 
 def test_torch_nccl_paths_one_rank():
