@@ -230,9 +230,11 @@ def cpu_baseline(n_in, n_out, opts, budget_s, batch, gpu_time_batch=None):
     cores = cpu_pool.host_cores()
     # one 256x256 chain of the reference holds its 64.7 M initial pairs (24 bytes each) plus the sort buffer: ~4 GB per process
     need_gb = 4.0 * (n_in * n_out / 65536.0) ** 2 + 0.5
-    # one process per chain of the batch, never more than half of the available memory allows at 1.5 x the estimate (a first attempt
-    # with "every core the memory allows" -- 200+ processes on the 256-core box -- took the box down)
-    workers = max(1, min(cores, batch, int(0.5 * cpu_pool.mem_available_gb() / (1.5 * need_gb))))
+    # one process per core, never more than half of the available memory allows at 1.5 x the estimate (a first attempt with 200+
+    # processes on the 256-core box took the box down: each started its numerical libraries' thread pools, 256 x 256 threads; the
+    # workers pin those to one thread since)
+    # (round 4: no longer capped at the batch size -- every host core the memory allows works on a chain of the batch, seeds repeating)
+    workers = max(1, min(cores, int(0.5 * cpu_pool.mem_available_gb() / (1.5 * need_gb))))
     method = opts.get('method0', 'wmc')
     # (1) a time-bounded prefix of a chain of the batch on every core, all cores busy at once
     samples, wall = cpu_pool.run_pool(cpu_pool.sample_worker, [(okind, n_in, n_out, i % batch, method, budget_s) for i in range(workers)], workers)
@@ -254,6 +256,19 @@ def cpu_baseline(n_in, n_out, opts, budget_s, batch, gpu_time_batch=None):
                      f'first {int(np.mean([smp["iterations"] for smp in samples]))} greedy iterations in {budget_s:.0f} s (wall {wall:.1f} s)'
                      + ('' if finished else f'; scaled to full chains with the time curve of a complete run of the same code ({cal["source"] if cal else "no calibration"})'),
            'est_seconds_per_solve_one_core': float(np.mean(est)) if est else None}  # fmt: skip
+    # (1b) complete runs of the same code at this very size, not extrapolated: the records of the benchmark matrices were made by
+    # oracle/_ref/libref.so in the build container (tests/golden/large_chain_golden.json keeps their wall times: one chain per core,
+    # eight at a time on 8 cores).  A per-core figure, and what `cores` perfectly scaling cores would reach at that rate.
+    try:
+        recs = json.loads((ROOT / 'tests' / 'golden' / 'large_chain_golden.json').read_text())
+        secs = [r['oracle_seconds'] for k, r in recs.items() if k.startswith(f'{n_in}x{n_out}_seed') and k.endswith('_single_chain_ref') and 'oracle_seconds' in r]
+        if secs:
+            out['measured_full_runs_build_container'] = {
+                'runs': len(secs), 'seconds_per_solve_one_core': {'mean': float(np.mean(secs)), 'min': float(np.min(secs)), 'max': float(np.max(secs))},
+                'solves_per_s_per_core': float(1.0 / np.mean(secs)), 'solves_per_s_if_all_host_cores_scaled_perfectly': float(cores / np.mean(secs)),
+                'sample': f'{len(secs)} complete {n_in}x{n_out} single-chain runs of the reference build (seeds of the benchmark batch), one core each, measured in the build container -- not on this box, not extrapolated'}  # fmt: skip
+    except (OSError, ValueError, KeyError):
+        pass
     # (2) fully measured, no scaling, GPU and CPU on the SAME matrices in the same run: complete 64x64 and 128x128 chains
     for n, key in ((64, 'measured_64x64'), (128, 'measured_128x128')):
         count = batch if n == 64 or cores >= batch else max(1, min(batch, cores))  # 128x128: ~60-90 s per chain and core -- one wave of the pool

@@ -775,6 +775,7 @@ template <class Cell, bool SHARDED = false> __device__ __forceinline__ int selec
     const float *step_tab = g->step_tab;
     int n_step_mant = g->n_step_mant;
     Ctx c = make_ctx_raw(g, 2 * iter);
+    c.hctl = nullptr;  // chains with control bytes are stepped by k_steps, never by this kernel: a constant for the compiler
     DA_GLOBAL int *collen = (DA_GLOBAL int *)g->collen;
     DA_GLOBAL unsigned long long *gtie_arr = (DA_GLOBAL unsigned long long *)g->gtie;
     DA_GLOBAL da_u2 *rowoff = (DA_GLOBAL da_u2 *)g->rowoff;
@@ -930,9 +931,10 @@ template <class Cell, bool SHARDED = false> __device__ __forceinline__ int selec
                 }
         }
         while (true) {
-            // the wave's TWO highest dirty groups are re-read together (their loads in flight at the same time): the second
-            // one would usually be next anyway, and an unnecessary re-read only leaves a group clean
-            const unsigned long long fl = __hip_atomic_load(&s_floor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // ds_read_b64, not a FLAT load
+            // ONE group per wave and round: the wave's highest dirty group is re-read while its (possibly stale) bound still reaches the
+            // rising floor.  (Two groups per round keep two sets of loads in flight, but every wave that re-reads anything then issues the
+            // instruction stream of both -- ~1500 instructions per round, most of them predicated off.)
+            const unsigned long long fl = __hip_atomic_load(&s_floor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             unsigned long long top = 0;
             int top_u = 0;
 #pragma unroll
@@ -943,107 +945,69 @@ template <class Cell, bool SHARDED = false> __device__ __forceinline__ int selec
                 }
             const unsigned long long wtop = wave_max_u64(top);
             if (wtop == 0 || wtop < fl) break;
-            int owner[2], own_u[2];
-            owner[0] = __ffsll((long long)__ballot(top == wtop)) - 1;
-            own_u[0] = __builtin_amdgcn_readlane(top_u, owner[0]);
-            unsigned long long top2 = 0;
-            int top2_u = 0;
+            const int owner = __ffsll((long long)__ballot(top == wtop)) - 1;
+            const int own_u = __builtin_amdgcn_readlane(top_u, owner);
+            const uint32_t grp = (uint32_t)(wid * GPW + owner + own_u * WAVE), base = grp * gs;
+            uint32_t rk[8], grank = 0;
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (dr[u] == 1 && !(lane == owner[0] && u == own_u[0]) && ubr[u] > top2) {
-                    top2 = ubr[u];
-                    top2_u = u;
-                }
-            const unsigned long long wtop2 = wave_max_u64(top2);
-            const int n_re = (wtop2 != 0 && wtop2 >= fl) ? 2 : 1;
-            owner[1] = n_re == 2 ? __ffsll((long long)__ballot(top2 == wtop2)) - 1 : 0;
-            own_u[1] = n_re == 2 ? __builtin_amdgcn_readlane(top2_u, owner[1]) : 0;
-            uint32_t grp[2], base[2], rk[2][8], grank[2] = {0, 0};
-            unsigned long long gt[2] = {0, 0};
-#pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                grp[r] = (uint32_t)(wid * GPW + owner[r] + own_u[r] * WAVE);
-                base[r] = grp[r] * gs;
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int o = lane + u * WAVE;
-                    rk[r][u] = (r < n_re && o < gs) ? c.hrank[base[r] + o] : 0u;
-                }
+            for (int u = 0; u < 8; ++u) {
+                const int o = lane + u * WAVE;
+                rk[u] = o < gs ? c.hrank[base + o] : 0u;
             }
 #pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                if (r < n_re) {
+            for (int u = 0; u < 8; ++u) grank = max(grank, rk[u]);
+            for (int o = lane + 8 * WAVE; o < gs; o += WAVE) grank = max(grank, c.hrank[base + o]);
+            grank = wave_max_u32(grank);
+            unsigned long long kk[8], gt = 0;
+            uint32_t bi[8];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) grank[r] = max(grank[r], rk[r][u]);
-                    for (int o = lane + 8 * WAVE; o < gs; o += WAVE) grank[r] = max(grank[r], c.hrank[base[r] + o]);
+            for (int u = 0; u < 8; ++u) {
+                const int o = lane + u * WAVE;
+                kk[u] = 0;
+                bi[u] = 0;
+                if (grank && o < gs && rk[u] == grank) {
+                    kk[u] = c.hkey[base + o];
+                    bi[u] = load_best_idx(c, base + o);
                 }
-                grank[r] = wave_max_u32(grank[r]);
             }
-            // the slots that hold a group's top rank: key and best-key index of ALL of them (both groups) are fetched before
-            // the first is looked at.  Equal ranks are the rule late in a chain (rank = count x overlap, most counts are 2):
-            // fetched and consumed slot by slot, every tied slot was a round trip of its own -- up to sixteen in a row.
-            unsigned long long kk[2][8];
-            uint32_t bi[2][8];
-#pragma unroll
-            for (int r = 0; r < 2; ++r)
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int o = lane + u * WAVE;
-                    kk[r][u] = 0;
-                    bi[r][u] = 0;
-                    if (grank[r] && o < gs && rk[r][u] == grank[r]) {
-                        kk[r][u] = c.hkey[base[r] + o];
-                        bi[r][u] = load_best_idx(c, base[r] + o);
-                    }
-                }
             load_fence();
 #pragma unroll
-            for (int r = 0; r < 2; ++r)
+            for (int u = 0; u < 8; ++u) pin_vgpr(kk[u], bi[u]);
+            if (grank) {
 #pragma unroll
-                for (int u = 0; u < 8; ++u) pin_vgpr(kk[r][u], bi[r][u]);  // nothing derived from a loaded value is computed (and waited for) above this line
-#pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                if (grank[r]) {
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const int o = lane + u * WAVE;
-                        if (o < gs && rk[r][u] == grank[r]) {
-                            const unsigned long long tw = tie_word((uint32_t)kk[r][u], (uint32_t)(kk[r][u] >> 32), (int)bi[r][u]);
-                            gt[r] = tw > gt[r] ? tw : gt[r];
-                        }
+                for (int u = 0; u < 8; ++u) {
+                    const int o = lane + u * WAVE;
+                    if (o < gs && rk[u] == grank) {
+                        const unsigned long long tw = tie_word((uint32_t)kk[u], (uint32_t)(kk[u] >> 32), (int)bi[u]);
+                        gt = tw > gt ? tw : gt;
                     }
-                    for (int o = lane + 8 * WAVE; o < gs; o += WAVE)
-                        if (c.hrank[base[r] + o] == grank[r]) {
-                            const unsigned long long kk = c.hkey[base[r] + o];
-                            const unsigned long long tw = tie_word((uint32_t)kk, (uint32_t)(kk >> 32), (int)load_best_idx(c, base[r] + o));
-                            gt[r] = tw > gt[r] ? tw : gt[r];
-                        }
                 }
-            }
-#pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                gt[r] = wave_max_u64(gt[r]);
-                if (r < n_re) {
-                    const unsigned long long exact = grank[r] ? bound_word(grank[r], gt[r]) : 0ull;
-                    if (lane == owner[r]) {  // no writer races with this kernel: bound and tie are exact, the group is clean again
-#pragma unroll
-                        for (int u = 0; u < 4; ++u)
-                            if (u == own_u[r]) {
-                                ubr[u] = exact;
-                                dr[u] = 2;
-                            }
-                        c.ub[grp[r]] = exact;
-                        gtie_arr[grp[r]] = gt[r];
-                        c.gdirty[grp[r]] = 0;
-                        if (exact) atomicMax(&s_floor, exact);
+                for (int o = lane + 8 * WAVE; o < gs; o += WAVE)
+                    if (c.hrank[base + o] == grank) {
+                        const unsigned long long k2 = c.hkey[base + o];
+                        const unsigned long long tw = tie_word((uint32_t)k2, (uint32_t)(k2 >> 32), (int)load_best_idx(c, base + o));
+                        gt = tw > gt ? tw : gt;
                     }
-                    if (grank[r] > wrank || (grank[r] == wrank && gt[r] > wtie)) {
-                        wrank = grank[r];
-                        wtie = gt[r];
-                    }
-                    ++rescans;
-                }
             }
+            gt = wave_max_u64(gt);
+            const unsigned long long exact = grank ? bound_word(grank, gt) : 0ull;
+            if (lane == owner) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (u == own_u) {
+                        ubr[u] = exact;
+                        dr[u] = 2;
+                    }
+                c.ub[grp] = exact;
+                gtie_arr[grp] = gt;
+                c.gdirty[grp] = 0;
+                if (exact) atomicMax(&s_floor, exact);
+            }
+            if (grank > wrank || (grank == wrank && gt > wtie)) {
+                wrank = grank;
+                wtie = gt;
+            }
+            ++rescans;
             lds_fence();
         }
         if (floor0) {

@@ -111,13 +111,18 @@ def test_replay_used_by_the_bench_verification(oracle):
             assert not np.array_equal(bench.replay_stage(*a) @ m1, k.astype(np.float64))
 
 
-def test_bench_launches_its_own_ranks():
-    """`python bench.py --gpus 2` started directly (no torchrun environment) spawns the two ranks itself; here with the
-    launcher self-test (gloo on this CPU host, nccl on a GPU host): rank 0 reports n_gpus 2 and the reduced values"""
-    r = subprocess.run([sys.executable, str(ROOT / 'bench.py'), '--gpus', '2', '--selftest-launcher'], capture_output=True, text=True, timeout=300)
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize('world', [2, 8])
+def test_bench_launches_its_own_ranks(world):
+    """`python bench.py --gpus N` started directly (no torchrun environment) spawns the N ranks itself; here with the
+    launcher self-test (gloo on this CPU host, nccl on a GPU host): rank 0 reports n_gpus N, the max over ranks of the
+    per-rank times and the sum of the per-rank solves -- at 2 ranks and at the 8 of a full node (SCALE / BASELINE configs[3])"""
+    r = subprocess.run([sys.executable, str(ROOT / 'bench.py'), '--gpus', str(world), '--selftest-launcher'], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
-    assert line['n_gpus'] == 2 and line['max_elapsed'] == 2.0 and line['total_solves'] == 128.0
+    assert line['n_gpus'] == world and line['max_elapsed'] == float(world) and line['total_solves'] == 64.0 * world
 
 
 def test_bench_refuses_more_ranks_than_gpus():

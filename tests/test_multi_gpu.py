@@ -231,6 +231,63 @@ def test_column_sharded_chain_gloo_world2_and_3():
             assert r['steps'] > 100 and r['steps'] == res[0]['steps']  # the ranks walked the same greedy steps
 
 
+COLSHARD8_WORKER = r'''
+import os, sys, json, hashlib
+sys.path.insert(0, os.environ["DA_ROOT"]); sys.path.insert(0, os.path.join(os.environ["DA_ROOT"], "tests"))
+import torch.distributed as dist
+from da4ml_amd import multi_gpu as mg
+from oracle.oracle import Oracle   # the sequential engine model stands in for the HIP engine: this host has no GPU
+from cases import int_matrix
+rank, world, local, device = mg.init("gloo")
+M = Oracle("model")
+sizes = []                          # int32 elements of every exchange, in call order
+plain_all_reduce = dist.all_reduce
+def counting_all_reduce(t, *a, **kw):
+    sizes.append(int(t.numel()))
+    return plain_all_reduce(t, *a, **kw)
+dist.all_reduce = counting_all_reduce
+single = dict(method0="wmc", method1="wmc", decompose_dc=-1, search_all_decompose_dc=False)
+res = {}
+for name, k in (("c4_split_64x256", int_matrix(0, 64, 256, -128, 128)), ("uneven_20x45", int_matrix(1, 20, 45, -128, 128)), ("fewer_columns_than_ranks_12x5", int_matrix(2, 12, 5, -64, 64))):
+    sizes.clear()
+    p, st = mg.solve_column_sharded(k, sharded_solver=M.solve_sharded, return_stats=True, **single)
+    dump = json.loads(json.dumps(p, default=lambda x: x.to_dict()))
+    steps = st["greedy_steps"]
+    # the exchanges of the greedy loop alternate: flags (+ status trailer), then the slab of partial count changes
+    loop = sizes[1:1 + 2 * steps] if st["sharded_chains"] else []
+    res[name] = {"sha": hashlib.sha256(json.dumps(dump, separators=(",", ":")).encode()).hexdigest(), "steps": steps, "chains": st["sharded_chains"], "calls": st["allreduce_calls"],
+                 "flag_bytes_per_step": 4.0 * sum(loop[0::2]) / max(steps, 1), "slab_bytes_per_step": 4.0 * sum(loop[1::2]) / max(steps, 1), "reproduces": bool((p.kernel == k).all())}
+print(json.dumps({"rank": rank, "res": res}), flush=True)
+mg.shutdown()
+'''
+
+
+def test_column_sharded_chain_gloo_world8():
+    """BASELINE config C4 at its OWN world size: 8 ranks, the 256 output columns of a 64 x 256 int8 matrix split 32 per rank (the
+    config's split), an uneven split (45 columns over 8 ranks) and a matrix with fewer columns than ranks.  Every rank returns the
+    same result -- digest equal on all eight and equal to the single-process oracle -- after the same greedy steps; the sizes of
+    the two per-step exchanges are recorded (DESIGN.md section 7 projects the 8-GPU step time from them)."""
+    import hashlib
+    import json
+
+    from cases import int_matrix
+    from oracle.oracle import Oracle
+
+    res = _run_world(COLSHARD8_WORKER, 8, timeout=1500)
+    assert [r['rank'] for r in res] == list(range(8))
+    single = dict(method0='wmc', method1='wmc', decompose_dc=-1, search_all_decompose_dc=False)
+    o = Oracle('port')
+    for name, k in (('c4_split_64x256', int_matrix(0, 64, 256, -128, 128)), ('uneven_20x45', int_matrix(1, 20, 45, -128, 128)), ('fewer_columns_than_ranks_12x5', int_matrix(2, 12, 5, -64, 64))):
+        want = json.loads(json.dumps(o.solve(k, **single), default=lambda x: x.to_dict()))
+        sha = hashlib.sha256(json.dumps(want, separators=(',', ':')).encode()).hexdigest()
+        for r in res:
+            assert r['res'][name]['sha'] == sha and r['res'][name]['reproduces'], (name, r['rank'])
+            assert r['res'][name]['steps'] == res[0]['res'][name]['steps'] and r['res'][name]['calls'] == res[0]['res'][name]['calls']
+    c4 = res[0]['res']['c4_split_64x256']
+    assert c4['chains'] >= 1 and c4['steps'] > 1000 and c4['slab_bytes_per_step'] > c4['flag_bytes_per_step'] > 0
+    print('C4 split at world 8:', json.dumps(c4))
+
+
 def test_init_needs_a_port_from_the_launcher(monkeypatch):
     """Ranks started without a rendezvous port must fail loudly instead of guessing one."""
     from da4ml_amd import multi_gpu
