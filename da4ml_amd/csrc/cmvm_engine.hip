@@ -3716,6 +3716,7 @@ class HipShardEngine : public ShardEngine {
         HIP_CHECK(hipMemsetAsync(d_.stamp, 0, sizeof(uint32_t) * (size_t)g.rcap, st_));
         HIP_CHECK(hipMemsetAsync(d_.hkey, 0xFF, sizeof(unsigned long long) * (size_t)g.C, st_));
         HIP_CHECK(hipMemsetAsync(d_.hrank, 0, sizeof(uint32_t) * (size_t)g.C, st_));
+        if (d_.hctl) HIP_CHECK(hipMemsetAsync(d_.hctl, 0, (size_t)g.C, st_));
         HIP_CHECK(hipMemsetAsync(d_.ub, 0, sizeof(unsigned long long) * (size_t)g.n_groups, st_));
         HIP_CHECK(hipMemsetAsync(d_.gdirty, 1, (size_t)g.n_groups, st_));
         d_.cb_words = (g.rcap + 31) / 32;
