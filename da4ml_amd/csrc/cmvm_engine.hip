@@ -1705,23 +1705,27 @@ __global__ void __launch_bounds__(UPD_THREADS, DA_UPD_OCC) __attribute__((amdgpu
 
 // ------------------------------------------------------------------------------------------------ k_steps
 // SEVERAL greedy steps of a chain per launch, by ONE 1024-thread workgroup (one workgroup per chain): selection, substitution
-// and -- for all but the fattest steps -- the update of the pair counts, step after step, without leaving the kernel.
+// and -- for all but the fattest steps -- the update of the pair counts, step after step, without leaving the kernel.  OPT-IN
+// (DA4ML_HIP_FUSE=K): exact under every setting, but slower on MI355X than the (k_iter_select, k_iter_update) pair it was built to
+// replace in the thin part of a chain -- 29 against 27 us per step for one 256x256 chain, worse in batches and on small problems
+// (profiles/r04_step_engine.txt).  The reason is in the numbers of that file: a step that is not spread over the chip is bound by ONE
+// CU's instruction issue (~6 cycles per dependent instruction of a wavefront, four SIMDs), not by the round trips and kernel
+// boundaries this engine removes.  Kept as the measured answer to "many steps per launch in one workgroup per chain".
 //
-// Why.  A step of the (select, update) kernel pair costs two launches, two descriptor reads, the bounds of all table groups
-// re-loaded from memory, the hand-off written to and re-read from memory, and an update kernel that spends a 16-lane group and
-// three dependent round trips on every partner row -- although from a quarter of the way into a chain a step has a few hundred
-// partner rows of which a handful own a count block at all.  Here:
+// What it does differently from the kernel pair:
 //   * the workgroup is the chain's only writer for the whole launch, so the bounds, dirty flags and stored tie words of the table
 //     groups live in LDS (loaded once per launch, every change written to both copies): no "load bounds" round trip per step, and a
 //     block that changes below its group's bound does not dirty the group (group_note);
-//   * the update is THREAD PER PARTNER ROW: the cells of the row in the m substituted columns are m independent loads from the
-//     column-major cell array (no list reference, no list walk), the two count blocks it may share with A and B are probed through the
-//     table's control bytes (one 16-byte load per bucket and thread instead of a 128-byte key bucket per 16-lane group), all in ONE
-//     round trip; the digit pairs are counted in bit-sliced registers (KeyCnt), no LDS counters, no cross-lane operation.  A thread
-//     that finds a control-byte match verifies the key and rewrites the block's payload line itself; a thread whose row gains a count
-//     >= 2 with the new row claims a slot (compare-and-swap) and writes the new block itself.
-//   * a step that substitutes more than fuse_max_m columns or has more than fuse_max_np partner rows is handed to k_iter_update
-//     exactly as k_iter_select would (the first ~10 % of a 256 x 256 chain), and the launch ends there.
+//   * the update starts with a FILTER, thread per partner row: the cells of the row in the m substituted columns are m independent
+//     loads from the column-major cell array (no list reference, no list walk), the two count blocks it may share with A and B are
+//     probed through the table's control bytes (one 16-byte load per bucket and thread instead of a 128-byte key bucket per 16-lane
+//     group), all in ONE round trip; whether a key of the pair (row, new row) reaches a count of 2 is decided in two saturating bit
+//     planes.  A row that owns no block with A or B and gains none with the new row -- nearly all of them, late in a chain -- is
+//     finished there; the others go to the step's HEAVY list with their candidate slots;
+//   * the heavy rows are updated by 16-lane groups (update_items: k_iter_update's scheme, but key check, payload lines and cells leave
+//     in one round trip because the candidate slots come with the item);
+//   * a step that substitutes more than fuse_max_m columns, has more than fuse_max_np partner rows or more than fuse_max_nh heavy
+//     rows is handed to k_iter_update exactly as k_iter_select would -- after the filter only its heavy rows -- and the launch ends.
 // Ordering inside the launch: every step ends with "all stores acknowledged (s_waitcnt vmcnt(0)) + workgroup barrier"; one CU, one
 // vector L1, hence no cache maintenance (values that are modified by atomics -- keys, row bitmaps -- are read past the L1).  Mutable
 // chain state (step number, row count, list arena fill) is carried in registers and written back when the launch ends.
