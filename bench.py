@@ -230,11 +230,12 @@ def cpu_baseline(n_in, n_out, opts, budget_s, batch, gpu_time_batch=None):
     cores = cpu_pool.host_cores()
     # one 256x256 chain of the reference holds its 64.7 M initial pairs (24 bytes each) plus the sort buffer: ~4 GB per process
     need_gb = 4.0 * (n_in * n_out / 65536.0) ** 2 + 0.5
-    # one process per core, never more than half of the available memory allows at 1.5 x the estimate (a first attempt with 200+
-    # processes on the 256-core box took the box down: each started its numerical libraries' thread pools, 256 x 256 threads; the
-    # workers pin those to one thread since)
-    # (round 4: no longer capped at the batch size -- every host core the memory allows works on a chain of the batch, seeds repeating)
-    workers = max(1, min(cores, int(0.5 * cpu_pool.mem_available_gb() / (1.5 * need_gb))))
+    # one process per chain of the batch, never more than half of the available memory allows at 1.5 x the estimate
+    # Capped at the batch size (64).  Round 4 tried "every host core the memory allows" again (230 single-threaded processes on the
+    # 256-core box, 1.5 x 4.5 GB each = half of the available memory by the estimate above): the box was lost within the first
+    # 100 seconds of the call, as in round 2 -- so the pool stays at one process per chain of the batch, and the line carries the
+    # complete runs of the build container beside the extrapolated figure (measured_full_runs_build_container).
+    workers = max(1, min(cores, batch, int(0.5 * cpu_pool.mem_available_gb() / (1.5 * need_gb))))
     method = opts.get('method0', 'wmc')
     # (1) a time-bounded prefix of a chain of the batch on every core, all cores busy at once
     samples, wall = cpu_pool.run_pool(cpu_pool.sample_worker, [(okind, n_in, n_out, i % batch, method, budget_s) for i in range(workers)], workers)
