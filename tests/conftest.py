@@ -33,6 +33,16 @@ def oracle():
 
 
 @pytest.fixture(scope='session')
+def reference_oracle():
+    """The reference's OWN sources (oracle/_ref/libref.so: api.cc, cmvm_core.cc, state_opr.cc, indexers.cc, bit_decompose.cc,
+    mat_decompose.cc compiled where they lie, oracle/Makefile) when the build is present -- it travels to the GPU box with the
+    repository snapshot --, the restatement otherwise.  The GPU parity tests compare with THIS checker, live."""
+    from oracle.oracle import HERE, Oracle
+
+    return Oracle('ref' if (HERE / '_ref' / 'libref.so').exists() else 'port')
+
+
+@pytest.fixture(scope='session')
 def model():
     """Sequential model of the GPU engine linked with the product's host logic (tests/model)."""
     from oracle.oracle import Oracle

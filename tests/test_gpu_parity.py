@@ -9,6 +9,13 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture(scope='module')
+def oracle(reference_oracle):
+    """in this file the checker is the reference's own sources, run live beside the GPU (conftest.reference_oracle); the restatement
+    only where that build is absent.  (The restatement itself is pinned against the same build in tests/test_oracle.py.)"""
+    return reference_oracle
+
+
+@pytest.fixture(scope='module')
 def hip():
     from da4ml_amd import _binary
 
@@ -358,8 +365,8 @@ def test_step_engine_settings(oracle, env):
     rec = json.loads((Path(__file__).parent / 'golden' / 'large_chain_golden.json').read_text())['128x128_seed0_single_chain_ref']
     code = (
         "import sys, json, hashlib; sys.path.insert(0, '.'); sys.path.insert(0, 'tests')\n"
-        "from cases import int_matrix, random_case\nfrom da4ml_amd import _binary as hip\nfrom oracle.oracle import Oracle\n"
-        "o = Oracle('port'); bad = []\n"
+        "from cases import int_matrix, random_case\nfrom da4ml_amd import _binary as hip\nfrom oracle.oracle import HERE, Oracle\n"
+        "o = Oracle('ref' if (HERE / '_ref' / 'libref.so').exists() else 'port'); bad = []  # the reference's own sources when the build is there\n"
         "for s in range(40):\n"
         "    k, opts, _ = random_case(s)\n"
         "    if hip.solve(k, **opts) != o.solve(k, **opts): bad.append(s)\n"
