@@ -90,9 +90,18 @@ def test_fork_after_use(emu):
     assert emu('fork', timeout=300) == {'child': 0, 'parent': True, 'fork_during_solve_ok': True}
 
 
-def test_capacity_retry(emu):
-    r = emu('retry', env=dict(DA4ML_HIP_TABLE_SCALE='0.02', DA4ML_HIP_ROW_SCALE='0.05'))
+@pytest.mark.parametrize('fuse', ['0', '8'], ids=['pair', 'steps'])
+def test_capacity_retry(emu, fuse):
+    """arena heuristics far too small: capacity error on the device, rerun with larger arenas -- with the kernel pair and with the
+    step engine (whose in-kernel updates claim table slots themselves)"""
+    r = emu('retry', env=dict(DA4ML_HIP_TABLE_SCALE='0.02', DA4ML_HIP_ROW_SCALE='0.05', DA4ML_HIP_FUSE=fuse))
     assert r['equal'] and r['retries'] >= 1
+
+
+def test_table_geometry_of_a_large_chain_step_engine(emu):
+    """the pair-table geometry of a 256x256 chain (4096 groups of 512 slots: every lane of the selection holds four group bounds, the
+    LDS copy of the bounds is 68 KB) under the step engine"""
+    assert emu('big_table', env=dict(DA4ML_HIP_TABLE_SCALE='6000', DA4ML_HIP_FUSE='8'), timeout=1800)['bad'] == []
 
 
 def test_table_geometry_of_a_large_chain(emu):
