@@ -101,6 +101,7 @@ def test_large_records_of_the_restatement_match_the_reference_build():
                 assert (rec['sha256'], rec['cost'], rec['n_ops']) == (port['sha256'], port['cost'], port['n_ops']), key
                 pairs.append(key)
     assert '128x128_seed0_single_chain_ref' in pairs and '256x256_seed0_single_chain_ref' in pairs
+    assert '128x128_seed0_default_ref' in pairs and '256x256_seed0_default_ref' in pairs  # the full default search too (256x256: 96 minutes of libref on six threads, round 4)
 
 
 # ---- the reference's own tests (tests/test_cmvm.py), seeded, against the oracle --------------------------------------
