@@ -1734,7 +1734,7 @@ __global__ void __launch_bounds__(UPD_THREADS, DA_UPD_OCC) __attribute__((amdgpu
 // lists the set bits in LDS and works through them like k_iter_update, four per pass, fetching the list reference of a row where
 // k_iter_update reads it from the partner list --; the last two blocks store the six pairs among {A, B, new row} from the exact
 // counts the selection left (one wavefront each), as its last six wavefronts used to.
-constexpr int WL_CAP = 256;  // partner rows a wavefront lists per chunk of eight bitmap words
+constexpr int WL_CAP = 256;  // partner rows a wavefront lists per chunk of 64 units of four rows
 template <class Cell, int NWV>
 __device__ __forceinline__ void update_body_d(ChainDev *gq, bool in_range, int block_y, int grid_y) {
     constexpr int NTHR = NWV * WAVE;
@@ -1792,21 +1792,28 @@ __device__ __forceinline__ void update_body_d(ChainDev *gq, bool in_range, int b
     __syncthreads();
     unsigned int found = 0, inserts = 0, partners = 0;
     const int nwords = (int)((Nw + 31) >> 5), m = u.m;
-    for (int w0 = gw; w0 < nwords; w0 += 8 * total_waves) {  // wave-uniform: eight words (at most 256 rows) per chunk
-        const int w = w0 + lane * total_waves;
+    // the rows are dealt out in UNITS of four (a nibble of a bitmap word = one pass of the wavefront's four groups): unit x goes to
+    // wavefront x mod W.  (By whole words -- 32 rows -- the few hundred rows of a young chain, nearly all of them partners, landed on a
+    // handful of wavefronts: 36 us per launch on average instead of 12.)
+    const int nunits = nwords * 8;
+    for (int u0 = gw; u0 < nunits; u0 += WAVE * total_waves) {  // wave-uniform: 64 units (at most 256 rows) per chunk, their loads in flight together
+        const int unit = u0 + lane * total_waves;
+        const int w = unit >> 3;
+        const uint32_t nib0 = (uint32_t)(unit & 7) * 4u;
         uint32_t bits = 0;
-        if (lane < 8 && w < nwords) {
+        if (unit < nunits) {
             for (int k = 0; k < m; ++k) bits |= colbits[(uint32_t)s.col[k] * (uint32_t)cbw + (uint32_t)w];
             if ((int)(A >> 5) == w) bits &= ~(1u << (A & 31));
             if ((int)(B >> 5) == w) bits &= ~(1u << (B & 31));
             if ((int)(Nw >> 5) == w) bits &= ~(1u << (Nw & 31));
+            bits = (bits >> nib0) & 0xFu;
         }
         const int cnt = popc32(bits), inc = (int)wave_scan_add_u32((uint32_t)cnt);
         const int total = __builtin_amdgcn_readlane(inc, WAVE - 1);
         if (total == 0) continue;
         int at = inc - cnt;
         while (bits) {
-            s_wl[at++] = (uint32_t)(w << 5) + (uint32_t)ctz32(bits);
+            s_wl[at++] = (uint32_t)(w << 5) + nib0 + (uint32_t)ctz32(bits);
             bits &= bits - 1;
         }
         lds_fence();
