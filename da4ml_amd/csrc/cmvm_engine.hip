@@ -229,8 +229,6 @@ struct ChainDev {
     uint8_t *hctl;        // [C] control bytes: 0 never used | 1 + tag tombstone | 5..255 fingerprint of the slot's key
     void *ccell;          // [n_out][rcap] column-major cells (nullptr: chain not stepped by k_steps)
     int cell_bytes;       // sizeof(Cell) of the chain's layout
-    int tail_mode;        // 1: k_iter_select ends after the substitution; k_iter_update_d finds the partner rows itself and stores the six special pairs
-    uint32_t *spec_cnt;   // [6][Kpad] exact counts of the pairs among {A, B, new row} of the step (tail_mode: select -> update)
     int fuse_max_m, fuse_max_np, fuse_max_nh;  // k_steps applies a step's update itself when it substitutes <= fuse_max_m columns, has <= fuse_max_np partner rows and <= fuse_max_nh of them own or gain a count block
     int pb_log2;
     unsigned long long *ub;
@@ -771,7 +769,7 @@ template <class Cell, bool SHARDED = false> __device__ __forceinline__ int selec
     // ---- ONE scalar round trip: every descriptor field the block needs, pinned before the first branch (pin_sgpr; left
     // alone the compiler sinks each load behind the branch that first needs it -- ten dependent round trips in this kernel)
     int was_done = g->done, had_error = g->error, iter = g->iter, n_groups = g->n_groups, lcap = g->lcap, claim_words = g->claim_words;
-    int n_rows0 = g->n_rows, rcap = g->rcap, cbw = g->cb_words, adder_size = g->adder_size, carry_size = g->carry_size, tail_mode = SHARDED ? 0 : g->tail_mode;
+    int n_rows0 = g->n_rows, rcap = g->rcap, cbw = g->cb_words, adder_size = g->adder_size, carry_size = g->carry_size;
     uint32_t offN = g->rl_used, rl_cap = g->rl_cap, n_live0 = g->n_live, live_peak0 = g->live_peak;
     const uint32_t *step_mant = g->step_mant;
     const float *step_tab = g->step_tab;
@@ -791,7 +789,7 @@ template <class Cell, bool SHARDED = false> __device__ __forceinline__ int selec
     DA_GLOBAL unsigned long long *plist = (DA_GLOBAL unsigned long long *)g->plist;
     DA_GLOBAL da_i4 *picks = (DA_GLOBAL da_i4 *)g->picks;
     DA_GLOBAL int32_t *cs_slab = (DA_GLOBAL int32_t *)g->cs_slab, *cs_flags = (DA_GLOBAL int32_t *)g->cs_flags;
-    pin_sgpr(was_done, had_error, iter, n_groups, lcap, claim_words, n_rows0, rcap, cbw, adder_size, carry_size, tail_mode, offN, rl_cap, n_live0, live_peak0, step_mant, step_tab, n_step_mant);
+    pin_sgpr(was_done, had_error, iter, n_groups, lcap, claim_words, n_rows0, rcap, cbw, adder_size, carry_size, offN, rl_cap, n_live0, live_peak0, step_mant, step_tab, n_step_mant);
     pin_sgpr(c.n_out, c.n_bits, c.K, c.Kpad, c.method, c.gs_log2, c.pb_log2, c.cmask, c.windows, c.hkey, c.hrank, c.hblk, c.ub, c.gdirty, c.rows);
     pin_sgpr(collen, gtie_arr, rowoff, rl, mA, mB, mcol, collist, cmap, colbits, pl_ids, plist, picks);
     if constexpr (SHARDED) pin_sgpr(cs_slab, cs_flags);
@@ -1219,29 +1217,6 @@ template <class Cell, bool SHARDED = false> __device__ __forceinline__ int selec
     }
     __syncthreads();
     SEL_TIMER_MARK(4)
-    if (tail_mode) {
-        // ---- tail mode: the selection ends here.  k_iter_update_d finds the partner rows itself (every wavefront ORs its share of the
-        // substituted columns' row bitmaps) and two extra blocks per chain store the six special pairs, from the exact counts handed over
-        // here -- off this kernel's critical path (one CU), into a launch that is spread over the chip anyway.
-        DA_GLOBAL uint32_t *spec = (DA_GLOBAL uint32_t *)g->spec_cnt;
-        for (int k = tid; k < 6 * Kpad; k += SEL_THREADS) spec[k] = s_cnt[k];
-        if (tid == 0) {
-            rowoff[Nw] = da_u2{offN, (uint32_t)m};
-            g->rl_used = offN + (uint32_t)m;
-            g->m = m;
-            g->n_partners = -1;  // unknown here: counted by the update launch
-            atomicAdd(&g->st_matches, (unsigned long long)s_matches);
-            const unsigned long long eb = sizeof(Entry), cb = sizeof(Cell);
-            atomicAdd(&g->st_sel_bytes, 17ull * (unsigned)n_groups + 4ull * (unsigned)n_out + 48ull + 2ull * eb * (unsigned)(lenA + (same ? 0 : lenB)) +
-                                            (unsigned)m * (4ull + 2ull * cb + eb + 8ull + 12ull) + 2ull * (unsigned)n_out + 24ull * (unsigned)c.K);
-            g->A = A;
-            g->B = B;
-            g->Nw = Nw;
-            g->n_rows = (int)Nw + 1;
-            g->iter = iter + 1;
-        }
-        return 0;
-    }
     int total = 0;
     if constexpr (SHARDED) {  // only the column-sharded chain still walks the column lists
     // exclusive prefix sum of the list lengths of the matched columns (m <= n_out)
@@ -1516,9 +1491,9 @@ template <class Cell> __device__ __forceinline__ void copy_handoff(const UpdStep
 // update_partners: ONE WAVEFRONT works through the partner rows first + q, first + stride + q, ... < limit of the step (q = its
 // four 16-lane groups); no block-level synchronisation inside.  `ref_next` = the (pre-fetched) reference of this group's first
 // partner, `rnew` the record of the new row.
-template <class Cell, class RefFn>
+template <class Cell>
 __device__ __forceinline__ void update_partners(ChainDev *g, const UpdStep<Cell> &u, const UpdLds<Cell> &s, int first, int stride, int limit, unsigned long long ref_next,
-                                                const RowInfo &rnew, unsigned int &found, unsigned int &inserts, RefFn ref_at) {
+                                                const RowInfo &rnew, unsigned int &found, unsigned int &inserts) {
     using F = RowFmt<Cell>;
     using Entry = typename F::Entry;
     constexpr int QCW = sizeof(Cell) == 4 ? 2 : 4;  // count words per lane: narrow layout Kpad / 2 <= 24 words, wide <= 60
@@ -1526,6 +1501,7 @@ __device__ __forceinline__ void update_partners(ChainDev *g, const UpdStep<Cell>
     const uint32_t A = u.A, B = u.B, Nw = u.Nw;
     const int m = u.m, n_in = u.n_in;
     const DA_GLOBAL Entry *rl = u.rl;
+    const DA_GLOBAL unsigned long long *plist = u.plist;
     Cell *s_mA = s.mA, *s_mB = s.mB;
     int *s_col = s.col;
     uint16_t *s_cmap = s.cmap;
@@ -1548,7 +1524,7 @@ __device__ __forceinline__ void update_partners(ChainDev *g, const UpdStep<Cell>
         const bool valid = idx < limit;
         // ---- round trip 1: the group's partner reference (the next pass's one is fetched now: off the critical path there)
         const unsigned long long ref = ref_next;
-        ref_next = idx + stride < limit ? ref_at(idx + stride) : 0ull;
+        ref_next = idx + stride < limit ? plist[idx + stride] : 0ull;
         const uint32_t pr = ref_row(ref), off = ref_off(ref);
         const bool dense = valid && (int)pr < n_in;  // dense input row: entry j is column j -- fetch the substituted columns only
         const int cnt = !valid ? 0 : dense ? m : (int)ref_len(ref);
@@ -1707,7 +1683,7 @@ __device__ __forceinline__ void update_body(ChainDev *gq, bool in_range, int blo
     copy_handoff<Cell>(u, s, tid, NTHR);  // one pass, one barrier (the column map arrives ready-made)
     __syncthreads();
     unsigned int found = 0, inserts = 0;
-    update_partners<Cell>(gq, u, s, gw * QN, total_waves * QN, u.n_partners, ref0, rnew, found, inserts, [&](int i) { return u.plist[i]; });
+    update_partners<Cell>(gq, u, s, gw * QN, total_waves * QN, u.n_partners, ref0, rnew, found, inserts);
     // statistics: summed per block in LDS, then ONE pair of device atomics per block.  (Four atomics per wave on one line
     // of the chain descriptor -- 640 per chain and launch, from all XCDs -- serialise at ~12 ns each and every launch had
     // to wait for them; the partner / cell counts are added by k_iter_select, which knows them without counting.)
@@ -1725,128 +1701,6 @@ template <class Cell>
 __global__ void __launch_bounds__(UPD_THREADS, DA_UPD_OCC) __attribute__((amdgpu_num_sgpr(DA_UPD_SGPRS))) k_iter_update(ChainDev *chains, int n_chains) {
     // Grid (chains padded to a multiple of 8, blocks per chain): the chain index is the FAST grid dimension (see update_body)
     update_body<Cell, UPD_WAVES>(&chains[(int)blockIdx.x < n_chains ? blockIdx.x : 0], (int)blockIdx.x < n_chains, (int)blockIdx.y, (int)gridDim.y);  // clamped: the descriptor read is unconditional
-}
-
-// ------------------------------------------------------------------------------------------------ k_iter_update_d (tail mode)
-// The update launch of a chain whose selection ended after the substitution (ChainDev::tail_mode): grid (chains padded to 8,
-// blocks per chain + 2).  The first blocks find the partner rows THEMSELVES -- every wavefront ORs its share of the substituted
-// columns' row bitmaps (words gw, gw + W, gw + 2W, ... of W wavefronts: the partner rows of a step are spread over all of them),
-// lists the set bits in LDS and works through them like k_iter_update, four per pass, fetching the list reference of a row where
-// k_iter_update reads it from the partner list --; the last two blocks store the six pairs among {A, B, new row} from the exact
-// counts the selection left (one wavefront each), as its last six wavefronts used to.
-constexpr int WL_CAP = 256;  // partner rows a wavefront lists per chunk of 64 units of four rows
-template <class Cell, int NWV>
-__device__ __forceinline__ void update_body_d(ChainDev *gq, bool in_range, int block_y, int grid_y) {
-    constexpr int NTHR = NWV * WAVE;
-    const UpdStep<Cell> u = load_upd_step<Cell>(gq);
-    const DA_GLOBAL uint32_t *colbits = (const DA_GLOBAL uint32_t *)gq->colbits;
-    const DA_GLOBAL da_u2 *rowoff = (const DA_GLOBAL da_u2 *)gq->rowoff;
-    const DA_GLOBAL uint32_t *spec = (const DA_GLOBAL uint32_t *)gq->spec_cnt;
-    int cbw = gq->cb_words;
-    pin_sgpr(colbits, rowoff, spec, cbw);
-    if (!in_range || u.done) return;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = lane_id(), wid = wave_id();
-    const int nb = grid_y - 2;  // partner blocks
-    const Ctx &c = u.c;
-    const uint32_t A = u.A, B = u.B, Nw = u.Nw;
-    const bool same = A == B;
-    if (block_y >= nb) {
-        // ---- the six special pairs: (A,A) (A,B) (B,B) are replaced, (A,N) (B,N) (N,N) created
-        const int sp = (block_y - nb) * NWV + wid;
-        if (sp >= 6) return;
-        uint32_t *cnt = reinterpret_cast<uint32_t *>(smem) + (size_t)wid * c.Kpad;
-        for (int k = lane; k < c.Kpad; k += WAVE) cnt[k] = spec[(size_t)sp * c.Kpad + k];
-        const RowInfo ra = load_row(c.rows, A), rb = load_row(c.rows, B), sn = load_row(c.rows, Nw);
-        lds_fence();
-        uint32_t lo = A, hi = A;
-        bool active = true, existed = false;
-        switch (sp) {
-        case 0: lo = A, hi = A, existed = true; break;
-        case 1: lo = A, hi = B, existed = true, active = !same; break;
-        case 2: lo = B, hi = B, existed = true, active = !same; break;
-        case 3: lo = A, hi = Nw; break;
-        case 4: lo = B, hi = Nw, active = !same; break;
-        default: lo = Nw, hi = Nw; break;
-        }
-        if (!active) return;
-        const unsigned long long key = pack_pair(lo, hi);
-        const int slot = existed ? table_find(c, key, hash_pair(lo, hi)) : -1;
-        if (slot >= 0)
-            table_update(c, slot, key, [&](int k, uint32_t) { return cnt[k]; });
-        else if (wave_any_ge2(cnt, c.K)) {
-            const RowInfo xa = pick_row(lo == Nw, sn, pick_row(lo == A, ra, rb)), xb = pick_row(hi == Nw, sn, pick_row(hi == A, ra, rb));
-            table_insert(c, lo, hi, xa, xb, [&](int k) { return cnt[k]; });
-        }
-        return;
-    }
-    UpdLds<Cell> s;
-    unsigned char *counters = smem + align16(UpdLds<Cell>::table_bytes(c.n_out));
-    s.carve(smem, counters + (size_t)wid * UpdLds<Cell>::wave_bytes(c.Kpad), c.n_out);
-    uint32_t *s_wl = reinterpret_cast<uint32_t *>(counters + (size_t)NWV * UpdLds<Cell>::wave_bytes(c.Kpad)) + (size_t)wid * WL_CAP;  // this wave's partner rows
-    const int total_waves = nb * NWV, gw = block_y * NWV + wid;
-    const RowInfo rnew = load_row(c.rows, Nw);
-    __shared__ unsigned int s_stat[3];
-    if (tid < 3) s_stat[tid] = 0;
-    copy_handoff<Cell>(u, s, tid, NTHR);
-    __syncthreads();
-    unsigned int found = 0, inserts = 0, partners = 0;
-    const int nwords = (int)((Nw + 31) >> 5), m = u.m;
-    // the rows are dealt out in UNITS of four (a nibble of a bitmap word = one pass of the wavefront's four groups): unit x goes to
-    // wavefront x mod W.  (By whole words -- 32 rows -- the few hundred rows of a young chain, nearly all of them partners, landed on a
-    // handful of wavefronts: 36 us per launch on average instead of 12.)
-    const int nunits = nwords * 8;
-    for (int u0 = gw; u0 < nunits; u0 += WAVE * total_waves) {  // wave-uniform: 64 units (at most 256 rows) per chunk, their loads in flight together
-        const int unit = u0 + lane * total_waves;
-        const int w = unit >> 3;
-        const uint32_t nib0 = (uint32_t)(unit & 7) * 4u;
-        uint32_t bits = 0;
-        if (unit < nunits) {
-            for (int k = 0; k < m; ++k) bits |= colbits[(uint32_t)s.col[k] * (uint32_t)cbw + (uint32_t)w];
-            if ((int)(A >> 5) == w) bits &= ~(1u << (A & 31));
-            if ((int)(B >> 5) == w) bits &= ~(1u << (B & 31));
-            if ((int)(Nw >> 5) == w) bits &= ~(1u << (Nw & 31));
-            bits = (bits >> nib0) & 0xFu;
-        }
-        const int cnt = popc32(bits), inc = (int)wave_scan_add_u32((uint32_t)cnt);
-        const int total = __builtin_amdgcn_readlane(inc, WAVE - 1);
-        if (total == 0) continue;
-        int at = inc - cnt;
-        while (bits) {
-            s_wl[at++] = (uint32_t)(w << 5) + nib0 + (uint32_t)ctz32(bits);
-            bits &= bits - 1;
-        }
-        lds_fence();
-        auto ref_at = [&](int i) {
-            const uint32_t r = s_wl[i];
-            const da_u2 ro = rowoff[r];
-            return ref_pack(r, ro.y, ro.x);
-        };
-        const unsigned long long ref0 = (lane >> 4) < total ? ref_at(lane >> 4) : 0ull;
-        update_partners<Cell>(gq, u, s, 0, QN, total, ref0, rnew, found, inserts, ref_at);
-        partners += (unsigned)total;
-        lds_fence();  // the list is rewritten by the next chunk
-    }
-    if (lane == 0 && (found | inserts | partners)) {
-        if (found) atomicAdd(&s_stat[0], found);
-        if (inserts) atomicAdd(&s_stat[1], inserts);
-        if (partners) atomicAdd(&s_stat[2], partners);
-    }
-    __syncthreads();
-    if (tid == 0) {
-        if (s_stat[0]) atomicAdd(&gq->st_found, (unsigned long long)s_stat[0]);
-        if (s_stat[1]) atomicAdd(&gq->st_inserts, (unsigned long long)s_stat[1]);
-        if (s_stat[2]) {
-            atomicAdd(&gq->st_partners, (unsigned long long)s_stat[2]);
-            atomicAdd(&gq->st_cells, (unsigned long long)s_stat[2] * (unsigned)m);
-            atomicAdd(&gq->st_sel_bytes, (unsigned long long)s_stat[2] * 12ull);  // a partner row's bitmap share is priced below; its id and list reference here
-        }
-        if (block_y == 0) atomicAdd(&gq->st_sel_bytes, 4ull * (unsigned)m * (unsigned)nwords + 6ull * (16ull + 4ull * (unsigned)c.K));  // the row bitmaps of the m columns, six special blocks
-    }
-}
-template <class Cell>
-__global__ void __launch_bounds__(UPD_THREADS, DA_UPD_OCC) __attribute__((amdgpu_num_sgpr(DA_UPD_SGPRS))) k_iter_update_d(ChainDev *chains, int n_chains) {
-    update_body_d<Cell, UPD_WAVES>(&chains[(int)blockIdx.x < n_chains ? blockIdx.x : 0], (int)blockIdx.x < n_chains, (int)blockIdx.y, (int)gridDim.y);
 }
 
 // ------------------------------------------------------------------------------------------------ k_steps
@@ -3129,7 +2983,6 @@ struct HipBackend::Impl {
     // batches and on small problems (profiles/r04_step_engine.txt): one CU's instruction issue is the bound of a step that is not
     // spread over the chip, DESIGN.md section 9.  Kept as the measured answer, not as the product path.
     int fuse_steps = 0, fuse_max_m = 8, fuse_max_np = 2048, fuse_max_nh = 96;
-    int tail_mode = 0;  // DA4ML_HIP_TAIL=1 (A/B): the selection ends after the substitution, k_iter_update_d does the rest (ChainDev::tail_mode)
 };
 
 HipBackend::HipBackend(int device) : impl_(new Impl) {
@@ -3146,7 +2999,6 @@ HipBackend::HipBackend(int device) : impl_(new Impl) {
     if (const char *e = std::getenv("DA4ML_HIP_FUSE_M")) impl_->fuse_max_m = std::max(0, std::atoi(e));
     if (const char *e = std::getenv("DA4ML_HIP_FUSE_NP")) impl_->fuse_max_np = std::max(0, std::atoi(e));
     if (const char *e = std::getenv("DA4ML_HIP_FUSE_NH")) impl_->fuse_max_nh = std::max(0, std::atoi(e));
-    if (const char *e = std::getenv("DA4ML_HIP_TAIL")) impl_->tail_mode = std::atoi(e) != 0;
     HIP_CHECK(hipMalloc(&impl_->d_done, sizeof(unsigned int)));
     HIP_CHECK(hipHostMalloc(&impl_->h_done, 2 * sizeof(unsigned int), hipHostMallocDefault));
     HIP_CHECK(hipStreamCreateWithFlags(&impl_->poll_stream, hipStreamNonBlocking));
@@ -3203,7 +3055,6 @@ size_t carve_chain(unsigned char *base, const ChainJob &job, const Geometry &g, 
     d.mA = c.take<unsigned char>(n_out * cell);
     d.mB = c.take<unsigned char>(n_out * cell);
     d.plist = c.take<unsigned long long>(g.rcap);
-    d.spec_cnt = c.take<uint32_t>((size_t)6 * g.Kpad);
     d.picks = c.take<int4>(g.rcap);
     d.fin_row = c.take<uint32_t>(n_out * (size_t)g.lcap);
     d.fin_cell = c.take<unsigned long long>(n_out * (size_t)g.lcap);
@@ -3393,7 +3244,6 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
         d.fuse_max_m = std::min(im.fuse_max_m, QG);  // update_items: one substituted column per lane of a 16-lane group
         d.fuse_max_np = std::min(im.fuse_max_np, 2 * SEL_THREADS);  // a filtered hand-off rewrites the heavy list in place: two items per thread
         d.fuse_max_nh = im.fuse_max_nh;
-        d.tail_mode = im.tail_mode && !g.fuse ? 1 : 0;
     }
     for (int i = 0; i < n; ++i) {
         desc[i].n_step_mant = (int)step_tabs[i].mant.size();
@@ -3442,8 +3292,7 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
         sel_lds[w] = std::max(sel_lds[w], s);
         if (geo[i].fuse)  // k_steps: group bounds + tie words + dirty flags, B's list, consumed digits of A and B, special counters, five per-column arrays
             steps_lds = std::max(steps_lds, align_up(17 * (size_t)geo[i].n_groups + no * (entb + 2 * cellb + 20) + (6 + (size_t)(SEL_THREADS / WAVE) * QN * 3) * (size_t)geo[i].Kpad * 4 + 16, 16));
-        upd_lds[w] = std::max(upd_lds[w], align_up(2 * no * cellb + no * 6, 16) + align_up((size_t)UPD_WAVES * QN * 3 * (size_t)geo[i].Kpad * 4, 16) +
-                                              (im.tail_mode ? (size_t)UPD_WAVES * WL_CAP * 4 : 0));  // UpdLds: hand-off tables | counters | (tail mode) the waves' partner lists
+        upd_lds[w] = std::max(upd_lds[w], align_up(2 * no * cellb + no * 6, 16) + align_up((size_t)UPD_WAVES * QN * 3 * (size_t)geo[i].Kpad * 4, 16));  // UpdLds: hand-off tables | counters
         pair_lds[w] = std::max(pair_lds[w], (size_t)4 * geo[i].Kpad * 4);
         max_pairs[w] = std::max(max_pairs[w], (long long)jobs[i].n_in * (jobs[i].n_in + 1) / 2);
     }
@@ -3514,12 +3363,7 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
         else
             hipLaunchKernelGGL(k_iter_select<uint64_t>, dim3(gr.count), dim3(SEL_THREADS), sel_lds[1], gr.stream, base, im.d_done);
         if (se) HIP_CHECK(hipEventRecord(se[1], gr.stream));
-        const bool tail = im.tail_mode && !(gr.w == 0 && fuse);
-        if (tail && gr.w == 0)
-            hipLaunchKernelGGL(k_iter_update_d<uint32_t>, dim3((gr.count + 7) & ~7, upd_blocks[0] + 2), dim3(UPD_THREADS), upd_lds[0], gr.stream, base, gr.count);
-        else if (tail)
-            hipLaunchKernelGGL(k_iter_update_d<uint64_t>, dim3((gr.count + 7) & ~7, upd_blocks[1] + 2), dim3(UPD_THREADS), upd_lds[1], gr.stream, base, gr.count);
-        else if (gr.w == 0)
+        if (gr.w == 0)
             hipLaunchKernelGGL(k_iter_update<uint32_t>, dim3((gr.count + 7) & ~7, upd_blocks[0]), dim3(UPD_THREADS), upd_lds[0], gr.stream, base, gr.count);
         else
             hipLaunchKernelGGL(k_iter_update<uint64_t>, dim3((gr.count + 7) & ~7, upd_blocks[1]), dim3(UPD_THREADS), upd_lds[1], gr.stream, base, gr.count);
