@@ -6,10 +6,8 @@
 //   k_prepare        _center + global digit width            bit_decompose.hh:25-34, bit_decompose.cc:22-27
 //   k_init_cells     CSD recoding + SparseExpr build          bit_decompose.cc:28-42, state_opr.cc:93-112
 //   k_init_pairs     all-pairs enumeration / FreqMap::initialize   state_opr.cc:117-143, types.hh:73-100
-//   k_steps          several greedy steps of a chain per launch by ONE workgroup: idx_* selectors + update_expr + update_stats
-//                    (thread-per-partner update, group bounds resident in LDS)      cmvm_core.cc:10-72, indexers.cc:6-90, state_opr.cc:227-345
-//   k_iter_select    idx_mc / idx_mc_dc / idx_wmc / idx_wmc_dc + update_expr   indexers.cc:6-90, state_opr.cc:227-283   (wide and column-sharded chains)
-//   k_iter_update    update_stats (purge + regenerate) as an exact incremental update   state_opr.cc:285-345     (steps k_steps hands off)
+//   k_iter_select    idx_mc / idx_mc_dc / idx_wmc / idx_wmc_dc + update_expr   indexers.cc:6-90, state_opr.cc:227-283
+//   k_iter_update    update_stats (purge + regenerate) as an exact incremental update   state_opr.cc:285-345
 //   k_extract        digit gather of to_solution             cmvm_core.cc:103-113
 //   k_col_dist       stage-1 CSD Hamming distances           mat_decompose.cc:75-93
 //
@@ -29,10 +27,7 @@
 //             hkey[C] u64 (16 keys = one 128-byte line = one probe bucket), hrank[C] u32 (selection rank of the block's
 //             best key, 0 = none; the array the selection re-reads), hblk[C] one PAYLOAD LINE per slot:
 //             {n_overlap, |dlat|, rank copy, index of the best key, K x u16 exact occurrence counts} -- a block update
-//             reads and writes ONE line instead of four arrays; hctl[C] u8 CONTROL BYTES (0 = slot never used, 1..4 = tombstone of
-//             launch tag 0..3, 5..255 = fingerprint of the key in the slot): a thread probes a 16-slot bucket with ONE 16-byte load
-//   ccell   [n_out][rcap]  Cell    column-major copy of the cells (chains stepped by k_steps): the cells of a partner row in the
-//                                  substituted columns are m independent loads, no list walk
+//             reads and writes ONE line instead of four arrays
 //   ub      [C / GS]       u64     upper bound of (rank << 32 | tie_word >> 23) over a group of GS consecutive slots
 //
 // The reference keeps a sorted table of all pairs with count >= 2, purges every entry touching the two
@@ -127,7 +122,6 @@ struct BlkHdr {
 // global loads in flight and serialise the software-pipelined loads of the greedy-loop kernels.  The hot kernels
 // therefore keep their table / row / list pointers in the global address space (GLOBAL instructions, vmcnt only).
 #define DA_GLOBAL __attribute__((address_space(1)))
-#define DA_LDS __attribute__((address_space(3)))
 template <class T> __device__ __forceinline__ T *gen(DA_GLOBAL T *p) { return (T *)p; }  // for the HIP atomic API
 // Wave-uniform values pinned into scalar registers at this point of the program.  The greedy-loop kernels read ~30 fields
 // of their chain descriptor; left alone, the compiler sinks each scalar load behind the early-exit branch that first needs
@@ -160,8 +154,6 @@ __device__ __forceinline__ void load_fence() {
     asm volatile("" ::: "memory");         // the optimiser does not move memory operations across
     __builtin_amdgcn_sched_barrier(0);      // nor does the instruction scheduler move anything (e.g. a wait + v_readfirstlane of
 }                                           // the first loaded value in front of the other loads)
-// every store this wave has issued is acknowledged (k_steps: in front of the workgroup barrier that ends a step)
-#define DA_DRAIN_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 __host__ __device__ __forceinline__ size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
 typedef float da_f4 __attribute__((ext_vector_type(4)));
 typedef int da_i4 __attribute__((ext_vector_type(4)));
@@ -226,10 +218,6 @@ struct ChainDev {
     unsigned long long *hkey;
     uint32_t *hrank;
     unsigned char *hblk;  // [C] payload lines of (1 << pb_log2) bytes
-    uint8_t *hctl;        // [C] control bytes: 0 never used | 1 + tag tombstone | 5..255 fingerprint of the slot's key
-    void *ccell;          // [n_out][rcap] column-major cells (nullptr: chain not stepped by k_steps)
-    int cell_bytes;       // sizeof(Cell) of the chain's layout
-    int fuse_max_m, fuse_max_np, fuse_max_nh;  // k_steps applies a step's update itself when it substitutes <= fuse_max_m columns, has <= fuse_max_np partner rows and <= fuse_max_nh of them own or gain a count block
     int pb_log2;
     unsigned long long *ub;
     unsigned long long *gtie;  // [n_groups] full tie word of the group's best entry (valid while the group is clean)
@@ -278,7 +266,6 @@ struct ChainDev {
     const float *step_tab;
     int n_step_mant;
     unsigned long long st_sel_bytes;  // algorithmic bytes of the selection steps (all but the group re-reads, which st_rescans prices)
-    unsigned long long st_fused, st_handoffs, st_tpp_bytes;  // k_steps: steps updated inside the kernel / handed to k_iter_update; algorithmic bytes of the in-kernel updates
     unsigned long long st_phase[12];  // shader-clock cycles per kernel phase (select: 0-6, update: 7-11)
 };
 
@@ -376,18 +363,10 @@ struct Ctx {
     DA_GLOBAL unsigned char *hblk;
     DA_GLOBAL unsigned long long *ub;
     DA_GLOBAL uint8_t *gdirty;
-    DA_GLOBAL uint8_t *hctl;
     const DA_GLOBAL RowInfo *rows;
     ChainDev *g;  // derived from the kernel argument: already known to be global
     unsigned long long tomb;  // this launch's tombstone value
-    // k_steps only: the group bounds and dirty flags of the chain live in LDS for the whole launch (the workgroup is the chain's only
-    // writer); every change goes to both copies.  nullptr elsewhere.
-    DA_LDS unsigned long long *l_ub;
-    DA_LDS uint8_t *l_dirty;
 };
-// control byte of a tombstone written with `tomb` / fingerprint of a row pair (5..255; independent of the slot hash)
-__device__ __forceinline__ uint8_t ctl_of_tomb(unsigned long long tomb) { return (uint8_t)(1u + (uint32_t)(KEY_TOMB - tomb)); }
-__device__ __forceinline__ uint32_t ctl_fp(uint32_t lo, uint32_t hi) { return 5u + (((((lo * 0xC2B2AE35u) ^ (hi * 0x27D4EB2Fu)) >> 24) * 251u) >> 8); }
 
 // launch_id: 2 * iteration for k_iter_select, 2 * iteration + 1 for k_iter_update (only the low two bits are used)
 __device__ __forceinline__ Ctx make_ctx_raw(ChainDev *g, int launch_id) {
@@ -407,11 +386,8 @@ __device__ __forceinline__ Ctx make_ctx_raw(ChainDev *g, int launch_id) {
     c.hblk = (DA_GLOBAL unsigned char *)g->hblk;
     c.ub = (DA_GLOBAL unsigned long long *)g->ub;
     c.gdirty = (DA_GLOBAL uint8_t *)g->gdirty;
-    c.hctl = (DA_GLOBAL uint8_t *)g->hctl;
     c.rows = (const DA_GLOBAL RowInfo *)g->rows;
     c.g = g;
-    c.l_ub = nullptr;
-    c.l_dirty = nullptr;
     return c;
 }
 __device__ __forceinline__ void ctx_finish(Ctx &c) { c.windows = c.windows / WAVE ? c.windows / WAVE : 1; }  // after the fields are pinned
@@ -440,10 +416,6 @@ __device__ __forceinline__ DA_GLOBAL uint16_t *blk_cnt(const Ctx &c, int slot) {
 // always stored in the first bucket of its sequence that had a free slot, and slots never return to EMPTY, so a
 // look-up stops at the first bucket that contains the key or an EMPTY slot.
 constexpr uint32_t BUCKET = 16;
-// Keys are claimed with compare-and-swap, which is performed in the L2: a workgroup that lives across many steps (k_steps) reads
-// them past its CU's L1 (global_load ... sc1), so that a line fetched in an earlier step cannot hide a later claim.
-__device__ __forceinline__ unsigned long long ld_key(const DA_GLOBAL unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ uint32_t ld_l2_u32(const DA_GLOBAL uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // look-up continuing at bucket number `first_bucket` of the sequence, 4 buckets (64 lanes) per step; slot or -1
 __device__ int table_find_from(const Ctx &c, unsigned long long key, uint32_t h, uint32_t first_bucket) {
@@ -451,7 +423,7 @@ __device__ int table_find_from(const Ctx &c, unsigned long long key, uint32_t h,
     const uint32_t b0 = (h & ~(BUCKET - 1)) + first_bucket * BUCKET;
     for (uint32_t w = 0; w < c.windows + 1; ++w) {
         uint32_t s = (b0 + w * WAVE + lane) & c.cmask;
-        unsigned long long kk = c.hctl ? ld_key(&c.hkey[s]) : c.hkey[s];  // (k_steps: past the L1, see ld_key)
+        unsigned long long kk = c.hkey[s];
         unsigned long long hit = __ballot(kk == key);
         if (hit) return (int)((b0 + w * WAVE + (__ffsll((long long)hit) - 1)) & c.cmask);
         if (__ballot(kk == KEY_EMPTY)) return -1;
@@ -465,7 +437,7 @@ __device__ int table_claim(const Ctx &c, unsigned long long key, uint32_t h) {
     const uint32_t b0 = h & ~(BUCKET - 1);
     for (uint32_t w = 0; w < c.windows + 1; ++w) {
         uint32_t s = (b0 + w * WAVE + lane) & c.cmask;
-        unsigned long long kk = c.hctl ? ld_key(&c.hkey[s]) : c.hkey[s];
+        unsigned long long kk = c.hkey[s];
         unsigned long long avail = __ballot(kk == KEY_EMPTY || (kk >= KEY_TOMB_LO && kk != c.tomb));
         while (avail) {
             int l = __ffsll((long long)avail) - 1;
@@ -474,7 +446,6 @@ __device__ int table_claim(const Ctx &c, unsigned long long key, uint32_t h) {
             if (lane == l) {
                 ok = atomicCAS(gen(&c.hkey[s]), kk, key) == kk;
                 if (ok && kk == KEY_EMPTY) atomicAdd(&c.g->n_used, 1u);
-                if (ok && c.hctl) c.hctl[s] = (uint8_t)ctl_fp((uint32_t)key, (uint32_t)(key >> 32));
             }
             ok = __shfl(ok, l);
             if (ok) return (int)((b0 + w * WAVE + l) & c.cmask);
@@ -484,22 +455,9 @@ __device__ int table_claim(const Ctx &c, unsigned long long key, uint32_t h) {
 }
 
 // A block's best (rank, key) changed from bound word `w_old` to `w_new` (0 = not selectable): raise the group's bound if needed and
-// mark the group dirty -- unless (k_steps, bounds in LDS) both words are below the group's bound: then the block neither was nor
-// becomes the group's best entry, and a clean group's bound and stored tie word stay exact.  (The bound only rises while blocks
-// are updated; a stale smaller value read here errs on the safe side.)
+// mark the group dirty
 __device__ __forceinline__ void group_note(const Ctx &c, int slot, unsigned long long w_old, unsigned long long w_new) {
     const int grp = slot >> c.gs_log2;
-    if (c.l_ub) {
-        const unsigned long long M = *(volatile DA_LDS unsigned long long *)&c.l_ub[grp];
-        if (w_new > M) {
-            (void)__hip_atomic_fetch_max(&c.l_ub[grp], w_new, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // ds_max_u64
-            atomicMax(gen(&c.ub[grp]), w_new);
-        }
-        if (w_old < M && w_new < M) return;
-        c.l_dirty[grp] = 1;
-        c.gdirty[grp] = 1;
-        return;
-    }
     if (w_new > w_old) atomicMax(gen(&c.ub[grp]), w_new);
     c.gdirty[grp] = 1;
 }
@@ -544,7 +502,6 @@ __device__ __forceinline__ void block_commit(const Ctx &c, int slot, unsigned lo
     if (!alive) {
         c.hrank[slot] = 0;
         c.hkey[slot] = c.tomb;
-        if (c.hctl) c.hctl[slot] = ctl_of_tomb(c.tomb);
         atomicSub(&c.g->n_live, 1u);
         if (h.rank) group_note(c, slot, w_old, 0ull);
         return;
@@ -661,8 +618,6 @@ __global__ void __launch_bounds__(256) k_init_state(ChainDev *chains) {
     fill16(ch.ub, sizeof(unsigned long long) * (size_t)ch.n_groups, 0u, t0, stride);
     fill16(ch.gdirty, (size_t)ch.n_groups, 0x01010101u, t0, stride);
     fill16(ch.colbits, sizeof(uint32_t) * (size_t)ch.n_out * ch.cb_words, 0u, t0, stride);
-    if (ch.hctl) fill16(ch.hctl, (size_t)ch.C, 0u, t0, stride);
-    if (ch.ccell) fill16(ch.ccell, (size_t)ch.n_out * (size_t)ch.rcap * (size_t)ch.cell_bytes, 0u, t0, stride);
 }
 
 template <class Cell> __global__ void __launch_bounds__(256) k_init_cells(ChainDev *chains) {
@@ -682,7 +637,6 @@ template <class Cell> __global__ void __launch_bounds__(256) k_init_cells(ChainD
             naf_masks(ch.xint[(size_t)i * ch.pn_out + ch.col0 + j], p, m);
             c = dead ? (Cell)0 : O::make(p, m);
             rl[(size_t)i * ch.n_out + j] = F::pack((uint32_t)j, c);  // dense row: entry j is column j, empty cells included
-            if (ch.ccell) reinterpret_cast<Cell *>(ch.ccell)[(size_t)j * ch.rcap + i] = c;
         }
         unsigned long long nz = __ballot(c != 0);
         if (lane < 2 && base + 32 * lane < ch.n_in) ch.colbits[(size_t)j * ch.cb_words + (base >> 5) + lane] = (uint32_t)(nz >> (32 * lane));
@@ -775,7 +729,6 @@ template <class Cell, bool SHARDED = false> __device__ __forceinline__ int selec
     const float *step_tab = g->step_tab;
     int n_step_mant = g->n_step_mant;
     Ctx c = make_ctx_raw(g, 2 * iter);
-    c.hctl = nullptr;  // chains with control bytes are stepped by k_steps, never by this kernel: a constant for the compiler
     DA_GLOBAL int *collen = (DA_GLOBAL int *)g->collen;
     DA_GLOBAL unsigned long long *gtie_arr = (DA_GLOBAL unsigned long long *)g->gtie;
     DA_GLOBAL da_u2 *rowoff = (DA_GLOBAL da_u2 *)g->rowoff;
@@ -1703,853 +1656,6 @@ __global__ void __launch_bounds__(UPD_THREADS, DA_UPD_OCC) __attribute__((amdgpu
     update_body<Cell, UPD_WAVES>(&chains[(int)blockIdx.x < n_chains ? blockIdx.x : 0], (int)blockIdx.x < n_chains, (int)blockIdx.y, (int)gridDim.y);  // clamped: the descriptor read is unconditional
 }
 
-// ------------------------------------------------------------------------------------------------ k_steps
-// SEVERAL greedy steps of a chain per launch, by ONE 1024-thread workgroup (one workgroup per chain): selection, substitution
-// and -- for all but the fattest steps -- the update of the pair counts, step after step, without leaving the kernel.  OPT-IN
-// (DA4ML_HIP_FUSE=K): exact under every setting, but slower on MI355X than the (k_iter_select, k_iter_update) pair it was built to
-// replace in the thin part of a chain -- 29 against 27 us per step for one 256x256 chain, worse in batches and on small problems
-// (profiles/r04_step_engine.txt).  The reason is in the numbers of that file: a step that is not spread over the chip is bound by ONE
-// CU's instruction issue (~6 cycles per dependent instruction of a wavefront, four SIMDs), not by the round trips and kernel
-// boundaries this engine removes.  Kept as the measured answer to "many steps per launch in one workgroup per chain".
-//
-// What it does differently from the kernel pair:
-//   * the workgroup is the chain's only writer for the whole launch, so the bounds, dirty flags and stored tie words of the table
-//     groups live in LDS (loaded once per launch, every change written to both copies): no "load bounds" round trip per step, and a
-//     block that changes below its group's bound does not dirty the group (group_note);
-//   * the update starts with a FILTER, thread per partner row: the cells of the row in the m substituted columns are m independent
-//     loads from the column-major cell array (no list reference, no list walk), the two count blocks it may share with A and B are
-//     probed through the table's control bytes (one 16-byte load per bucket and thread instead of a 128-byte key bucket per 16-lane
-//     group), all in ONE round trip; whether a key of the pair (row, new row) reaches a count of 2 is decided in two saturating bit
-//     planes.  A row that owns no block with A or B and gains none with the new row -- nearly all of them, late in a chain -- is
-//     finished there; the others go to the step's HEAVY list with their candidate slots;
-//   * the heavy rows are updated by 16-lane groups (update_items: k_iter_update's scheme, but key check, payload lines and cells leave
-//     in one round trip because the candidate slots come with the item);
-//   * a step that substitutes more than fuse_max_m columns, has more than fuse_max_np partner rows or more than fuse_max_nh heavy
-//     rows is handed to k_iter_update exactly as k_iter_select would -- after the filter only its heavy rows -- and the launch ends.
-// Ordering inside the launch: every step ends with "all stores acknowledged (s_waitcnt vmcnt(0)) + workgroup barrier"; one CU, one
-// vector L1, hence no cache maintenance (values that are modified by atomics -- keys, row bitmaps -- are read past the L1).  Mutable
-// chain state (step number, row count, list arena fill) is carried in registers and written back when the launch ends.
-// Tombstone tags as with the kernel pair: the selection part of step i frees slots with tag 2i, its update part with tag 2i + 1.
-constexpr int TPP_CH = 4;  // cells of a partner row fetched together by its thread (substituted columns per chunk)
-
-// control bytes of one bucket (16 bytes in four words): high bit of every byte of the result set where the byte equals v (exact)
-__device__ __forceinline__ uint32_t ctl_eq(uint32_t w, uint32_t v) {
-    const uint32_t x = w ^ (v * 0x01010101u);
-    const uint32_t t = (x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu;
-    return ~(t | x | 0x7F7F7F7Fu);
-}
-__device__ __forceinline__ da_i4 ld_ctl(const Ctx &c, uint32_t bucket_base) { return *reinterpret_cast<const DA_GLOBAL da_i4 *>(c.hctl + bucket_base); }
-// Where in its first bucket can the key with fingerprint fp live?  0..15 = offset of the first slot whose control byte matches
-// (to be verified against the key array), CAND_SLOW = no match but no never-used slot either (the key may live in a following
-// bucket: full search), CAND_NONE = the key is not in the table.
-constexpr uint32_t CAND_SLOW = 16, CAND_NONE = 17;
-__device__ __forceinline__ uint32_t ctl_candidate(const da_i4 &ct, uint32_t fp) {
-    // lowest set bit of ctl_eq = first matching byte; selects instead of branches (the threads of a wave disagree all the time)
-    const uint32_t m0 = ctl_eq((uint32_t)ct.x, fp), m1 = ctl_eq((uint32_t)ct.y, fp), m2 = ctl_eq((uint32_t)ct.z, fp), m3 = ctl_eq((uint32_t)ct.w, fp);
-    const uint32_t e = ctl_eq((uint32_t)ct.x, 0u) | ctl_eq((uint32_t)ct.y, 0u) | ctl_eq((uint32_t)ct.z, 0u) | ctl_eq((uint32_t)ct.w, 0u);
-    uint32_t cand = e ? CAND_NONE : CAND_SLOW;
-    cand = m3 ? 12u + ((uint32_t)ctz32(m3 | 0x80000000u) >> 3) : cand;  // (the bit that is or-ed in keeps the count defined for m = 0; it is the highest one)
-    cand = m2 ? 8u + ((uint32_t)ctz32(m2 | 0x80000000u) >> 3) : cand;
-    cand = m1 ? 4u + ((uint32_t)ctz32(m1 | 0x80000000u) >> 3) : cand;
-    cand = m0 ? ((uint32_t)ctz32(m0 | 0x80000000u) >> 3) : cand;
-    return cand;
-}
-// item of a step's HEAVY list (partner rows that own a count block with A or B, or gain one with the new row):
-// row:24 | candidate of (A, row):5 | candidate of (B, row):5 | a count with the new row reached 2:1
-__device__ __forceinline__ unsigned long long item_pack(uint32_t r, uint32_t ca, uint32_t cb, uint32_t ins) {
-    return (unsigned long long)r | ((unsigned long long)ca << 24) | ((unsigned long long)cb << 29) | ((unsigned long long)ins << 34);
-}
-
-// re-evaluation of one count block by a 16-lane group (lane l holds the count words l, l + 16, ...): new counts = old - d[],
-// reduction of the best key inside the DPP row, lane 15 publishes (block_commit).  All lanes of the wave call it.
-template <int QCW>
-__device__ __forceinline__ void group_apply(const Ctx &c, int slot, unsigned long long key, const da_i4 &hd, const uint32_t (&w)[QCW], const uint32_t *d, int l, int qsh, int KW) {
-    const bool has = slot >= 0;
-    const int ov = hd.x;
-    const float dl = __int_as_float(hd.y);
-    unsigned long long best = 0;
-    int alive = 0;
-#pragma unroll
-    for (int u = 0; u < QCW; ++u) {
-        const int j = l + u * QG;
-        if (has && j < KW) {
-            const uint32_t o0 = w[u] & 0xFFFFu, o1 = w[u] >> 16;
-            const uint32_t n0 = o0 - d[2 * j], n1 = o1 - d[2 * j + 1];
-            if (n0 != o0 || n1 != o1) reinterpret_cast<DA_GLOBAL uint32_t *>(blk_ptr(c, slot) + 16)[j] = (n0 & 0xFFFFu) | (n1 << 16);
-            alive |= (n0 >= 2u) | (n1 >= 2u);
-            const uint32_t r0 = entry_rank(n0, ov, dl, c.method), r1 = entry_rank(n1, ov, dl, c.method);
-            const unsigned long long c0 = r0 ? (((unsigned long long)r0 << 8) | (unsigned)(2 * j)) : 0ull;
-            const unsigned long long c1 = r1 ? (((unsigned long long)r1 << 8) | (unsigned)(2 * j + 1)) : 0ull;
-            best = c0 > best ? c0 : best;
-            best = c1 > best ? c1 : best;
-        }
-    }
-    best = row_max_u64(best);  // all lanes take part (the DPP source lanes must be active); lane 15 of the row holds the result
-    const bool any_alive = (((uint32_t)(__ballot(alive != 0) >> qsh) & 0xFFFFu) != 0);
-    if (has && l == QG - 1) block_commit(c, slot, key, BlkHdr{ov, dl, (uint32_t)hd.z, (uint32_t)hd.w}, best, any_alive);
-}
-
-// update_items: ONE WAVEFRONT works through the heavy items first + q, first + stride + q, ... < n_items of a step of k_steps (q =
-// its four 16-lane groups), like update_partners -- but the candidate slots come with the item (found by the item's thread through
-// the control bytes), so the key check, the payload lines and the row's cells in the substituted columns (column-major array) all
-// leave in ONE round trip.  s_cnt = this wave's counters [QN][3][Kpad]; item(i) = the i-th item.
-template <class Cell, class ItemFn>
-__device__ __forceinline__ void update_items(const Ctx &c, ItemFn item, int first, int stride, int n_items, uint32_t A, uint32_t B, uint32_t Nw, int m,
-                                             const DA_GLOBAL Cell *cc, const uint32_t *s_cbase, const Cell *s_mA, const Cell *s_mB, uint32_t *s_cnt, const RowInfo &rnew,
-                                             unsigned int &found, unsigned int &inserts) {
-    constexpr int QCW = sizeof(Cell) == 4 ? 2 : 4;
-    const int nb = c.n_bits, Kpad = c.Kpad, KW = Kpad / 2;
-    const int lane = lane_id();
-    const int q = lane >> 4, l = lane & (QG - 1), qsh = q * QG;
-    const bool same = A == B;
-    uint32_t *dA = s_cnt + (size_t)q * 3 * Kpad, *dB = dA + Kpad, *cN = dB + Kpad;
-    for (int base = first; base < n_items; base += stride) {
-        const int idx = base + q;
-        const bool valid = idx < n_items;
-        const unsigned long long it = valid ? item(idx) : 0ull;
-        const uint32_t pr = (uint32_t)it & 0xFFFFFFu, ca = valid ? (uint32_t)(it >> 24) & 31u : CAND_NONE, cb = valid && !same ? (uint32_t)(it >> 29) & 31u : CAND_NONE;
-        const bool ins = valid && ((it >> 34) & 1ull);
-        const uint32_t lA = min(A, pr), hA = max(A, pr), lB = min(B, pr), hB = max(B, pr);
-        const unsigned long long keyA = pack_pair(lA, hA), keyB = pack_pair(lB, hB);
-        int sA = ca < 16u ? (int)(((hash_pair(lA, hA) & ~(BUCKET - 1)) & c.cmask) + ca) : ca == CAND_SLOW ? SLOT_SLOW : SLOT_NONE;
-        int sB = cb < 16u ? (int)(((hash_pair(lB, hB) & ~(BUCKET - 1)) & c.cmask) + cb) : cb == CAND_SLOW ? SLOT_SLOW : SLOT_NONE;
-        // ---- ONE round trip: the keys in the candidate slots, their payload lines (header + count words), the row's cells
-        const unsigned long long kA = sA >= 0 ? ld_key(&c.hkey[sA]) : 0ull, kB = sB >= 0 ? ld_key(&c.hkey[sB]) : 0ull;
-        const da_i4 z4 = da_i4{0, 0, 0, 0};
-        const da_i4 hdA = sA >= 0 ? *reinterpret_cast<const DA_GLOBAL da_i4 *>(blk_ptr(c, sA)) : z4;
-        const da_i4 hdB = sB >= 0 ? *reinterpret_cast<const DA_GLOBAL da_i4 *>(blk_ptr(c, sB)) : z4;
-        uint32_t wA[QCW], wB[QCW];
-#pragma unroll
-        for (int u = 0; u < QCW; ++u) {
-            const int j = l + u * QG;
-            wA[u] = (sA >= 0 && j < KW) ? reinterpret_cast<const DA_GLOBAL uint32_t *>(blk_ptr(c, sA) + 16)[j] : 0u;
-            wB[u] = (sB >= 0 && j < KW) ? reinterpret_cast<const DA_GLOBAL uint32_t *>(blk_ptr(c, sB) + 16)[j] : 0u;
-        }
-        const Cell x = (valid && l < m) ? cc[s_cbase[l < m ? l : 0] + pr] : (Cell)0;  // m <= 16: one substituted column per lane (s_cbase: start of the column in the column-major cells)
-        for (int k = l; k < 3 * Kpad; k += QG) dA[k] = 0;  // while the loads are in flight
-        load_fence();
-        if (sA >= 0 && kA != keyA) sA = SLOT_SLOW;  // a fingerprint collision: search the key (rare)
-        if (sB >= 0 && kB != keyB) sB = SLOT_SLOW;
-        lds_fence();  // counters are zero
-        if (x) {
-            const Cell ma = s_mA[l], mb = s_mB[l];
-            if (sA != SLOT_NONE) {
-                for_pairs_part<Cell>(ma, x, A < pr, nb, [&](int k) { atomicAdd(&dA[k], 1u); });
-                if (same) for_pairs_part<Cell>(mb, x, A < pr, nb, [&](int k) { atomicAdd(&dA[k], 1u); });
-            }
-            if (!same && sB != SLOT_NONE) for_pairs_part<Cell>(mb, x, B < pr, nb, [&](int k) { atomicAdd(&dB[k], 1u); });
-            if (ins) for_pairs_cross<Cell>(x, ma, nb, [&](int k) { atomicAdd(&cN[k], 1u); });
-        }
-        lds_fence();
-        group_apply<QCW>(c, sA, keyA, hdA, wA, dA, l, qsh, KW);
-        group_apply<QCW>(c, sB, keyB, hdB, wB, dB, l, qsh, KW);
-        found += (unsigned)__popcll(__ballot(l == 0 && sA >= 0)) + (unsigned)__popcll(__ballot(l == 0 && sB >= 0));
-        // ---- rare: keys to be searched, block creation -- the whole wave, one group at a time
-        const unsigned long long rare = __ballot(valid && (sA == SLOT_SLOW || sB == SLOT_SLOW || ins));
-        if (rare) {
-#pragma unroll 1
-            for (int qq = 0; qq < QN; ++qq) {
-                if (!((rare >> (qq * QG)) & 1ull)) continue;
-                const uint32_t rpr = (uint32_t)__builtin_amdgcn_readlane((int)pr, qq * QG);
-                const int rsA = __builtin_amdgcn_readlane(sA, qq * QG), rsB = __builtin_amdgcn_readlane(sB, qq * QG);
-                const int rins = __builtin_amdgcn_readlane((int)ins, qq * QG);
-                const uint32_t *rdA = s_cnt + (size_t)qq * 3 * Kpad, *rdB = rdA + Kpad, *rcN = rdB + Kpad;
-                if (rsA == SLOT_SLOW) {
-                    const uint32_t lo = min(A, rpr), hi = max(A, rpr);
-                    const int slot = table_find(c, pack_pair(lo, hi), hash_pair(lo, hi));
-                    if (slot >= 0) {
-                        table_update(c, slot, pack_pair(lo, hi), [&](int k, uint32_t old) { return old - rdA[k]; });
-                        ++found;
-                    }
-                }
-                if (rsB == SLOT_SLOW) {
-                    const uint32_t lo = min(B, rpr), hi = max(B, rpr);
-                    const int slot = table_find(c, pack_pair(lo, hi), hash_pair(lo, hi));
-                    if (slot >= 0) {
-                        table_update(c, slot, pack_pair(lo, hi), [&](int k, uint32_t old) { return old - rdB[k]; });
-                        ++found;
-                    }
-                }
-                if (rins) {
-                    table_insert(c, rpr, Nw, load_row(c.rows, rpr), rnew, [&](int k) { return rcN[k]; });
-                    ++inserts;
-                }
-            }
-        }
-        lds_fence();  // the next pass overwrites the counters
-    }
-}
-
-// statistics of a launch, summed in LDS and added to the chain descriptor once, when the launch ends
-enum { SS_RESCANS = 0, SS_PARTNERS, SS_MATCHES, SS_FOUND, SS_INSERTS, SS_CELLS, SS_SELBYTES, SS_TPPBYTES, SS_FUSED, SS_HANDOFFS, SS_N };
-
-template <class Cell> __device__ __forceinline__ void steps_body(ChainDev *g, unsigned int *n_done, int max_steps) {
-    using O = CellOps<Cell>;
-    using F = RowFmt<Cell>;
-    using Entry = typename F::Entry;
-    // ---- ONE scalar round trip: the descriptor fields every step needs, pinned before the first branch.  (What only a handed-over
-    // step needs -- the hand-off arrays -- is read from the descriptor there: fewer live scalar registers in the loop.)
-    int was_done = g->done, had_error = g->error, iter = g->iter, n_groups = g->n_groups, lcap = g->lcap, max_m = g->fuse_max_m, max_np = g->fuse_max_np, max_nh = g->fuse_max_nh;
-    int n_rows = g->n_rows, rcap = g->rcap, cbw = g->cb_words, adder_size = g->adder_size, carry_size = g->carry_size;
-    uint32_t offN = g->rl_used, rl_cap = g->rl_cap, n_live0 = g->n_live, live_peak0 = g->live_peak;
-    const uint32_t *step_mant = g->step_mant;
-    const float *step_tab = g->step_tab;
-    int n_step_mant = g->n_step_mant;
-    Ctx c = make_ctx_raw(g, 0);
-    DA_GLOBAL int *collen = (DA_GLOBAL int *)g->collen;
-    DA_GLOBAL unsigned long long *gtie_arr = (DA_GLOBAL unsigned long long *)g->gtie;
-    DA_GLOBAL da_u2 *rowoff = (DA_GLOBAL da_u2 *)g->rowoff;
-    DA_GLOBAL Entry *rl = (DA_GLOBAL Entry *)g->rlist;
-    DA_GLOBAL unsigned long long *collist = (DA_GLOBAL unsigned long long *)g->collist;
-    DA_GLOBAL uint32_t *colbits = (DA_GLOBAL uint32_t *)g->colbits;
-    DA_GLOBAL uint32_t *pl_ids = (DA_GLOBAL uint32_t *)g->pl_ids;
-    DA_GLOBAL unsigned long long *plist = (DA_GLOBAL unsigned long long *)g->plist;
-    DA_GLOBAL da_i4 *picks = (DA_GLOBAL da_i4 *)g->picks;
-    DA_GLOBAL Cell *ccell = (DA_GLOBAL Cell *)g->ccell;
-    pin_sgpr(was_done, had_error, iter, n_groups, lcap, max_m, max_np, max_nh, n_rows, rcap, cbw, adder_size, carry_size, offN, rl_cap, n_live0, live_peak0, step_mant, step_tab, n_step_mant);
-    pin_sgpr(c.n_out, c.n_bits, c.K, c.Kpad, c.method, c.gs_log2, c.pb_log2, c.cmask, c.windows, c.hkey, c.hrank, c.hblk, c.ub, c.gdirty, c.hctl, c.rows);
-    pin_sgpr(collen, gtie_arr, rowoff, rl, collist, colbits, pl_ids, plist, picks, ccell);
-    ctx_finish(c);
-    if (was_done) return;
-    const int n_out = c.n_out, Kpad = c.Kpad, nb = c.n_bits;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // dynamic LDS carve: group bounds | stored tie words | B's list | consumed digits of A and B | special-pair counters | per-column scratch |
-    // pair counters of the heavy rows | dirty flags
-    unsigned long long *l_ub = reinterpret_cast<unsigned long long *>(smem);         // [n_groups]
-    unsigned long long *l_gt = l_ub + n_groups;                                       // [n_groups]
-    Entry *s_bent = reinterpret_cast<Entry *>(l_gt + n_groups);                      // [n_out] entries of row B (updated in place)
-    Cell *s_mA = reinterpret_cast<Cell *>(s_bent + n_out);                           // [n_out] digits consumed from A per substituted column (= the new row's cell)
-    Cell *s_mB = s_mA + n_out;                                                       // [n_out] digits consumed from B
-    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_mB + n_out);                    // [6][Kpad]
-    int *s_len = reinterpret_cast<int *>(s_cnt + 6 * Kpad);                           // [n_out] pre-append list length of every substituted column
-    int *s_col = s_len + n_out;                                                       // [n_out] substituted columns
-    int *s_bpos = s_col + n_out;                                                      // [n_out] 1 + position of a column in B's list, 0 = absent (all zero between the steps)
-    int *s_clen = s_bpos + n_out;                                                     // [n_out] list length of every column (kept current across the steps)
-    uint32_t *s_cbase = reinterpret_cast<uint32_t *>(s_clen + n_out);                // [n_out] substituted column * rcap: start of the column in the column-major cells
-    constexpr int NW = SEL_THREADS / WAVE;
-    uint32_t *s_ucnt = s_cbase + n_out;                                              // [NW][QN][3][Kpad] pair counters of the heavy rows (update_items)
-    uint8_t *l_dirty = reinterpret_cast<uint8_t *>(s_ucnt + (size_t)NW * QN * 3 * Kpad);  // [n_groups]
-    __shared__ unsigned long long s_red_tie[NW], s_wfl[NW], s_floor;
-    __shared__ uint32_t s_red_rank[NW];
-    __shared__ int s_np, s_nh, s_part[NW];
-    __shared__ unsigned int s_matches;
-    __shared__ RowInfo s_new, s_ra, s_rb;
-    __shared__ da_u2 s_refA, s_refB;
-    constexpr int IDS_LDS = DA_IDS_LDS;
-    __shared__ uint32_t s_ids[IDS_LDS];  // the first partner row ids of the step (the rest, if any, goes through pl_ids in HBM)
-    __shared__ unsigned long long s_items[IDS_LDS];  // the first heavy items of the step (the rest through plist in HBM)
-    __shared__ Log2Table s_log2;
-    __shared__ unsigned long long s_stat[SS_N];
-
-    const int tid = threadIdx.x, lane = lane_id(), wid = wave_id();
-    const int gs = 1 << c.gs_log2;
-    int status = 0;  // 0 running | 1 chain finished (or stopped by an error) | 2 step handed to k_iter_update
-    if (had_error != E_OK) {  // a capacity error poisons the chain: stop it (the host retries with a larger arena)
-        if (tid == 0) {
-            g->done = 1;
-            g->n_partners = 0;
-            atomicAdd(n_done, 1u);
-        }
-        return;
-    }
-    // ---- once per launch: group bounds, stored tie words and dirty flags into LDS; the list lengths of all columns; the latency
-    // model's table.  One round trip.
-    for (int q = tid; q < n_groups; q += SEL_THREADS) {
-        const unsigned long long ubv = c.ub[q], gtv = gtie_arr[q];
-        const uint8_t dv = c.gdirty[q];
-        l_ub[q] = ubv;
-        l_gt[q] = gtv;
-        l_dirty[q] = dv;
-    }
-    for (int j = tid; j < n_out; j += SEL_THREADS) {
-        s_clen[j] = collen[j];
-        s_bpos[j] = 0;
-    }
-    if ((adder_size >= 0 || carry_size >= 0) && tid < (int)(sizeof(Log2Table) / 4)) reinterpret_cast<uint32_t *>(&s_log2)[tid] = reinterpret_cast<const uint32_t *>(&c_log2)[tid];
-    if (tid < SS_N) s_stat[tid] = 0ull;
-    if (tid == 0 && n_live0 > live_peak0) g->live_peak = n_live0;
-    c.l_ub = (DA_LDS unsigned long long *)l_ub;
-    c.l_dirty = (DA_LDS uint8_t *)l_dirty;
-    int m = 0, np = 0, nh = 0;
-    uint32_t A = 0, B = 0, Nw = 0;
-    const int GPW = (n_groups + NW - 1) / NW;  // groups per wave, <= 4 * WAVE
-
-    for (int step = 0; step < max_steps; ++step) {
-        SEL_TIMER_DECL
-        SEL_TIMER_MARK(0)
-        // every store of the previous step (and of the prologue) is acknowledged, then visible to the whole workgroup
-        DA_DRAIN_VMEM();
-        __syncthreads();
-        if (tid == 0) {  // counters of the step (everybody has finished reading the previous step's values; the next barrier precedes their first use)
-            s_np = 0;
-            s_nh = 0;
-            s_matches = 0;
-            s_floor = 0;
-        }
-        c.tomb = KEY_TOMB - (unsigned long long)((2 * iter) & 3);
-        // ---------------- (1) selection: as k_iter_select, with the bounds in LDS.  Wave w owns the groups [w GPW, (w + 1) GPW).
-        unsigned long long ubr[4];
-        int dr[4];  // 0 clean on entry, 1 dirty, 2 verified in this step, 3 absent
-        {
-            unsigned long long cl = 0;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int q = wid * GPW + lane + u * WAVE;
-                const bool in = lane + u * WAVE < GPW && q < n_groups;
-                const int qc = in ? q : 0;
-                ubr[u] = in ? l_ub[qc] : 0ull;
-                dr[u] = in ? (l_dirty[qc] ? 1 : 0) : 3;
-                if (dr[u] == 0) cl = max(cl, ubr[u]);
-            }
-            cl = wave_max_u64(cl);
-            if (lane == 0) s_wfl[wid] = cl;
-        }
-        __syncthreads();
-        SEL_TIMER_MARK(1)
-        uint32_t best_rank, cand_rank;
-        unsigned long long best_tie, cand_tie;
-        RowInfo cand_ra, cand_rb;
-        da_u2 cand_refA, cand_refB;
-        {
-            // the best clean bound: a floor of the answer (s_floor, zero at this point, collects the bounds the waves verify)
-            const unsigned long long floor0 = wave_max_u64(lane < NW ? s_wfl[lane] : 0ull);
-            uint32_t wrank = 0;
-            unsigned long long wtie = 0;
-            unsigned int rescans = 0;
-            // groups that were clean on entry and tie the floor: their stored tie word decides
-            unsigned long long clean_tie = 0;
-            bool clean_any = false;
-            if (floor0) {
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    if (dr[u] == 0 && ubr[u] == floor0) {
-                        const unsigned long long gtv = l_gt[wid * GPW + lane + u * WAVE];
-                        clean_tie = gtv > clean_tie ? gtv : clean_tie;
-                        clean_any = true;
-                    }
-            }
-            while (true) {
-                // the wave's highest dirty group is re-read while its (possibly stale) bound still reaches the rising floor
-                const unsigned long long flv = __hip_atomic_load(&s_floor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                const unsigned long long fl = flv > floor0 ? flv : floor0;
-                unsigned long long top = 0;
-                int top_u = 0;
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    if (dr[u] == 1 && ubr[u] > top) {
-                        top = ubr[u];
-                        top_u = u;
-                    }
-                const unsigned long long wtop = wave_max_u64(top);
-                if (wtop == 0 || wtop < fl) break;
-                const int owner = __ffsll((long long)__ballot(top == wtop)) - 1;
-                const int own_u = __builtin_amdgcn_readlane(top_u, owner);
-                const uint32_t grp = (uint32_t)(wid * GPW + owner + own_u * WAVE), base = grp << c.gs_log2;
-                uint32_t rk[8], grank = 0;
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int o = lane + u * WAVE;
-                    rk[u] = o < gs ? c.hrank[base + (uint32_t)o] : 0u;
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) grank = max(grank, rk[u]);
-                for (int o = lane + 8 * WAVE; o < gs; o += WAVE) grank = max(grank, c.hrank[base + (uint32_t)o]);
-                grank = wave_max_u32(grank);
-                // the slots that hold the group's top rank: key and best-key index of ALL of them are fetched before the first is looked at
-                unsigned long long kk[8], gt = 0;
-                uint32_t bi[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int o = lane + u * WAVE;
-                    kk[u] = 0;
-                    bi[u] = 0;
-                    if (grank && o < gs && rk[u] == grank) {
-                        kk[u] = ld_key(&c.hkey[base + (uint32_t)o]);
-                        bi[u] = load_best_idx(c, base + (uint32_t)o);
-                    }
-                }
-                load_fence();
-#pragma unroll
-                for (int u = 0; u < 8; ++u) pin_vgpr(kk[u], bi[u]);
-                if (grank) {
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const int o = lane + u * WAVE;
-                        if (o < gs && rk[u] == grank) {
-                            const unsigned long long tw = tie_word((uint32_t)kk[u], (uint32_t)(kk[u] >> 32), (int)bi[u]);
-                            gt = tw > gt ? tw : gt;
-                        }
-                    }
-                    for (int o = lane + 8 * WAVE; o < gs; o += WAVE)
-                        if (c.hrank[base + (uint32_t)o] == grank) {
-                            const unsigned long long k2 = ld_key(&c.hkey[base + (uint32_t)o]);
-                            const unsigned long long tw = tie_word((uint32_t)k2, (uint32_t)(k2 >> 32), (int)load_best_idx(c, base + (uint32_t)o));
-                            gt = tw > gt ? tw : gt;
-                        }
-                }
-                gt = wave_max_u64(gt);
-                const unsigned long long exact = grank ? bound_word(grank, gt) : 0ull;
-                if (lane == owner) {  // nobody writes the table during the selection: bound and tie are exact, the group is clean again
-#pragma unroll
-                    for (int u = 0; u < 4; ++u)
-                        if (u == own_u) {
-                            ubr[u] = exact;
-                            dr[u] = 2;
-                        }
-                    l_ub[grp] = exact;
-                    l_gt[grp] = gt;
-                    l_dirty[grp] = 0;
-                    c.ub[grp] = exact;
-                    gtie_arr[grp] = gt;
-                    c.gdirty[grp] = 0;
-                    if (exact) atomicMax(&s_floor, exact);
-                }
-                if (grank > wrank || (grank == wrank && gt > wtie)) {
-                    wrank = grank;
-                    wtie = gt;
-                }
-                ++rescans;
-                lds_fence();
-            }
-            if (floor0) {
-                const unsigned long long ct = wave_max_u64(clean_tie);
-                if (__any(clean_any)) {
-                    const uint32_t r0 = (uint32_t)(floor0 >> 32);
-                    if (r0 > wrank || (r0 == wrank && ct > wtie)) {
-                        wrank = r0;
-                        wtie = ct;
-                    }
-                }
-            }
-            // every wave fetches the list references and records of ITS candidate pair now (in flight across the reduction)
-            const uint32_t cA = wrank ? (uint32_t)((wtie >> 7) & 0xFFFFFFu) : 0u, cB = wrank ? (uint32_t)(wtie >> 31) : 0u;
-            cand_ra = load_row(c.rows, cA);
-            cand_rb = load_row(c.rows, cB);
-            cand_refA = rowoff[cA];
-            cand_refB = rowoff[cB];
-            cand_rank = wrank;
-            cand_tie = wtie;
-            if (lane == 0) {
-                s_red_rank[wid] = wrank;
-                s_red_tie[wid] = wtie;
-                if (rescans) atomicAdd(&s_stat[SS_RESCANS], (unsigned long long)rescans);
-            }
-            __syncthreads();
-            {
-                const uint32_t r = lane < NW ? s_red_rank[lane] : 0u;
-                const unsigned long long t = lane < NW ? s_red_tie[lane] : 0ull;
-                best_rank = wave_max_u32(r);
-                best_tie = wave_max_u64(r == best_rank ? t : 0ull);
-            }
-        }
-        SEL_TIMER_MARK(2)
-        Nw = (uint32_t)n_rows;
-        if (best_rank == 0 || (int)Nw >= rcap) {
-            if (tid == 0) {
-                if (best_rank != 0) g->error = E_ROW_CAPACITY;
-                g->done = 1;
-                atomicAdd(n_done, 1u);
-            }
-            status = 1;
-            break;
-        }
-        A = (uint32_t)((best_tie >> 7) & 0xFFFFFFu);
-        B = (uint32_t)(best_tie >> 31);
-        const int idx = (int)(best_tie & 0x7F);
-        int shift, sub;
-        key_decode(idx, nb, shift, sub);
-        const bool same = A == B;
-
-        // ---------------- (2) new row record + substitution
-        if (cand_rank == best_rank && cand_tie == best_tie && lane == 0) {  // exactly one wave holds the winner (tie words are unique)
-            s_ra = cand_ra;
-            s_rb = cand_rb;
-            s_refA = cand_refA;
-            s_refB = cand_refB;
-        }
-        __syncthreads();
-        const RowInfo ra = s_ra, rb = s_rb;
-        const da_u2 refA = s_refA, refB = s_refB;
-        const int lenA = (int)refA.y, lenB = (int)refB.y;
-        if (offN + (uint32_t)lenA > rl_cap) {  // the new row has at most lenA entries (cannot happen with the exact bound; guarded)
-            if (tid == 0) {
-                g->error = E_LIST_CAPACITY;
-                g->done = 1;
-                atomicAdd(n_done, 1u);
-            }
-            status = 1;
-            break;
-        }
-        DA_GLOBAL Entry *rlA = rl + refA.x, *rlB = rl + refB.x, *rlN = rl + offN;
-        Entry eA0 = rl[tid < lenA ? refA.x + (uint32_t)tid : 0u], eB0 = rl[tid < lenB ? refB.x + (uint32_t)tid : 0u];
-        load_fence();
-        RowInfo rn = RowInfo{0.0f, 0.0f, 0.0f, 0.0f};
-        int derr = 0;
-        if (tid == 0) {  // arithmetic only, while the entries are in flight
-            qint_add_pair(ra, rb, shift, sub, rn.lo, rn.hi, rn.step);
-            float dlat = adder_dlat(ra, rb, shift, sub, adder_size, carry_size, s_log2, StepLog2{n_step_mant, step_mant, step_tab}, derr);
-            rn.lat = (ra.lat < rb.lat ? rb.lat : ra.lat) + dlat;
-            s_new = rn;
-        }
-        for (int k = tid; k < 6 * Kpad; k += SEL_THREADS) s_cnt[k] = 0;
-        if (tid >= lenA) eA0 = F::none();
-        if (same || tid >= lenB) eB0 = F::none();
-        pin_vgpr(eA0, eB0);
-        if (!same) {  // B's list into LDS, addressable by column
-            if (tid < lenB) {
-                s_bent[tid] = eB0;
-                s_bpos[F::col(eB0)] = tid + 1;
-            }
-            for (int t = tid + SEL_THREADS; t < lenB; t += SEL_THREADS) {
-                const Entry e = rlB[t];
-                s_bent[t] = e;
-                s_bpos[F::col(e)] = t + 1;
-            }
-        }
-        if (tid == 0) {
-            if (derr) g->error = E_FLOAT_DOMAIN;
-            store_row((DA_GLOBAL RowInfo *)c.rows, Nw, rn);
-            picks[iter] = da_i4{(int)A, (int)B, sub, shift};
-        }
-        __syncthreads();
-        SEL_TIMER_MARK(3)
-        uint32_t *cAA = s_cnt, *cAB = s_cnt + Kpad, *cBB = s_cnt + 2 * Kpad, *cAN = s_cnt + 3 * Kpad, *cBN = s_cnt + 4 * Kpad, *cNN = s_cnt + 5 * Kpad;
-        unsigned int my_matches = 0;
-        m = 0;  // substituted columns so far (block-uniform)
-        // pass 1: one thread per entry of A (ascending columns); the matched columns are compacted in column order = the new row's list
-        for (int t0 = 0; t0 < lenA; t0 += SEL_THREADS) {
-            const int t = t0 + tid;
-            Cell a = 0, b = 0, ma = 0, mb = 0, na = 0, nbv = 0;
-            uint32_t colA = 0;
-            int pos = 0;
-            if (t < lenA) {
-                const Entry e = t0 == 0 ? eA0 : rlA[t];
-                colA = F::col(e);
-                a = F::cell(e);
-                if (same)
-                    b = a;
-                else {
-                    pos = s_bpos[colA];
-                    b = pos ? F::cell(s_bent[pos - 1]) : (Cell)0;
-                }
-                if (a && b) substitute_column<Cell>(a, b, same, shift, sub, ma, mb);
-                na = same ? (Cell)(a & ~ma & ~mb) : (Cell)(a & ~ma);
-                nbv = b & ~mb;
-            }
-            const bool hit = ma != 0;
-            const unsigned long long bal = __ballot(hit);
-            if (lane == 0) s_part[wid] = __popcll(bal);
-            __syncthreads();
-            int wbase = 0, chunk = 0;
-#pragma unroll
-            for (int w = 0; w < NW; ++w) {
-                const int v = s_part[w];
-                wbase += w < wid ? v : 0;
-                chunk += v;
-            }
-            if (hit) {
-                const int at = m + wbase + __popcll(bal & ((1ull << lane) - 1));
-                const uint32_t cbase = colA * (uint32_t)rcap;
-                rlA[t] = F::pack(colA, na);
-                if (!same) s_bent[pos - 1] = F::pack(colA, nbv);
-                rlN[at] = F::pack(colA, ma);
-                s_mA[at] = ma;
-                s_mB[at] = mb;
-                s_cbase[at] = cbase;
-                {  // row bitmaps of this column: the new row enters, a row whose cell just lost its last digit leaves
-                    DA_GLOBAL uint32_t *cb = colbits + colA * (uint32_t)cbw;
-                    atomicOr(gen(&cb[Nw >> 5]), 1u << (Nw & 31));
-                    if (na == 0) atomicAnd(gen(&cb[A >> 5]), ~(1u << (A & 31)));
-                    if (!same && nbv == 0) atomicAnd(gen(&cb[B >> 5]), ~(1u << (B & 31)));
-                }
-                {  // column-major copy of the three cells
-                    DA_GLOBAL Cell *cc = ccell + cbase;
-                    cc[A] = na;
-                    if (!same) cc[B] = nbv;
-                    cc[Nw] = ma;
-                }
-                s_len[at] = s_clen[colA];  // the pre-append length
-                s_col[at] = (int)colA;
-                my_matches += popc32(O::plus(ma) | O::minus(ma));
-            }
-            // ---------------- (3) exact recount of the pairs among {A, B, new}; the self pairs of B are counted in pass 2
-            if (na) for_pairs_self<Cell>(na, nb, [&](int k) { atomicAdd(&cAA[k], 1u); });
-            if (!same) {
-                if (na && nbv) for_pairs_cross<Cell>(na, nbv, nb, [&](int k) { atomicAdd(&cAB[k], 1u); });
-                if (nbv && ma) for_pairs_cross<Cell>(nbv, ma, nb, [&](int k) { atomicAdd(&cBN[k], 1u); });
-            }
-            if (na && ma) for_pairs_cross<Cell>(na, ma, nb, [&](int k) { atomicAdd(&cAN[k], 1u); });
-            if (ma) for_pairs_self<Cell>(ma, nb, [&](int k) { atomicAdd(&cNN[k], 1u); });
-            m += chunk;
-            __syncthreads();  // s_part is reused by the next chunk; s_bent updates visible to pass 2
-        }
-        if (my_matches) atomicAdd(&s_matches, my_matches);
-        // pass 2: B's list back to memory, self pairs of what is left of B; the column -> position map returns to all zero
-        if (!same)
-            for (int t = tid; t < lenB; t += SEL_THREADS) {
-                const Entry e = s_bent[t];
-                rlB[t] = e;
-                s_bpos[F::col(e)] = 0;
-                const Cell nbv = F::cell(e);
-                if (nbv) for_pairs_self<Cell>(nbv, nb, [&](int k) { atomicAdd(&cBB[k], 1u); });
-            }
-        // the new row joins the lists of its columns
-        {
-            const unsigned long long refN = ref_pack(Nw, (uint32_t)m, offN);
-            for (int k = tid; k < m; k += SEL_THREADS) {
-                const int j = s_col[k], len = s_len[k];
-                if (len < lcap) {
-                    collist[(size_t)j * lcap + len] = refN;
-                    collen[j] = len + 1;
-                    s_clen[j] = len + 1;
-                } else
-                    g->error = E_LIST_CAPACITY;
-            }
-        }
-        __syncthreads();
-        SEL_TIMER_MARK(4)
-        // ---------------- (4) partner rows (OR of the substituted columns' row bitmaps) by the first NW-6 waves; the last six waves
-        // store the six special pairs meanwhile
-        constexpr int CLAIM_WAVES = NW - 6, CLAIM_THREADS = CLAIM_WAVES * WAVE;
-        if (wid < CLAIM_WAVES) {
-            const DA_GLOBAL uint32_t *cb = colbits;
-            const int nwords = (int)((Nw + 31) >> 5);
-            for (int wb = wid * WAVE; wb < nwords; wb += CLAIM_THREADS) {  // wave-uniform trip count
-                const int w = wb + lane;
-                uint32_t bits = 0;
-                if (w < nwords) {
-                    for (int k = 0; k < m; ++k) bits |= ld_l2_u32(&cb[(uint32_t)s_col[k] * (uint32_t)cbw + (uint32_t)w]);  // the bitmaps are modified by atomics: read past the L1
-                    if ((int)(A >> 5) == w) bits &= ~(1u << (A & 31));
-                    if ((int)(B >> 5) == w) bits &= ~(1u << (B & 31));
-                    if ((int)(Nw >> 5) == w) bits &= ~(1u << (Nw & 31));
-                }
-                const int cnt = popc32(bits), inc = (int)wave_scan_add_u32((uint32_t)cnt);
-                const int wave_total = __builtin_amdgcn_readlane(inc, WAVE - 1);
-                if (wave_total == 0) continue;
-                int base = 0;
-                if (lane == 0) base = atomicAdd(&s_np, wave_total);
-                int at = __builtin_amdgcn_readfirstlane(base) + inc - cnt;
-                while (bits) {
-                    const uint32_t id = (uint32_t)(w << 5) + (uint32_t)ctz32(bits);
-                    if (at < IDS_LDS)
-                        s_ids[at] = id;
-                    else
-                        pl_ids[at] = id;
-                    ++at;
-                    bits &= bits - 1;
-                }
-            }
-        } else {
-            const int sp = wid - CLAIM_WAVES;
-            uint32_t lo = A, hi = A;
-            const uint32_t *cnt = s_cnt + sp * Kpad;
-            bool active = true, existed = false;
-            switch (sp) {
-            case 0: lo = A, hi = A, existed = true; break;
-            case 1: lo = A, hi = B, existed = true, active = !same; break;
-            case 2: lo = B, hi = B, existed = true, active = !same; break;
-            case 3: lo = A, hi = Nw; break;
-            case 4: lo = B, hi = Nw, active = !same; break;
-            default: lo = Nw, hi = Nw; break;
-            }
-            if (active) {
-                unsigned long long key = pack_pair(lo, hi);
-                int slot = existed ? table_find(c, key, hash_pair(lo, hi)) : -1;
-                if (slot >= 0)
-                    table_update(c, slot, key, [&](int k, uint32_t) { return cnt[k]; });
-                else if (wave_any_ge2(cnt, c.K)) {
-                    const RowInfo sn = s_new;
-                    const RowInfo xa = pick_row(lo == Nw, sn, pick_row(lo == A, ra, rb)), xb = pick_row(hi == Nw, sn, pick_row(hi == A, ra, rb));
-                    table_insert(c, lo, hi, xa, xb, [&](int k) { return cnt[k]; });
-                }
-            }
-        }
-        DA_DRAIN_VMEM();  // partner ids beyond the LDS staging area, and the special blocks: acknowledged before anybody looks at them
-        __syncthreads();
-        SEL_TIMER_MARK(5)
-        np = s_np;
-        const unsigned long long eb = sizeof(Entry), cbts = sizeof(Cell);
-        if (tid == 0) {
-            rowoff[Nw] = da_u2{offN, (uint32_t)m};
-            atomicAdd(&s_stat[SS_MATCHES], (unsigned long long)s_matches);
-            atomicAdd(&s_stat[SS_PARTNERS], (unsigned long long)np);
-            atomicAdd(&s_stat[SS_CELLS], (unsigned long long)np * (unsigned)m);
-            // algorithmic bytes of this selection step: records and list references of A and B, both row lists
-            // read and written back, the row bitmaps of the m substituted columns, per partner its id, the new row (list, column-list
-            // and bitmap updates, column-major cells), six special blocks.  The bounds are in LDS: priced once per launch, below.
-            const unsigned long long nwords = (Nw + 31) >> 5;
-            atomicAdd(&s_stat[SS_SELBYTES], 48ull + 2ull * eb * (unsigned)(lenA + (same ? 0 : lenB)) + 4ull * (unsigned)m * nwords + 4ull * (unsigned)np +
-                                                (unsigned)m * (eb + 8ull + 12ull + 3ull * cbts) + 6ull * (16ull + 4ull * (unsigned)c.K) + 32ull);
-        }
-        const bool too_fat = m > max_m || np > max_np;
-        // ---------------- (5) the update.  Phase A, THREAD PER PARTNER ROW: control bytes of the two buckets the row's blocks with A
-        // and B would live in, and its cells in the substituted columns -- one round trip; a row that owns no such block and gains
-        // none with the new row (nearly all of them, late in a chain) is finished.  The others go to the heavy list.
-        Ctx cu = c;
-        cu.tomb = KEY_TOMB - (unsigned long long)((2 * iter + 1) & 3);
-        const DA_GLOBAL Cell *cc = ccell;
-        if (!too_fat) {
-            for (int t0 = wid * WAVE; t0 < np; t0 += SEL_THREADS) {  // wave-uniform trip count
-                const int t = t0 + lane;
-                const bool valid = t < np;
-                const uint32_t r = !valid ? 0u : t < IDS_LDS ? s_ids[t] : pl_ids[t];
-                const bool aLo = A < r, bLo = B < r;
-                const uint32_t lA = aLo ? A : r, hA = aLo ? r : A, lB = bLo ? B : r, hB = bLo ? r : B;
-                const da_i4 ctA = ld_ctl(cu, (hash_pair(lA, hA) & ~(BUCKET - 1)) & cu.cmask);
-                const da_i4 ctB = ld_ctl(cu, (hash_pair(lB, hB) & ~(BUCKET - 1)) & cu.cmask);
-                Cell x[TPP_CH];
-#pragma unroll
-                for (int u = 0; u < TPP_CH; ++u) x[u] = cc[s_cbase[u < m ? u : 0] + r];
-                load_fence();
-                const uint32_t ca = ctl_candidate(ctA, ctl_fp(lA, hA)), cb = same ? CAND_NONE : ctl_candidate(ctB, ctl_fp(lB, hB));
-                // does a key of the pair (row, new row) reach a count of 2?  two saturating bit planes: seen once / seen twice
-                unsigned long long once = 0, twice = 0;
-                for (int k0 = 0; k0 < m; k0 += TPP_CH) {
-                    if (k0) {
-#pragma unroll
-                        for (int u = 0; u < TPP_CH; ++u) x[u] = cc[s_cbase[k0 + u < m ? k0 + u : 0] + r];
-                    }
-#pragma unroll
-                    for (int u = 0; u < TPP_CH; ++u) {
-                        const Cell xv = k0 + u < m ? x[u] : (Cell)0;
-                        if (!xv) continue;
-                        for_pairs_cross<Cell>(xv, s_mA[k0 + u], nb, [&](int k) {
-                            const unsigned long long bit = 1ull << (k & 63);  // keys 64 apart share a bit: a false alarm costs a heavy item that creates nothing
-                            twice |= once & bit;
-                            once |= bit;
-                        });
-                    }
-                }
-                const bool ins = twice != 0ull;
-                const bool heavy = valid && (ca != CAND_NONE || cb != CAND_NONE || ins);
-                const unsigned long long hb = __ballot(heavy);
-                if (hb) {
-                    int hbase = 0;
-                    if (lane == 0) hbase = atomicAdd(&s_nh, __popcll(hb));
-                    hbase = __builtin_amdgcn_readfirstlane(hbase);
-                    if (heavy) {
-                        const int at = hbase + __popcll(hb & ((1ull << lane) - 1));
-                        const unsigned long long it = item_pack(r, ca, cb, ins ? 1u : 0u);
-                        if (at < IDS_LDS)
-                            s_items[at] = it;
-                        else
-                            plist[at] = it;  // (the partner list of k_iter_update: rewritten below if the step is handed over)
-                    }
-                }
-            }
-            DA_DRAIN_VMEM();
-            __syncthreads();
-            nh = s_nh;
-        }
-        SEL_TIMER_MARK(6)
-        if (too_fat || nh > max_nh) {
-            // ---- the step's update is handed to k_iter_update, as k_iter_select would: consumed digits, substituted columns, column
-            // map, partner list with list references -- of the heavy rows only if the filter ran (the others have nothing to update)
-            DA_GLOBAL Cell *mA = (DA_GLOBAL Cell *)g->mA, *mB = (DA_GLOBAL Cell *)g->mB;
-            DA_GLOBAL int *mcol = (DA_GLOBAL int *)g->mcol;
-            DA_GLOBAL uint16_t *cmap = (DA_GLOBAL uint16_t *)g->cmap;
-            for (int j = tid; j < n_out; j += SEL_THREADS) cmap[j] = 0;
-            const int nl = too_fat ? np : nh;
-            unsigned long long ref1 = 0, ref2 = 0;  // (a heavy item and its list reference share the slot in plist: read all, barrier, write)
-            const int t1 = tid, t2 = tid + SEL_THREADS;
-            auto row_of = [&](int t) -> uint32_t {
-                if (too_fat) return t < IDS_LDS ? s_ids[t] : pl_ids[t];
-                return (uint32_t)(t < IDS_LDS ? s_items[t] : plist[t]) & 0xFFFFFFu;
-            };
-            if (nl <= 2 * SEL_THREADS) {
-                const uint32_t r1 = t1 < nl ? row_of(t1) : 0u, r2 = t2 < nl ? row_of(t2) : 0u;
-                const da_u2 ro1 = rowoff[r1], ro2 = rowoff[r2];
-                load_fence();
-                ref1 = ref_pack(r1, ro1.y, ro1.x);
-                ref2 = ref_pack(r2, ro2.y, ro2.x);
-            }
-            DA_DRAIN_VMEM();
-            __syncthreads();  // cmap zeroed (acknowledged: other threads write its entries next); every heavy item read
-            for (int k = tid; k < m; k += SEL_THREADS) {
-                mcol[k] = s_col[k];
-                mA[k] = s_mA[k];
-                mB[k] = s_mB[k];
-                cmap[s_col[k]] = (uint16_t)(k + 1);
-            }
-            if (nl <= 2 * SEL_THREADS) {
-                if (t1 < nl) plist[t1] = ref1;
-                if (t2 < nl) plist[t2] = ref2;
-            } else {  // (only an unfiltered list can be this long: its ids are in s_ids / pl_ids, not in plist)
-                for (int t = tid; t < nl; t += SEL_THREADS) {
-                    const uint32_t r1 = row_of(t);
-                    const da_u2 ro1 = rowoff[r1];
-                    plist[t] = ref_pack(r1, ro1.y, ro1.x);
-                }
-            }
-            if (tid == 0) {
-                atomicAdd(&s_stat[SS_SELBYTES], 2ull * (unsigned)n_out + (unsigned)m * (4ull + 2ull * cbts) + 16ull * (unsigned)nl);
-                if (!too_fat) atomicAdd(&s_stat[SS_TPPBYTES], (unsigned long long)np * (32ull + cbts * (unsigned)m) + 16ull * (unsigned)nh);
-            }
-            np = nl;
-            status = 2;
-            offN += (uint32_t)m;
-            n_rows += 1;
-            iter += 1;
-            break;
-        }
-        // Phase B: the heavy rows, a 16-lane group each (update_items)
-        if (nh) {
-            const RowInfo rnew = s_new;
-            unsigned int found = 0, inserts = 0;
-            update_items<Cell>(cu, [&](int i) { return i < IDS_LDS ? s_items[i] : plist[i]; }, wid * QN, NW * QN, nh, A, B, Nw, m, cc, s_cbase, s_mA, s_mB,
-                               s_ucnt + (size_t)wid * QN * 3 * Kpad, rnew, found, inserts);
-            if (lane == 0 && (found | inserts)) {
-                if (found) atomicAdd(&s_stat[SS_FOUND], (unsigned long long)found);
-                if (inserts) atomicAdd(&s_stat[SS_INSERTS], (unsigned long long)inserts);
-            }
-        }
-        if (tid == 0) {
-            atomicAdd(&s_stat[SS_FUSED], 1ull);
-            // algorithmic bytes of the in-kernel update: per partner row two control-byte buckets and m cells; per heavy row its item
-            atomicAdd(&s_stat[SS_TPPBYTES], (unsigned long long)np * (32ull + cbts * (unsigned)m) + 16ull * (unsigned)nh);
-        }
-#ifdef DA_PHASE_TIMERS
-        __syncthreads();  // the update of all heavy rows has been issued
-        SEL_TIMER_MARK(7)
-        if (tid == 0) {
-            SEL_TIMER_FLUSH
-        }
-#endif
-        offN += (uint32_t)m;
-        n_rows += 1;
-        iter += 1;
-        np = 0;
-        nh = 0;
-    }
-    // ---- the launch ends: mutable chain state and statistics back into the descriptor (read by the next launch, by k_iter_update
-    // if a step was handed over, and by the host at the end of the chain)
-    __syncthreads();
-    if (tid == 0) {
-        g->rl_used = offN;
-        g->n_rows = n_rows;
-        g->iter = iter;
-        g->m = m;
-        g->n_partners = status == 2 ? np : 0;
-        g->A = A;
-        g->B = B;
-        g->Nw = Nw;
-        if (status == 2) atomicAdd(&s_stat[SS_HANDOFFS], 1ull);
-        atomicAdd(&g->st_rescans, s_stat[SS_RESCANS]);
-        atomicAdd(&g->st_partners, s_stat[SS_PARTNERS]);
-        atomicAdd(&g->st_matches, s_stat[SS_MATCHES]);
-        atomicAdd(&g->st_cells, s_stat[SS_CELLS]);
-        atomicAdd(&g->st_sel_bytes, s_stat[SS_SELBYTES] + 17ull * (unsigned)n_groups + 4ull * (unsigned)n_out);  // + the bounds, dirty flags, tie words and column lengths, once per launch
-        atomicAdd(&g->st_tpp_bytes, s_stat[SS_TPPBYTES] + (s_stat[SS_FOUND] + s_stat[SS_INSERTS]) * (16ull + 2ull * (unsigned)c.K));
-        atomicAdd(&g->st_fused, s_stat[SS_FUSED]);
-        atomicAdd(&g->st_handoffs, s_stat[SS_HANDOFFS]);
-        atomicAdd(&g->st_found, s_stat[SS_FOUND]);  // of the steps updated here (k_iter_update counts the blocks of the steps handed to it)
-        atomicAdd(&g->st_inserts, s_stat[SS_INSERTS]);
-    }
-}
-template <class Cell> __global__ void __launch_bounds__(SEL_THREADS) k_steps(ChainDev *chains, unsigned int *n_done, int max_steps) {
-    steps_body<Cell>(&chains[blockIdx.x], n_done, max_steps);
-}
-
 // ================================================================================= column-sharded chains (cmvm_shard.h)
 // The chain holds the digits of a slice of the columns and a replica of the pair table; counts are sums over columns,
 // exchanged between the ranks as int32 slabs (all-reduce(sum) between the kernels below, driven by cmvm_shard.cc).
@@ -2975,14 +2081,6 @@ struct HipBackend::Impl {
     hipStream_t poll_stream = nullptr;
     GpuTimings timings;
     double table_scale = 1.0;  // grows on E_TABLE_CAPACITY retries
-    // greedy loop of the narrow chains.  fuse_steps = 0 (default): the (k_iter_select, k_iter_update) pair per step, as for wide
-    // chains.  fuse_steps = K > 0 (DA4ML_HIP_FUSE, opt-in): k_steps runs up to K greedy steps per launch in one workgroup per chain
-    // and applies a step's update itself unless the step substitutes more than fuse_max_m columns, has more than fuse_max_np partner
-    // rows or more than fuse_max_nh of them own / gain a count block (then k_iter_update, launched after every k_steps, does it).
-    // Exact (GPU parity suite under all settings), but SLOWER on MI355X -- 29 against 27 us per step for one 256x256 chain, worse in
-    // batches and on small problems (profiles/r04_step_engine.txt): one CU's instruction issue is the bound of a step that is not
-    // spread over the chip, DESIGN.md section 9.  Kept as the measured answer, not as the product path.
-    int fuse_steps = 0, fuse_max_m = 8, fuse_max_np = 2048, fuse_max_nh = 96;
 };
 
 HipBackend::HipBackend(int device) : impl_(new Impl) {
@@ -2995,10 +2093,6 @@ HipBackend::HipBackend(int device) : impl_(new Impl) {
     if (const char *e = std::getenv("DA4ML_HIP_ROW_SCALE")) row_scale_ = std::max(1e-4, std::atof(e));
     if (const char *e = std::getenv("DA4ML_HIP_UPD_BLOCKS")) impl_->upd_total_blocks = std::max(2, std::atoi(e));
     if (const char *e = std::getenv("DA4ML_HIP_LANES")) impl_->n_lanes = std::max(1, std::min((int)Impl::MAX_LANES, std::atoi(e)));
-    if (const char *e = std::getenv("DA4ML_HIP_FUSE")) impl_->fuse_steps = std::max(0, std::min(4096, std::atoi(e)));
-    if (const char *e = std::getenv("DA4ML_HIP_FUSE_M")) impl_->fuse_max_m = std::max(0, std::atoi(e));
-    if (const char *e = std::getenv("DA4ML_HIP_FUSE_NP")) impl_->fuse_max_np = std::max(0, std::atoi(e));
-    if (const char *e = std::getenv("DA4ML_HIP_FUSE_NH")) impl_->fuse_max_nh = std::max(0, std::atoi(e));
     HIP_CHECK(hipMalloc(&impl_->d_done, sizeof(unsigned int)));
     HIP_CHECK(hipHostMalloc(&impl_->h_done, 2 * sizeof(unsigned int), hipHostMallocDefault));
     HIP_CHECK(hipStreamCreateWithFlags(&impl_->poll_stream, hipStreamNonBlocking));
@@ -3022,7 +2116,6 @@ namespace {
 
 struct Geometry {
     bool wide;  // 64-bit cells and 16-byte list entries (more than 12 digits or more than 256 columns)
-    bool fuse;  // stepped by k_steps (several greedy steps per launch, updates inside the kernel): gets the column-major cells
     int n_mant = 0;  // distinct non-power-of-two step mantissas of the inputs (StepLog2): rows of the -log2f table
     int n_bits, K, Kpad, rcap, lcap, gs_log2, n_groups, pk_cap, pb_log2;
     uint32_t C, rl_cap;
@@ -3042,9 +2135,6 @@ size_t carve_chain(unsigned char *base, const ChainJob &job, const Geometry &g, 
     d.hkey = c.take<unsigned long long>(g.C);
     d.hrank = c.take<uint32_t>(g.C);
     d.hblk = c.take<unsigned char>((size_t)g.C << g.pb_log2);
-    d.hctl = g.fuse ? c.take<uint8_t>(g.C) : nullptr;
-    d.ccell = g.fuse ? c.take<unsigned char>(n_out * (size_t)g.rcap * cell) : nullptr;
-    d.cell_bytes = (int)cell;
     d.ub = c.take<unsigned long long>(g.n_groups);
     d.gtie = c.take<unsigned long long>(g.n_groups);
     d.gdirty = c.take<uint8_t>(g.n_groups);
@@ -3171,10 +2261,9 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
         g.n_bits = d.prep_nbits;
         if (g.n_bits > 30) throw std::runtime_error("kernel needs more than 30 CSD digits per entry (the reference overflows int32 there); unsupported");
         g.wide = g.n_bits > 12 || jobs[i].n_out > 256;  // the narrow list entry is col:8 | minus:12 | plus:12
-        g.fuse = !g.wide && im.fuse_steps > 0;          // k_steps (instantiated for the narrow layout)
         g.n_mant = (int)step_tabs[i].mant.size();
         g.K = key_count(g.n_bits);
-        g.Kpad = (g.K + 7) & ~7;  // count words (two u16 each) in whole 16-byte quads
+        g.Kpad = (g.K + 3) & ~3;
         g.pb_log2 = 5;  // payload line of a pair block: 16-byte header + Kpad u16 counts, padded to a power of two
         while ((1 << g.pb_log2) < 16 + 2 * g.Kpad) ++g.pb_log2;
         long long D0 = d.prep_digits;
@@ -3241,9 +2330,6 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
         d.iter = 0;
         d.done = (jobs[i].method == M_DUMMY || jobs[i].method < 0) ? 1 : 0;
         d.cb_words = (g.rcap + 31) / 32;
-        d.fuse_max_m = std::min(im.fuse_max_m, QG);  // update_items: one substituted column per lane of a 16-lane group
-        d.fuse_max_np = std::min(im.fuse_max_np, 2 * SEL_THREADS);  // a filtered hand-off rewrites the heavy list in place: two items per thread
-        d.fuse_max_nh = im.fuse_max_nh;
     }
     for (int i = 0; i < n; ++i) {
         desc[i].n_step_mant = (int)step_tabs[i].mant.size();
@@ -3279,7 +2365,7 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
     int active = 0;
     for (int i = 0; i < n; ++i) active += desc[i].done ? 0 : 1;
 
-    size_t sel_lds[2] = {0, 0}, upd_lds[2] = {0, 0}, pair_lds[2] = {0, 0}, steps_lds = 0;
+    size_t sel_lds[2] = {0, 0}, upd_lds[2] = {0, 0}, pair_lds[2] = {0, 0};
     int upd_blocks[2] = {1, 1};
     long long max_pairs[2] = {0, 0};
     for (int i = 0; i < n; ++i) {
@@ -3290,8 +2376,6 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
         size_t s = no * entb + 6 * (size_t)geo[i].Kpad * 4 + (5 * no + 1) * 4 + claim_bytes;
         s = align_up(s, 16);
         sel_lds[w] = std::max(sel_lds[w], s);
-        if (geo[i].fuse)  // k_steps: group bounds + tie words + dirty flags, B's list, consumed digits of A and B, special counters, five per-column arrays
-            steps_lds = std::max(steps_lds, align_up(17 * (size_t)geo[i].n_groups + no * (entb + 2 * cellb + 20) + (6 + (size_t)(SEL_THREADS / WAVE) * QN * 3) * (size_t)geo[i].Kpad * 4 + 16, 16));
         upd_lds[w] = std::max(upd_lds[w], align_up(2 * no * cellb + no * 6, 16) + align_up((size_t)UPD_WAVES * QN * 3 * (size_t)geo[i].Kpad * 4, 16));  // UpdLds: hand-off tables | counters
         pair_lds[w] = std::max(pair_lds[w], (size_t)4 * geo[i].Kpad * 4);
         max_pairs[w] = std::max(max_pairs[w], (long long)jobs[i].n_in * (jobs[i].n_in + 1) / 2);
@@ -3322,11 +2406,6 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
         HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_iter_select<uint32_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sel_lds[0]));
     if (ranges[1].count)
         HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_iter_select<uint64_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sel_lds[1]));
-    const bool fuse = ranges[0].count > 0 && im.fuse_steps > 0;  // all narrow chains of a batch or none (Geometry::fuse)
-    if (fuse) {
-        if (steps_lds > 150 * 1024) throw std::runtime_error("k_steps needs more than 150 KiB of LDS (internal error: narrow chains have at most 256 columns)");
-        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_steps<uint32_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)steps_lds));
-    }
 
     HIP_CHECK(hipStreamSynchronize(st));
     lap("arena + init kernels");
@@ -3356,9 +2435,7 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
     auto launch_pair = [&](const Group &gr, hipEvent_t *se) {
         ChainDev *base = d_desc + gr.first;
         if (se) HIP_CHECK(hipEventRecord(se[0], gr.stream));
-        if (gr.w == 0 && fuse)
-            hipLaunchKernelGGL(k_steps<uint32_t>, dim3(gr.count), dim3(SEL_THREADS), steps_lds, gr.stream, base, im.d_done, im.fuse_steps);
-        else if (gr.w == 0)
+        if (gr.w == 0)
             hipLaunchKernelGGL(k_iter_select<uint32_t>, dim3(gr.count), dim3(SEL_THREADS), sel_lds[0], gr.stream, base, im.d_done);
         else
             hipLaunchKernelGGL(k_iter_select<uint64_t>, dim3(gr.count), dim3(SEL_THREADS), sel_lds[1], gr.stream, base, im.d_done);
@@ -3603,16 +2680,12 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
         im.timings.rescans += (long long)d.st_rescans;
         im.timings.select_bytes += (double)d.st_sel_bytes + (double)d.st_rescans * ((double)(4u << d.gs_log2) + 24.0);  // + every re-read group: its ranks, ~2 tied slots' key and index
         im.timings.partners += (long long)d.st_partners;
-        im.timings.fused_steps += (double)d.st_fused;
-        im.timings.handoff_steps += (double)d.st_handoffs;
-        im.timings.tpp_bytes += (double)d.st_tpp_bytes;
         im.timings.table_bytes += (double)d.C * (8.0 + 4.0 + (double)(1 << d.pb_log2));
     }
     lap("extract + download + unpack");
     im.timings.loop_ms += loop_ms;
     im.timings.host_launch_ms += host_launch_ms;
     im.timings.lockstep_iters += launched_iters;
-    if (fuse) im.timings.steps_chain_launches += (double)launched_iters * ranges[0].count;
     im.timings.chains += n;
     im.timings.arena_bytes = std::max(im.timings.arena_bytes, (double)arena_bytes);
     im.timings.total_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
@@ -3663,11 +2736,10 @@ class HipShardEngine : public ShardEngine {
         g.n_bits = d_.prep_nbits;
         if (g.n_bits > 30) throw std::runtime_error("kernel needs more than 30 CSD digits per entry; unsupported");
         g.wide = g.n_bits > 12 || n_loc_ > 256;
-        g.fuse = false;  // the column-sharded chain steps with k_iter_select<SHARDED>
         if (job.adder_size >= 0 || job.carry_size >= 0) step_tab_.build(job.qints, job.n_in);  // -log2f of non-power-of-two input steps (StepLog2), as in run_chains
         g.n_mant = (int)step_tab_.mant.size();
         g.K = key_count(g.n_bits);
-        g.Kpad = (g.K + 7) & ~7;
+        g.Kpad = (g.K + 3) & ~3;
         g.pb_log2 = 5;
         while ((1 << g.pb_log2) < 16 + 2 * g.Kpad) ++g.pb_log2;
         const long long D0 = d_.prep_digits;
@@ -3720,7 +2792,6 @@ class HipShardEngine : public ShardEngine {
         HIP_CHECK(hipMemsetAsync(d_.stamp, 0, sizeof(uint32_t) * (size_t)g.rcap, st_));
         HIP_CHECK(hipMemsetAsync(d_.hkey, 0xFF, sizeof(unsigned long long) * (size_t)g.C, st_));
         HIP_CHECK(hipMemsetAsync(d_.hrank, 0, sizeof(uint32_t) * (size_t)g.C, st_));
-        if (d_.hctl) HIP_CHECK(hipMemsetAsync(d_.hctl, 0, (size_t)g.C, st_));
         HIP_CHECK(hipMemsetAsync(d_.ub, 0, sizeof(unsigned long long) * (size_t)g.n_groups, st_));
         HIP_CHECK(hipMemsetAsync(d_.gdirty, 1, (size_t)g.n_groups, st_));
         d_.cb_words = (g.rcap + 31) / 32;

@@ -10,7 +10,7 @@ namespace da {
 namespace gpu {
 
 struct GpuTimings {  // accumulated since the last reset; read by the benchmark harness
-    double loop_ms = 0;       // HIP-event time of the greedy loops (k_steps / k_iter_select + k_iter_update launches)
+    double loop_ms = 0;       // HIP-event time of the greedy loops (k_iter_select + k_iter_update launches)
     double dist_ms = 0;       // HIP-event time of k_col_dist
     double total_ms = 0;      // wall time inside run_chains (uploads, set-up, loop, downloads)
     long long lockstep_iters = 0;  // launched (select, update) kernel pairs
@@ -33,9 +33,6 @@ struct GpuTimings {  // accumulated since the last reset; read by the benchmark 
     double arena_bytes = 0;   // largest device arena used
     double select_bytes = 0;    // algorithmic bytes of k_iter_select, counted on the device
     double host_launch_ms = 0;  // host time spent queueing the greedy loop's launches (the launch thread's share of the loop)
-    // k_steps (several greedy steps per launch, updates applied inside the kernel): launches x chains, steps whose update was
-    // applied in the kernel, steps handed to k_iter_update, device-counted algorithmic bytes of the in-kernel updates
-    double steps_chain_launches = 0, fused_steps = 0, handoff_steps = 0, tpp_bytes = 0;
 };
 
 class HipBackend : public Backend {

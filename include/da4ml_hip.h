@@ -155,10 +155,8 @@ int da_dais_run_on(const int32_t *program, int64_t n_words, const double *inputs
  * count-block bytes (2K per touched block), partner-cell bytes -- accumulated since the last reset */
 int da_timings(double *t, int reset);
 /* Further engine counters, same accumulation and reset as da_timings (call BEFORE a resetting da_timings); writes min(n, 16) values:
- * out[0] algorithmic bytes of the selection steps (k_steps / k_iter_select; device-counted), out[1] host ms
- * spent queueing greedy-loop launches, out[2] chains x launches of k_steps, out[3] greedy steps whose update k_steps applied itself,
- * out[4] steps it handed to k_iter_update, out[5] algorithmic bytes of the in-kernel updates, out[6..15] reserved (0); returns the
- * number written */
+ * out[0] algorithmic bytes of k_iter_select (device-counted), out[1] host ms spent queueing greedy-loop
+ * launches, out[2..15] reserved (0); returns the number written */
 int da_engine_stats(double *out, int n);
 
 #ifdef __cplusplus

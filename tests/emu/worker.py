@@ -223,23 +223,6 @@ def race_cases():
     out(digests=[digest(p) for p in got] + [digest(hip.solve(int_matrix(4, 8, 8, -32, 32)))], partners_per_step=tm['partners'] / max(tm['iterations'], 1))
 
 
-def steps():
-    """k_steps under the settings the test put into the environment (steps per launch, which steps are updated inside the kernel):
-    random option sets, a mixed batch, a 28x28 chain -- against the oracle; reports how many steps were updated in the kernel
-    and how many were handed to k_iter_update"""
-    o = Oracle('port')
-    bad = []
-    for seed in range(30):
-        k, opts, _ = random_case(seed)
-        if hip.solve(k, **opts) != o.solve(k, **opts):
-            bad.append(seed)
-    ks = [int_matrix(s, 6 + s % 5, 4 + s % 7, -64, 64) for s in range(12)] + [int_matrix(40, 4, 5, -8192, 8192), int_matrix(7, 28, 28, -128, 128), int_matrix(8, 40, 12, -2048, 2048)]
-    got = hip.solve_many(ks, **SINGLE)
-    bad += [100 + i for i, k in enumerate(ks) if got[i] != o.solve(k, **SINGLE)]
-    tm = hip.timings()
-    out(bad=bad, fused=tm['fused_steps'], handoffs=tm['handoff_steps'], iterations=tm['iterations'])
-
-
 def dais():
     """k_dais_run on the emulated device against the host executor"""
     from dais_cases import random_program
@@ -255,4 +238,4 @@ def dais():
 if __name__ == '__main__':
     what = sys.argv[1]
     {'random': lambda: random_cases(int(sys.argv[2]), int(sys.argv[3])), 'oddsteps': lambda: odd_steps(int(sys.argv[2]), int(sys.argv[3])), 'layouts': layouts, 'batch': batch, 'retry': retry, 'big_table': big_table, 'fork': fork_after_use, 'record': lambda: record(sys.argv[2], sys.argv[3]),
-     'shard_single': shard_single, 'shard_retry': shard_retry, 'shard_rank': shard_rank, 'dais': dais, 'race_cases': race_cases, 'steps': steps}[what]()  # fmt: skip
+     'shard_single': shard_single, 'shard_retry': shard_retry, 'shard_rank': shard_rank, 'dais': dais, 'race_cases': race_cases}[what]()  # fmt: skip

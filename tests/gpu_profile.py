@@ -19,5 +19,3 @@ print('select cycles/iteration:', {k: round(v / its) for k, v in ph.items() if k
 print('update cycles/partner  :', {k: round(v / pa) for k, v in ph.items() if k.startswith('upd_')}, 'partners/iter', round(pa / its), 'found/partner %.2f' % (tm['found'] / pa), 'inserts/partner %.3f' % (tm['inserts'] / pa))
 sm = max(tm['samples'], 1)
 print('sampled per-launch: select %.1f us, update %.1f us, chains/launch %.1f' % (1e3 * tm['select_ms_sampled'] / sm, 1e3 * tm['update_ms_sampled'] / sm, tm['sampled_chain_launches'] / sm))
-print('k_steps: fused steps %.0f, handed over %.0f, chain-launches %.0f -> %.2f steps per chain-launch; loop us per greedy step of a chain %.2f' % (
-    tm['fused_steps'], tm['handoff_steps'], tm['steps_chain_launches'], its / max(tm['steps_chain_launches'], 1), 1e3 * tm['loop_ms'] * B / its))

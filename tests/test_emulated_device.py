@@ -57,28 +57,6 @@ def test_batched_chains(emu):
     assert r['bad'] == [] and r['chains'] >= 13
 
 
-@pytest.mark.parametrize('env', [
-    {'DA4ML_HIP_FUSE': '0'},
-    {'DA4ML_HIP_FUSE': '1'},
-    {'DA4ML_HIP_FUSE': '64'},
-    {'DA4ML_HIP_FUSE': '8', 'DA4ML_HIP_FUSE_M': '2', 'DA4ML_HIP_FUSE_NP': '12'},
-    {'DA4ML_HIP_FUSE': '8', 'DA4ML_HIP_FUSE_NH': '3'},
-    {'DA4ML_HIP_FUSE': '8', 'DA4ML_HIP_FUSE_M': '100', 'DA4ML_HIP_FUSE_NP': '1000000', 'DA4ML_HIP_FUSE_NH': '1000000'},
-], ids=['pair', 'steps1', 'steps64', 'mixed', 'filtered_handoff', 'all_fused'])
-def test_step_engine_settings(emu, env):
-    """k_steps -- several greedy steps per launch, the update applied by the selecting workgroup itself, thread per partner row,
-    table probed through its control bytes -- under every setting of its knobs, next to the kernel pair it replaces for narrow
-    chains (DA4ML_HIP_FUSE=0): all equal the oracle.  (The emulated build stages 16 partner ids in LDS, so both id paths run.)"""
-    r = emu('steps', env=env)
-    assert r['bad'] == []
-    if env.get('DA4ML_HIP_FUSE') == '0':
-        assert r['fused'] == 0 and r['handoffs'] == 0
-    elif env.get('DA4ML_HIP_FUSE_M') == '100':
-        assert r['fused'] > 0.9 * r['iterations']
-    else:
-        assert r['fused'] > 0 and r['handoffs'] > 0
-
-
 def test_wide_host_pool(emu):
     """the host thread pool as on the 256-core GPU box: 200 threads, of which those beyond the first 63 are woken for wide loops
     only (here: 14 chains x 8 column ranges of the adder trees)"""
@@ -90,18 +68,10 @@ def test_fork_after_use(emu):
     assert emu('fork', timeout=300) == {'child': 0, 'parent': True, 'fork_during_solve_ok': True}
 
 
-@pytest.mark.parametrize('fuse', ['0', '8'], ids=['pair', 'steps'])
-def test_capacity_retry(emu, fuse):
-    """arena heuristics far too small: capacity error on the device, rerun with larger arenas -- with the kernel pair and with the
-    step engine (whose in-kernel updates claim table slots themselves)"""
-    r = emu('retry', env=dict(DA4ML_HIP_TABLE_SCALE='0.02', DA4ML_HIP_ROW_SCALE='0.05', DA4ML_HIP_FUSE=fuse))
+def test_capacity_retry(emu):
+    """arena heuristics far too small: capacity error on the device, rerun with larger arenas"""
+    r = emu('retry', env=dict(DA4ML_HIP_TABLE_SCALE='0.02', DA4ML_HIP_ROW_SCALE='0.05'))
     assert r['equal'] and r['retries'] >= 1
-
-
-def test_table_geometry_of_a_large_chain_step_engine(emu):
-    """the pair-table geometry of a 256x256 chain (4096 groups of 512 slots: every lane of the selection holds four group bounds, the
-    LDS copy of the bounds is 68 KB) under the step engine"""
-    assert emu('big_table', env=dict(DA4ML_HIP_TABLE_SCALE='6000', DA4ML_HIP_FUSE='8'), timeout=1800)['bad'] == []
 
 
 def test_table_geometry_of_a_large_chain(emu):

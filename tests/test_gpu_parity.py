@@ -340,53 +340,3 @@ def test_repeated_solves_are_deterministic(hip, oracle):
         got = hip.solve_many([k for k, _ in cases], adder_size=1, carry_size=-1) + [hip.solve(big)]
         for i, (g, w) in enumerate(zip(got, want)):
             assert g == w, f'repetition {rep}, case {i}'
-
-
-@pytest.mark.parametrize('env', [
-    {'DA4ML_HIP_FUSE': '0'},                                                    # the (k_iter_select, k_iter_update) pair for every step
-    {'DA4ML_HIP_FUSE': '1'},                                                    # k_steps, one step per launch
-    {'DA4ML_HIP_FUSE': '64'},                                                   # up to 64 steps per launch
-    {'DA4ML_HIP_FUSE': '8', 'DA4ML_HIP_FUSE_M': '2', 'DA4ML_HIP_FUSE_NP': '48'},                       # fused steps and hand-offs interleaved
-    {'DA4ML_HIP_FUSE': '8', 'DA4ML_HIP_FUSE_NH': '3'},                          # the filter runs, then nearly every step hands its heavy rows to k_iter_update
-    {'DA4ML_HIP_FUSE': '8', 'DA4ML_HIP_FUSE_M': '100', 'DA4ML_HIP_FUSE_NP': '1000000', 'DA4ML_HIP_FUSE_NH': '1000000'},  # every step the kernel can take is updated inside k_steps
-], ids=['pair', 'steps1', 'steps64', 'mixed', 'filtered_handoff', 'all_fused'])
-def test_step_engine_settings(oracle, env):
-    """k_steps (several greedy steps per launch, updates applied by the selecting workgroup itself, thread per partner row) against
-    the kernel pair it replaces for narrow chains: whatever the steps per launch and wherever the line between in-kernel updates
-    and steps handed to k_iter_update is drawn, results equal the oracle -- random option sets, a mixed batch with both entry
-    layouts, a 64x64 batch and the 128x128 chain of the reference-build record."""
-    import hashlib
-    import json
-    import os
-    import subprocess
-    import sys
-    from pathlib import Path
-
-    rec = json.loads((Path(__file__).parent / 'golden' / 'large_chain_golden.json').read_text())['128x128_seed0_single_chain_ref']
-    code = (
-        "import sys, json, hashlib; sys.path.insert(0, '.'); sys.path.insert(0, 'tests')\n"
-        "from cases import int_matrix, random_case\nfrom da4ml_amd import _binary as hip\nfrom oracle.oracle import HERE, Oracle\n"
-        "o = Oracle('ref' if (HERE / '_ref' / 'libref.so').exists() else 'port'); bad = []  # the reference's own sources when the build is there\n"
-        "for s in range(40):\n"
-        "    k, opts, _ = random_case(s)\n"
-        "    if hip.solve(k, **opts) != o.solve(k, **opts): bad.append(s)\n"
-        "single = dict(method0='wmc', method1='wmc', decompose_dc=-1, search_all_decompose_dc=False)\n"
-        "ks = [int_matrix(s, 6 + s % 5, 4 + s % 7, -64, 64) for s in range(12)] + [int_matrix(40, 4, 5, -8192, 8192), int_matrix(41, 3, 300, -4, 4)]\n"
-        "ks += [int_matrix(100 + s, 64, 64, -128, 128) for s in range(8)]\n"
-        "got = hip.solve_many(ks, **single)\n"
-        "bad += [100 + i for i, k in enumerate(ks) if got[i] != o.solve(k, **single)]\n"
-        f"p = hip.solve(int_matrix(0, 128, 128, -128, 128), **json.loads({json.dumps(json.dumps(rec['opts']))}))\n"
-        "dump = json.loads(json.dumps(p, default=lambda x: x.to_dict()))\n"
-        "t = hip.timings()\n"
-        "print(json.dumps({'bad': bad, 'sha': hashlib.sha256(json.dumps(dump, separators=(',', ':')).encode()).hexdigest(), 'fused': t['fused_steps'], 'handoffs': t['handoff_steps']}))\n"
-    )
-    out = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, **env), capture_output=True, text=True, cwd=str(Path(__file__).resolve().parent.parent), timeout=600)
-    assert out.returncode == 0, out.stderr[-3000:]
-    r = json.loads(out.stdout.strip().splitlines()[-1])
-    assert r['bad'] == [] and r['sha'] == rec['sha256']
-    if env.get('DA4ML_HIP_FUSE') == '0':
-        assert r['fused'] == 0 and r['handoffs'] == 0
-    elif env.get('DA4ML_HIP_FUSE_M') == '100':  # (the host still caps the substituted columns per in-kernel update at 16, one per lane of a group)
-        assert r['fused'] > 1000
-    else:
-        assert r['fused'] > 0 and r['handoffs'] > 0
