@@ -217,7 +217,11 @@ def _run_world(worker, world, timeout=600, _retry=True):
         assert p.returncode == 0, e[-3000:]
     import json
 
-    return [json.loads(o.strip().splitlines()[-1]) for o, _ in outs]
+    def last_json(text):  # (a rank may print nothing of its own; gloo prints a connection banner on stdout)
+        lines = [ln for ln in text.splitlines() if ln.startswith('{')]
+        return json.loads(lines[-1]) if lines else None
+
+    return [last_json(o) for o, _ in outs]
 
 
 def test_column_sharded_chain_gloo_world2_and_3():
@@ -289,6 +293,19 @@ def test_column_sharded_chain_gloo_world8():
     c4 = res[0]['res']['c4_split_32x256']
     assert c4['chains'] >= 1 and c4['steps'] > 500 and c4['slab_bytes_per_step'] > c4['flag_bytes_per_step'] > 0
     print('C4 split at world 8:', json.dumps(c4))
+
+
+def test_instance_and_candidate_sharding_gloo_world8():
+    """the two layouts that have no per-step collective, at the size of a full node (8 ranks over gloo): the C5 batch of 7 layer
+    shapes sharded by estimated cost and by count (7 units over 8 ranks: one rank gets nothing and still takes part in the gather)
+    comes back on rank 0 in input order, equal to the single-process solves; the candidates of a searching solve split over 8
+    ranks (10 candidates for a 16-column matrix: two ranks get two) give the single-process result on every rank."""
+    res = _run_world(MANY_WORKER, 8, timeout=900)
+    assert res[0] == {'cost': [True] * 7, 'count': [True] * 7}, res[0]
+    res = _run_world(CAND_WORKER, 8, timeout=900)
+    assert [r['rank'] for r in res] == list(range(8))
+    for r in res:
+        assert r['same'] == [True, True, True], r
 
 
 def test_init_needs_a_port_from_the_launcher(monkeypatch):
