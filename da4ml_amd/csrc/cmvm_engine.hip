@@ -715,7 +715,7 @@ template <class Cell> __global__ void __launch_bounds__(256) k_init_pairs(ChainD
 // the head of the exchange slab instead of the table, and instead of a partner list the kernel leaves one flag per row.
 // select_body: one greedy step's selection + substitution of chain `g` by a 1024-thread workgroup; returns 1 when the chain
 // is (or just became) finished, 0 after an ordinary step (hand-off for the update written).  Called by the k_iter_select
-// wrapper (one launch per step: the column-sharded chain and the DA4ML_HIP_ENGINE=launch path) and by the persistent k_greedy.
+// wrapper, one launch per step.
 template <class Cell, bool SHARDED = false> __device__ __forceinline__ int select_body(ChainDev *g, unsigned int *n_done) {
     using O = CellOps<Cell>;
     using F = RowFmt<Cell>;
