@@ -195,6 +195,16 @@ __device__ __forceinline__ uint32_t ref_row(unsigned long long r) { return (uint
 __device__ __forceinline__ uint32_t ref_len(unsigned long long r) { return (uint32_t)(r >> REF_ROW_BITS) & ((1u << REF_LEN_BITS) - 1u); }
 __device__ __forceinline__ uint32_t ref_off(unsigned long long r) { return (uint32_t)(r >> (REF_ROW_BITS + REF_LEN_BITS)); }
 
+// A table entry together with what a substitution needs of its two rows: the best entry a search found (64 bytes = one
+// s_load_dwordx16 of the block that takes it up)
+struct SpecPick {
+    unsigned long long word;  // bound word of the entry (rank << 32 | tie >> 23); 0 = none / not usable
+    unsigned long long tie;   // its full tie word (id1, id0, key index)
+    da_u2 refA, refB;         // {offset, length} of the lists of rows id0 and id1
+    RowInfo ra, rb;           // their records
+};
+static_assert(sizeof(SpecPick) == 64, "SpecPick is read as sixteen words");
+
 // Per-chain descriptor in device memory.  Pointers are raw device addresses into the arena.
 struct ChainDev {
     // geometry (constant after set-up)
@@ -267,6 +277,16 @@ struct ChainDev {
     int n_step_mant;
     unsigned long long st_sel_bytes;  // algorithmic bytes of the selection steps (all but the group re-reads, which st_rescans prices)
     unsigned long long st_phase[12];  // shader-clock cycles per kernel phase (select: 0-6, update: 7-11)
+    // ---- the next pick, known one step ahead (k_iter_select2: search_body / pick_body)
+    SpecPick spec[2];              // [t & 1]: the best entry of the table of step t that touches neither row of step t's pick -- step t
+                                   // does not change it --, left by the search block of step t for step t + 1 (word 0: not usable)
+    unsigned long long mword[2];   // [t & 1]: the largest bound word among the entries the update of step t wrote (only those >= spec[t & 1].word
+                                   // are folded in); zeroed by the selection of step t
+    SpecPick pick;                 // a step that cannot use spec[]: the pick, found and published by the search block for the substitution block
+    unsigned int pick_flag;        // t + 1 once `pick` holds the pick of step t
+    uint32_t *sp_cnt;              // [6][Kpad] exact counts of the six pairs among {A, B, new row}: select -> update
+    unsigned long long st_fast;    // steps whose pick was known before the step began
+    unsigned long long st_qphase[4];  // shader-clock cycles of the search block: bounds, arg-max (steps without a known pick), search, steps timed
 };
 
 __constant__ Log2Table c_log2;
@@ -366,6 +386,8 @@ struct Ctx {
     const DA_GLOBAL RowInfo *rows;
     ChainDev *g;  // derived from the kernel argument: already known to be global
     unsigned long long tomb;  // this launch's tombstone value
+    unsigned long long rword;  // k_iter_update: bound word of the entry the next selection would like to take unseen (0: none);
+    unsigned long long *mw;    // every entry written with a bound word >= rword is folded into *mw (group_note)
 };
 
 // launch_id: 2 * iteration for k_iter_select, 2 * iteration + 1 for k_iter_update (only the low two bits are used)
@@ -388,6 +410,8 @@ __device__ __forceinline__ Ctx make_ctx_raw(ChainDev *g, int launch_id) {
     c.gdirty = (DA_GLOBAL uint8_t *)g->gdirty;
     c.rows = (const DA_GLOBAL RowInfo *)g->rows;
     c.g = g;
+    c.rword = 0;
+    c.mw = nullptr;
     return c;
 }
 __device__ __forceinline__ void ctx_finish(Ctx &c) { c.windows = c.windows / WAVE ? c.windows / WAVE : 1; }  // after the fields are pinned
@@ -460,12 +484,14 @@ __device__ __forceinline__ void group_note(const Ctx &c, int slot, unsigned long
     const int grp = slot >> c.gs_log2;
     if (w_new > w_old) atomicMax(gen(&c.ub[grp]), w_new);
     c.gdirty[grp] = 1;
+    if (c.rword && w_new >= c.rword) atomicMax(c.mw, w_new);  // a changed entry that the next pick would have to beat (rare by construction)
 }
 
 // Store a complete block.  cnt_of(k) gives the count of key k; returns false when the table is full.
 // Precondition: at least one count >= 2 (checked by the caller), key absent.  ra / rb: intervals of rows lo / hi.
+// `w_out` (optional): the bound word of the new block's best entry, 0 when none is selectable (wave-uniform).
 template <class CntFn>
-__device__ bool table_insert(const Ctx &c, uint32_t lo, uint32_t hi, const RowInfo &ra, const RowInfo &rb, CntFn cnt_of) {
+__device__ bool table_insert(const Ctx &c, uint32_t lo, uint32_t hi, const RowInfo &ra, const RowInfo &rb, CntFn cnt_of, unsigned long long *w_out = nullptr) {
     int lane = lane_id();
     unsigned long long key = pack_pair(lo, hi);
     int slot = table_claim(c, key, hash_pair(lo, hi));
@@ -486,6 +512,7 @@ __device__ bool table_insert(const Ctx &c, uint32_t lo, uint32_t hi, const RowIn
         best = cand > best ? cand : best;
     }
     best = wave_max_u64(best);
+    if (w_out) *w_out = (best >> 8) ? bound_word((uint32_t)(best >> 8), tie_word(lo, hi, (int)(best & 0xFF))) : 0ull;
     if (lane == 0) {
         uint32_t rank = (uint32_t)(best >> 8), idx = (uint32_t)(best & 0xFF);
         store_hdr(c, slot, ov, dl, rank, idx);
@@ -514,8 +541,9 @@ __device__ __forceinline__ void block_commit(const Ctx &c, int slot, unsigned lo
 }
 
 // Re-evaluate a block after its counts changed (new_cnt(k, old) -> new count); deletes it when no count >= 2.
+// Returns the bound word of the block's best entry afterwards (0: deleted, or nothing selectable); wave-uniform.
 template <class CntFn>
-__device__ void table_update(const Ctx &c, int slot, unsigned long long key, CntFn new_cnt) {
+__device__ unsigned long long table_update(const Ctx &c, int slot, unsigned long long key, CntFn new_cnt) {
     int lane = lane_id();
     const BlkHdr h = load_hdr(c, slot);
     DA_GLOBAL uint16_t *cnt = blk_cnt(c, slot);
@@ -533,6 +561,7 @@ __device__ void table_update(const Ctx &c, int slot, unsigned long long key, Cnt
     best = wave_max_u64(best);
     alive = __any(alive);
     if (lane == 0) block_commit(c, slot, key, h, best, alive);
+    return alive && (best >> 8) ? bound_word((uint32_t)(best >> 8), tie_word((uint32_t)key, (uint32_t)(key >> 32), (int)(best & 0xFF))) : 0ull;
 }
 
 // ------------------------------------------------------------------------------------------------ k_prepare
@@ -1352,6 +1381,662 @@ template <class Cell, bool SHARDED = false> __global__ void __launch_bounds__(SE
     (void)select_body<Cell, SHARDED>(&chains[blockIdx.x], n_done);
 }
 
+
+// ================================================================================= k_iter_select2: the next pick, one step ahead
+// A greedy step changes only table entries that touch the two rows of its pick (A, B) or the row it creates (N).  So the
+// best entry R_t of the table of step t that touches neither A_t nor B_t is still in the table of step t + 1, unchanged, and
+// the pick of step t + 1 is the larger of R_t and the best entry touching A_t, B_t or N_t.  The selection of a step is split
+// into two workgroups per chain that run side by side:
+//   * the SEARCH block (search_body, blockIdx.y == 0) looks for R_t -- the lazy arg-max over the group bounds with A_t / B_t
+//     excluded -- and for V_t, the best entry that touches exactly one of A_t / B_t (its value BEFORE step t's update).  It
+//     leaves R_t in spec[t & 1] if R_t beats V_t, "none" otherwise;
+//   * the update of step t folds every entry it writes whose bound word reaches R_t's into mword[t & 1] (group_note; the
+//     blocks of the three pairs among {A, B} are folded in whether they changed or not: they are not covered by V_t);
+//   * the SUBSTITUTION block (pick_body, blockIdx.y == 1) of step t + 1 takes R_t as its pick when spec[t & 1].word >
+//     mword[t & 1] -- no bounds, no arg-max in front of the substitution -- and waits for the search block to publish the
+//     pick otherwise (which then runs the arg-max first, as k_iter_select did, and its search afterwards).
+// Exactness: an entry of the table of step t + 1 is (i) untouched by step t: at most R_t; (ii) touches A_t or B_t and was
+// re-evaluated with a changed best (rank, key), or is new: folded into mword if it reaches R_t; (iii) touches A_t or B_t,
+// best (rank, key) unchanged: at most V_t < R_t, or one of the three special blocks: folded.  Bound words drop the low 23 bits
+// of the tie word, so equal words are treated as "cannot tell" (the step takes the slow path).
+// Only the search block reads or writes group bounds; the table itself is not written by this kernel at all (the six special
+// blocks moved to k_iter_update), so the two blocks share nothing but the descriptor fields named above.
+constexpr uint32_t ROW_NONE = 0xFFFFFFFFu;
+
+#ifdef DA_PHASE_TIMERS
+#define Q_TIMER_DECL long long qp[4];
+#define Q_TIMER_MARK(i) qp[i] = clock64();
+#else
+#define Q_TIMER_DECL
+#define Q_TIMER_MARK(i)
+#endif
+
+template <class Cell> __device__ __forceinline__ void search_body(ChainDev *g, int step) {
+    constexpr int NW = SEL_THREADS / WAVE;
+    const int par = step & 1;
+    int was_done = g->done, had_error = g->error, n_groups = g->n_groups;
+    unsigned long long sp_word = g->spec[par ^ 1].word, sp_tie = g->spec[par ^ 1].tie, mw_prev = g->mword[par ^ 1];
+    Ctx c = make_ctx_raw(g, 2 * step);
+    DA_GLOBAL unsigned long long *gtie_arr = (DA_GLOBAL unsigned long long *)g->gtie;
+    const DA_GLOBAL da_u2 *rowoff = (const DA_GLOBAL da_u2 *)g->rowoff;
+    pin_sgpr(was_done, had_error, n_groups, sp_word, sp_tie, mw_prev);
+    pin_sgpr(c.gs_log2, c.pb_log2, c.hkey, c.hrank, c.hblk, c.ub, c.gdirty, c.rows);
+    pin_sgpr(gtie_arr, rowoff);
+    if (was_done || had_error != E_OK) return;  // (the substitution block stops the chain)
+    const bool fast = sp_word != 0 && sp_word > mw_prev;
+    __shared__ unsigned long long q_floor, q_red_tie[NW], q_red_vtie[NW];
+    __shared__ uint32_t q_red_rank[NW], q_red_vrank[NW];
+    const int tid = threadIdx.x, lane = lane_id(), wid = wave_id();
+    const int gs = 1 << c.gs_log2;
+    Q_TIMER_DECL
+    Q_TIMER_MARK(0)
+    // ---- ONE vector round trip: bound, dirty flag and stored tie word of this lane's (up to four) groups (wave w owns the groups
+    // [w * GPW, (w + 1) * GPW)); unconditional loads, index clamped (see select_body)
+    const int GPW = (n_groups + NW - 1) / NW;
+    unsigned long long ubr[4], gtr[4];
+    int dr[4];  // 0 clean (bound and tie word exact), 1 dirty, 3 absent, 4 read in this pass, 5 clean but its best entry touches an excluded row
+    {
+        bool in[4];
+        uint8_t dv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int q = wid * GPW + lane + u * WAVE;
+            in[u] = lane + u * WAVE < GPW && q < n_groups;
+            const int qc = in[u] ? q : 0;
+            ubr[u] = c.ub[qc];
+            dv[u] = c.gdirty[qc];
+            gtr[u] = gtie_arr[qc];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            ubr[u] = in[u] ? ubr[u] : 0ull;
+            dr[u] = in[u] ? (dv[u] ? 1 : 0) : 3;
+        }
+    }
+    Q_TIMER_MARK(1)
+    uint32_t exA = ROW_NONE, exB = ROW_NONE;  // rows whose entries the pass leaves out
+    if (fast) {
+        exA = (uint32_t)((sp_tie >> 7) & 0xFFFFFFu);
+        exB = (uint32_t)(sp_tie >> 31);
+    }
+    unsigned int rescans = 0;
+    for (int pass = fast ? 1 : 0; pass < 2; ++pass) {
+        // pass 0 (only when the pick is not known yet): the arg-max over the whole table -> the pick, published for the substitution block;
+        // pass 1: the same with the entries of the pick's rows left out -> R (and V, the best entry touching exactly one of the rows)
+        if (tid == 0) q_floor = 0;
+        uint32_t nr = 0, vr = 0;  // this lane's best candidates so far: outside / touching the excluded rows
+        unsigned long long nt = 0, vt = 0;
+        auto offer = [&](uint32_t r, unsigned long long tw) -> unsigned long long {  // returns the bound word if the entry counts towards the floor
+            const uint32_t i0 = (uint32_t)((tw >> 7) & 0xFFFFFFu), i1 = (uint32_t)(tw >> 31);
+            const bool t0 = i0 == exA || i0 == exB, t1 = i1 == exA || i1 == exB;
+            if (!(t0 || t1)) {
+                if (r > nr || (r == nr && tw > nt)) {
+                    nr = r;
+                    nt = tw;
+                }
+                return bound_word(r, tw);
+            }
+            if (!(t0 && t1) && (r > vr || (r == vr && tw > vt))) {
+                vr = r;
+                vt = tw;
+            }
+            return 0ull;
+        };
+        unsigned long long cl = 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (dr[u] == 4 || dr[u] == 5) dr[u] = 0;  // read (and, if it was dirty, verified) in the previous pass: exact values in the registers
+            if (dr[u] == 0 && (uint32_t)(ubr[u] >> 32) != 0) {
+                const unsigned long long w = offer((uint32_t)(ubr[u] >> 32), gtr[u]);
+                if (w)
+                    cl = max(cl, w);
+                else
+                    dr[u] = 5;
+            }
+        }
+        __syncthreads();  // q_floor zeroed
+        cl = wave_max_u64(cl);
+        if (lane == 0 && cl) atomicMax(&q_floor, cl);
+        __syncthreads();
+        while (true) {
+            // ONE group per wave and round: the wave's highest group that is dirty (bound possibly stale) or whose best entry is excluded,
+            // while its bound still reaches the rising floor = the best entry found so far
+            const unsigned long long fl = __hip_atomic_load(&q_floor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            unsigned long long top = 0;
+            int top_u = 0, top_s = 0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if ((dr[u] == 1 || dr[u] == 5) && ubr[u] > top) {
+                    top = ubr[u];
+                    top_u = u;
+                    top_s = dr[u];
+                }
+            const unsigned long long wtop = wave_max_u64(top);
+            if (wtop == 0 || wtop < fl) break;
+            const int owner = __ffsll((long long)__ballot(top == wtop)) - 1;
+            const int own_u = __builtin_amdgcn_readlane(top_u, owner);
+            const bool own_dirty = __builtin_amdgcn_readlane(top_s, owner) == 1;
+            const uint32_t grp = (uint32_t)(wid * GPW + owner + own_u * WAVE), base = grp * gs;
+            uint32_t rk[8], grank = 0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int o = lane + u * WAVE;
+                rk[u] = o < gs ? c.hrank[base + o] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) grank = max(grank, rk[u]);
+            for (int o = lane + 8 * WAVE; o < gs; o += WAVE) grank = max(grank, c.hrank[base + o]);
+            grank = wave_max_u32(grank);
+            // keys and best-key indices of every slot whose rank reaches the floor's (the floor's own rank included: the tie word decides)
+            const uint32_t fr = (uint32_t)(fl >> 32), thr = fr ? fr : 1u;
+            unsigned long long kk[8], gt = 0, lw = 0;
+            uint32_t bi[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int o = lane + u * WAVE;
+                kk[u] = 0;
+                bi[u] = 0;
+                if (o < gs && rk[u] >= thr) {
+                    kk[u] = c.hkey[base + o];
+                    bi[u] = load_best_idx(c, base + o);
+                }
+            }
+            load_fence();
+#pragma unroll
+            for (int u = 0; u < 8; ++u) pin_vgpr(kk[u], bi[u]);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int o = lane + u * WAVE;
+                if (o < gs && rk[u] >= thr) {
+                    const unsigned long long tw = tie_word((uint32_t)kk[u], (uint32_t)(kk[u] >> 32), (int)bi[u]);
+                    if (rk[u] == grank) gt = tw > gt ? tw : gt;
+                    lw = max(lw, offer(rk[u], tw));
+                }
+            }
+            for (int o = lane + 8 * WAVE; o < gs; o += WAVE) {
+                const uint32_t r2 = c.hrank[base + o];
+                if (r2 >= thr) {
+                    const unsigned long long k2 = c.hkey[base + o];
+                    const unsigned long long tw = tie_word((uint32_t)k2, (uint32_t)(k2 >> 32), (int)load_best_idx(c, base + o));
+                    if (r2 == grank) gt = tw > gt ? tw : gt;
+                    lw = max(lw, offer(r2, tw));
+                }
+            }
+            if (lw > fl) atomicMax(&q_floor, lw);
+            if (own_dirty) {
+                // tighten the group's bound.  Its best entry is known exactly when its rank reaches the floor's (the keys were read):
+                // the group becomes clean; otherwise (rank below the floor's) the bound drops to "that rank, any key" and the group stays dirty
+                const bool exact_known = grank >= thr || grank == 0;
+                if (exact_known) gt = wave_max_u64(gt);
+                const unsigned long long nb = grank == 0 ? 0ull : exact_known ? bound_word(grank, gt) : (((unsigned long long)grank << 32) | 0xFFFFFFFFull);
+                if (lane == owner) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (u == own_u) {
+                            ubr[u] = nb < ubr[u] ? nb : ubr[u];
+                            if (exact_known) {
+                                gtr[u] = gt;
+                                dr[u] = 4;
+                            }
+                        }
+                    if (exact_known) {
+                        c.ub[grp] = nb;
+                        gtie_arr[grp] = gt;
+                        c.gdirty[grp] = 0;
+                    } else if (nb < wtop)
+                        c.ub[grp] = nb;
+                }
+            } else if (lane == owner) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (u == own_u) dr[u] = 4;
+            }
+            ++rescans;
+            lds_fence();
+        }
+        // the wave's best entry outside / touching the excluded rows (highest rank, then highest tie word among its holders)
+        const uint32_t wnr = wave_max_u32(nr), wvr = wave_max_u32(vr);
+        const unsigned long long wnt = wave_max_u64(nr == wnr ? nt : 0ull), wvt = wave_max_u64(vr == wvr ? vt : 0ull);
+        // every wave fetches list references and records of ITS candidate's rows now (in flight across the reduction)
+        const uint32_t cA = wnr ? (uint32_t)((wnt >> 7) & 0xFFFFFFu) : 0u, cB = wnr ? (uint32_t)(wnt >> 31) : 0u;
+        const RowInfo cand_ra = load_row(c.rows, cA), cand_rb = load_row(c.rows, cB);
+        const da_u2 cand_refA = rowoff[cA], cand_refB = rowoff[cB];
+        if (lane == 0) {
+            q_red_rank[wid] = wnr;
+            q_red_tie[wid] = wnt;
+            q_red_vrank[wid] = wvr;
+            q_red_vtie[wid] = wvt;
+        }
+        __syncthreads();
+        uint32_t best_rank, v_rank;
+        unsigned long long best_tie, v_tie;
+        {
+            const uint32_t r = lane < NW ? q_red_rank[lane] : 0u, r2 = lane < NW ? q_red_vrank[lane] : 0u;
+            const unsigned long long t = lane < NW ? q_red_tie[lane] : 0ull, t2 = lane < NW ? q_red_vtie[lane] : 0ull;
+            best_rank = wave_max_u32(r);
+            best_tie = wave_max_u64(r == best_rank ? t : 0ull);
+            v_rank = wave_max_u32(r2);
+            v_tie = wave_max_u64(r2 == v_rank ? t2 : 0ull);
+        }
+        const bool mine = best_rank != 0 && wnr == best_rank && wnt == best_tie;  // exactly one wave holds the winner (tie words are unique)
+        if (pass == 0) {
+            Q_TIMER_MARK(2)
+            // the pick of this step, for the substitution block that waits for it (device-scope stores, then the flag with release)
+            if (best_rank == 0) {
+                if (tid == 0) {
+                    __hip_atomic_store(&g->pick.word, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&g->pick_flag, (unsigned int)step + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    g->spec[par].word = 0;
+                }
+                if (lane == 0 && rescans) atomicAdd(&g->st_rescans, (unsigned long long)rescans);
+                return;  // the table holds nothing selectable: the chain ends
+            }
+            if (mine && lane == 0) {
+                unsigned long long *pw = reinterpret_cast<unsigned long long *>(&g->pick);
+                const unsigned long long v[8] = {bound_word(best_rank, best_tie),
+                                                 best_tie,
+                                                 ((unsigned long long)cand_refA.y << 32) | cand_refA.x,
+                                                 ((unsigned long long)cand_refB.y << 32) | cand_refB.x,
+                                                 ((unsigned long long)f2u(cand_ra.hi) << 32) | f2u(cand_ra.lo),
+                                                 ((unsigned long long)f2u(cand_ra.lat) << 32) | f2u(cand_ra.step),
+                                                 ((unsigned long long)f2u(cand_rb.hi) << 32) | f2u(cand_rb.lo),
+                                                 ((unsigned long long)f2u(cand_rb.lat) << 32) | f2u(cand_rb.step)};
+#pragma unroll
+                for (int q = 0; q < 8; ++q) __hip_atomic_store(&pw[q], v[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&g->pick_flag, (unsigned int)step + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            exA = (uint32_t)((best_tie >> 7) & 0xFFFFFFu);
+            exB = (uint32_t)(best_tie >> 31);
+        } else {
+            // R for the next step: usable only if it beats every entry that touches exactly one of the pick's rows (their values may change)
+            const bool usable = best_rank != 0 && (v_rank == 0 || best_rank > v_rank || (best_rank == v_rank && best_tie > v_tie));
+            if (best_rank == 0) {
+                if (tid == 0) g->spec[par].word = 0;
+            } else if (mine && lane == 0) {
+                SpecPick sp;
+                sp.word = usable ? bound_word(best_rank, best_tie) : 0ull;
+                sp.tie = best_tie;
+                sp.refA = cand_refA;
+                sp.refB = cand_refB;
+                sp.ra = cand_ra;
+                sp.rb = cand_rb;
+                g->spec[par] = sp;
+            }
+        }
+    }
+    Q_TIMER_MARK(3)
+    if (lane == 0 && rescans) atomicAdd(&g->st_rescans, (unsigned long long)rescans);
+    if (tid == 0) {
+#ifdef DA_PHASE_TIMERS
+        g->st_qphase[0] += (unsigned long long)(qp[1] - qp[0]);
+        if (!fast) g->st_qphase[1] += (unsigned long long)(qp[2] - qp[1]);
+        g->st_qphase[2] += (unsigned long long)(qp[3] - (fast ? qp[1] : qp[2]));
+        g->st_qphase[3] += 1;
+#endif
+    }
+}
+
+// pick_body: the substitution block of a step (see above).  Phases (2)-(4) of select_body -- substitution of the pick in the
+// lists of rows A and B, exact recount of the six pairs among {A, B, new} (their counts go to sp_cnt: the blocks are written by
+// k_iter_update), partner rows -- behind a pick that is either read from the descriptor (known one step ahead) or awaited
+// from the search block.  Returns 1 when the chain is (or just became) finished.
+template <class Cell> __device__ __forceinline__ int pick_body(ChainDev *g, unsigned int *n_done, int step) {
+    using O = CellOps<Cell>;
+    using F = RowFmt<Cell>;
+    using Entry = typename F::Entry;
+    const int par = step & 1, iter = step;
+    // ---- ONE scalar round trip: every descriptor field the block needs, the entry left by the previous step's search included
+    int was_done = g->done, had_error = g->error, lcap = g->lcap;
+    int n_rows0 = g->n_rows, rcap = g->rcap, cbw = g->cb_words, adder_size = g->adder_size, carry_size = g->carry_size;
+    uint32_t offN = g->rl_used, rl_cap = g->rl_cap, n_live0 = g->n_live, live_peak0 = g->live_peak;
+    const uint32_t *step_mant = g->step_mant;
+    const float *step_tab = g->step_tab;
+    int n_step_mant = g->n_step_mant;
+    unsigned long long sp_word = g->spec[par ^ 1].word, sp_tie = g->spec[par ^ 1].tie, mw_prev = g->mword[par ^ 1];
+    uint32_t sp_ax = g->spec[par ^ 1].refA.x, sp_ay = g->spec[par ^ 1].refA.y, sp_bx = g->spec[par ^ 1].refB.x, sp_by = g->spec[par ^ 1].refB.y;
+    float sp_ra0 = g->spec[par ^ 1].ra.lo, sp_ra1 = g->spec[par ^ 1].ra.hi, sp_ra2 = g->spec[par ^ 1].ra.step, sp_ra3 = g->spec[par ^ 1].ra.lat;
+    float sp_rb0 = g->spec[par ^ 1].rb.lo, sp_rb1 = g->spec[par ^ 1].rb.hi, sp_rb2 = g->spec[par ^ 1].rb.step, sp_rb3 = g->spec[par ^ 1].rb.lat;
+    Ctx c = make_ctx_raw(g, 2 * iter);
+    DA_GLOBAL int *collen = (DA_GLOBAL int *)g->collen;
+    DA_GLOBAL da_u2 *rowoff = (DA_GLOBAL da_u2 *)g->rowoff;
+    DA_GLOBAL Entry *rl = (DA_GLOBAL Entry *)g->rlist;
+    DA_GLOBAL Cell *mA = (DA_GLOBAL Cell *)g->mA, *mB = (DA_GLOBAL Cell *)g->mB;
+    DA_GLOBAL int *mcol = (DA_GLOBAL int *)g->mcol;
+    DA_GLOBAL unsigned long long *collist = (DA_GLOBAL unsigned long long *)g->collist;
+    DA_GLOBAL uint16_t *cmap = (DA_GLOBAL uint16_t *)g->cmap;
+    DA_GLOBAL uint32_t *colbits = (DA_GLOBAL uint32_t *)g->colbits;
+    DA_GLOBAL uint32_t *pl_ids = (DA_GLOBAL uint32_t *)g->pl_ids;
+    DA_GLOBAL unsigned long long *plist = (DA_GLOBAL unsigned long long *)g->plist;
+    DA_GLOBAL da_i4 *picks = (DA_GLOBAL da_i4 *)g->picks;
+    DA_GLOBAL uint32_t *sp_cnt = (DA_GLOBAL uint32_t *)g->sp_cnt;
+    pin_sgpr(was_done, had_error, lcap, n_rows0, rcap, cbw, adder_size, carry_size, offN, rl_cap, n_live0, live_peak0, step_mant, step_tab, n_step_mant);
+    pin_sgpr(sp_word, sp_tie, mw_prev, sp_ax, sp_ay, sp_bx, sp_by, sp_ra0, sp_ra1, sp_ra2, sp_ra3, sp_rb0, sp_rb1, sp_rb2, sp_rb3);
+    pin_sgpr(c.n_out, c.n_bits, c.K, c.Kpad, c.rows);
+    pin_sgpr(collen, rowoff, rl, mA, mB, mcol, collist, cmap, colbits, pl_ids, plist, picks, sp_cnt);
+    const int n_out = c.n_out, Kpad = c.Kpad, nb = c.n_bits;
+    if (was_done) return 1;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // dynamic LDS carve: B's list | special-pair counters | per-matched-column scratch | column -> position in B
+    Entry *s_bent = reinterpret_cast<Entry *>(smem);                                  // [n_out] entries of row B (updated in place)
+    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_bent + n_out);                  // [6][Kpad]
+    int *s_len = reinterpret_cast<int *>(s_cnt + 6 * Kpad);                           // [n_out + 1] list lengths of the matched columns
+    int *s_col = s_len + n_out + 1;                                                   // [n_out] matched columns
+    int *s_bpos = s_col + n_out;                                                      // [n_out] 1 + position of a column in B's list, 0 = absent
+    int *s_clen = s_bpos + n_out;                                                     // [n_out] list length of every column
+    int *s_cm = s_clen + n_out;                                                       // [n_out] 1 + index among the matched columns, 0 = not matched
+    constexpr int NW = SEL_THREADS / WAVE;
+    __shared__ int s_np, s_part[NW];
+    __shared__ unsigned int s_matches;
+    __shared__ RowInfo s_new;
+    __shared__ unsigned long long s_pick[8];  // the published pick (a step whose pick was not known ahead)
+    constexpr int IDS_LDS = DA_IDS_LDS;
+    __shared__ uint32_t s_ids[IDS_LDS];  // the first partner row ids of the step (the rest, if any, goes through pl_ids in HBM)
+    __shared__ Log2Table s_log2;  // copy of c_log2 (the latency model's look-up then stays off the memory path)
+
+    const int tid = threadIdx.x, lane = lane_id(), wid = wave_id();
+
+    SEL_TIMER_DECL
+    SEL_TIMER_MARK(0)
+    if (had_error != E_OK) {  // a capacity error poisons the chain: stop it (the host retries with a larger arena)
+        if (tid == 0) {
+            g->done = 1;
+            g->n_partners = 0;
+            atomicAdd(n_done, 1u);
+        }
+        return 1;
+    }
+    const bool fast = sp_word != 0 && sp_word > mw_prev;
+    {
+        // the list lengths of all columns (needed for the matched columns only, after the substitution) and the latency model's table
+        const int clen0 = collen[tid < n_out ? tid : 0];
+        const bool want_log2 = (adder_size >= 0 || carry_size >= 0) && tid < (int)(sizeof(Log2Table) / 4);
+        const uint32_t l2w = want_log2 ? reinterpret_cast<const uint32_t *>(&c_log2)[tid] : 0u;
+        if (tid == 0) {
+            s_np = 0;
+            s_matches = 0;
+            g->mword[par] = 0;  // this step's update folds into it (last read by the selection of step - 1)
+        }
+        if (tid < n_out) {
+            s_clen[tid] = clen0;
+            s_cm[tid] = 0;
+            s_bpos[tid] = 0;
+        }
+        if (want_log2) reinterpret_cast<uint32_t *>(&s_log2)[tid] = l2w;
+        for (int j = tid + SEL_THREADS; j < n_out; j += SEL_THREADS) {
+            s_clen[j] = collen[j];
+            s_cm[j] = 0;
+            s_bpos[j] = 0;
+        }
+    }
+    SEL_TIMER_MARK(1)
+    // ---------------- (1) the pick: known from the descriptor, or awaited from the search block of this launch
+    if (!fast && wid == 0) {
+        if (lane == 0)
+            while (__hip_atomic_load(&g->pick_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != (unsigned int)step + 1u) __builtin_amdgcn_s_sleep(2);
+        __builtin_amdgcn_wave_barrier();
+        if (lane < 8) s_pick[lane] = __hip_atomic_load(reinterpret_cast<unsigned long long *>(&g->pick) + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    SEL_TIMER_MARK(2)
+    unsigned long long pk_word = sp_word, best_tie = sp_tie;
+    da_u2 refA = da_u2{sp_ax, sp_ay}, refB = da_u2{sp_bx, sp_by};
+    RowInfo ra = RowInfo{sp_ra0, sp_ra1, sp_ra2, sp_ra3}, rb = RowInfo{sp_rb0, sp_rb1, sp_rb2, sp_rb3};
+    if (!fast) {
+        pk_word = s_pick[0];
+        best_tie = s_pick[1];
+        refA = da_u2{(uint32_t)s_pick[2], (uint32_t)(s_pick[2] >> 32)};
+        refB = da_u2{(uint32_t)s_pick[3], (uint32_t)(s_pick[3] >> 32)};
+        ra = RowInfo{u2f((uint32_t)s_pick[4]), u2f((uint32_t)(s_pick[4] >> 32)), u2f((uint32_t)s_pick[5]), u2f((uint32_t)(s_pick[5] >> 32))};
+        rb = RowInfo{u2f((uint32_t)s_pick[6]), u2f((uint32_t)(s_pick[6] >> 32)), u2f((uint32_t)s_pick[7]), u2f((uint32_t)(s_pick[7] >> 32))};
+    }
+    const uint32_t Nw = (uint32_t)n_rows0;
+    if (pk_word == 0 || (int)Nw >= rcap) {
+        if (tid == 0) {
+            if (pk_word != 0) g->error = E_ROW_CAPACITY;
+            g->done = 1;
+            g->n_partners = 0;
+            atomicAdd(n_done, 1u);
+        }
+        return 1;
+    }
+    const uint32_t A = (uint32_t)((best_tie >> 7) & 0xFFFFFFu), B = (uint32_t)(best_tie >> 31);
+    const int idx = (int)(best_tie & 0x7F);
+    int shift, sub;
+    key_decode(idx, nb, shift, sub);
+    const bool same = A == B;
+
+    // ---------------- (2) new row record + substitution (as select_body)
+    const int lenA = (int)refA.y, lenB = (int)refB.y;
+    if (offN + (uint32_t)lenA > rl_cap) {  // the new row has at most lenA entries (cannot happen with the exact bound; guarded)
+        if (tid == 0) {
+            g->error = E_LIST_CAPACITY;
+            g->done = 1;
+            g->n_partners = 0;
+            atomicAdd(n_done, 1u);
+        }
+        return 1;
+    }
+    DA_GLOBAL Entry *rlA = rl + refA.x, *rlB = rl + refB.x, *rlN = rl + offN;
+    Entry eA0 = rl[tid < lenA ? refA.x + (uint32_t)tid : 0u], eB0 = rl[tid < lenB ? refB.x + (uint32_t)tid : 0u];
+    load_fence();
+    RowInfo rn = RowInfo{0.0f, 0.0f, 0.0f, 0.0f};
+    int derr = 0;
+    if (tid == 0) {  // arithmetic only, while the entries are in flight; the global stores follow once they have been consumed
+        qint_add_pair(ra, rb, shift, sub, rn.lo, rn.hi, rn.step);
+        float dlat = adder_dlat(ra, rb, shift, sub, adder_size, carry_size, s_log2, StepLog2{n_step_mant, step_mant, step_tab}, derr);
+        rn.lat = (ra.lat < rb.lat ? rb.lat : ra.lat) + dlat;
+        s_new = rn;
+    }
+    for (int k = tid; k < 6 * Kpad; k += SEL_THREADS) s_cnt[k] = 0;
+    if (tid >= lenA) eA0 = F::none();
+    if (same || tid >= lenB) eB0 = F::none();
+    pin_vgpr(eA0, eB0);  // both consumed (waited for) here, in front of thread 0's stores below
+    if (!same) {  // B's list into LDS, addressable by column (s_bpos was zeroed in the prologue, a barrier ago)
+        if (tid < lenB) {
+            s_bent[tid] = eB0;
+            s_bpos[F::col(eB0)] = tid + 1;
+        }
+        for (int t = tid + SEL_THREADS; t < lenB; t += SEL_THREADS) {
+            const Entry e = rlB[t];
+            s_bent[t] = e;
+            s_bpos[F::col(e)] = t + 1;
+        }
+    }
+    if (tid == 0) {  // (a wait for a loaded value also waits for every store issued before it: these come after the last one)
+        if (derr) g->error = E_FLOAT_DOMAIN;
+        store_row((DA_GLOBAL RowInfo *)c.rows, Nw, rn);
+        picks[iter] = da_i4{(int)A, (int)B, sub, shift};
+        if (n_live0 > live_peak0) g->live_peak = n_live0;
+    }
+    __syncthreads();
+    SEL_TIMER_MARK(3)
+    uint32_t *cAA = s_cnt, *cAB = s_cnt + Kpad, *cBB = s_cnt + 2 * Kpad, *cAN = s_cnt + 3 * Kpad, *cBN = s_cnt + 4 * Kpad,
+             *cNN = s_cnt + 5 * Kpad;
+    unsigned int my_matches = 0;
+    int m = 0;  // matched columns so far (block-uniform)
+    // pass 1: one thread per entry of A (ascending columns); the matched columns are compacted in column order, which
+    // is the order of the new row's list
+    for (int t0 = 0; t0 < lenA; t0 += SEL_THREADS) {
+        const int t = t0 + tid;
+        Cell a = 0, b = 0, ma = 0, mb = 0, na = 0, nbv = 0;
+        uint32_t colA = 0;
+        int pos = 0;
+        if (t < lenA) {
+            const Entry e = t0 == 0 ? eA0 : rlA[t];
+            colA = F::col(e);
+            a = F::cell(e);
+            if (same)
+                b = a;
+            else {
+                pos = s_bpos[colA];
+                b = pos ? F::cell(s_bent[pos - 1]) : (Cell)0;
+            }
+            if (a && b) substitute_column<Cell>(a, b, same, shift, sub, ma, mb);
+            na = same ? (Cell)(a & ~ma & ~mb) : (Cell)(a & ~ma);
+            nbv = b & ~mb;
+        }
+        const bool hit = ma != 0;
+        const unsigned long long bal = __ballot(hit);
+        if (lane == 0) s_part[wid] = __popcll(bal);
+        __syncthreads();
+        int wbase = 0, chunk = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            const int v = s_part[w];
+            wbase += w < wid ? v : 0;
+            chunk += v;
+        }
+        if (hit) {
+            const int at = m + wbase + __popcll(bal & ((1ull << lane) - 1));
+            rlA[t] = F::pack(colA, na);
+            if (!same) s_bent[pos - 1] = F::pack(colA, nbv);
+            rlN[at] = F::pack(colA, ma);
+            mcol[at] = (int)colA;
+            mA[at] = ma;
+            mB[at] = mb;
+            s_cm[colA] = at + 1;
+            {  // row bitmaps of this column: the new row enters, a row whose cell just lost its last digit leaves
+                DA_GLOBAL uint32_t *cb = colbits + (size_t)colA * cbw;
+                atomicOr(gen(&cb[Nw >> 5]), 1u << (Nw & 31));
+                if (na == 0) atomicAnd(gen(&cb[A >> 5]), ~(1u << (A & 31)));
+                if (!same && nbv == 0) atomicAnd(gen(&cb[B >> 5]), ~(1u << (B & 31)));
+            }
+            s_len[at] = s_clen[colA];  // the pre-append length: the new row itself is not a partner
+            s_col[at] = (int)colA;
+            my_matches += popc32(O::plus(ma) | O::minus(ma));
+        }
+        // ---------------- (3) exact recount of the pairs among {A, B, new} (their old blocks are replaced); the
+        // self pairs of B are counted in pass 2 (B may have columns A does not have)
+        if (na) for_pairs_self<Cell>(na, nb, [&](int k) { atomicAdd(&cAA[k], 1u); });
+        if (!same) {
+            if (na && nbv) for_pairs_cross<Cell>(na, nbv, nb, [&](int k) { atomicAdd(&cAB[k], 1u); });
+            if (nbv && ma) for_pairs_cross<Cell>(nbv, ma, nb, [&](int k) { atomicAdd(&cBN[k], 1u); });
+        }
+        if (na && ma) for_pairs_cross<Cell>(na, ma, nb, [&](int k) { atomicAdd(&cAN[k], 1u); });
+        if (ma) for_pairs_self<Cell>(ma, nb, [&](int k) { atomicAdd(&cNN[k], 1u); });
+        m += chunk;
+        __syncthreads();  // s_part is reused by the next chunk; s_bent updates visible to pass 2
+    }
+    if (my_matches) atomicAdd(&s_matches, my_matches);  // LDS; added to the chain's statistics by thread 0 at the end
+    // pass 2: B's list back to memory, self pairs of what is left of B
+    if (!same)
+        for (int t = tid; t < lenB; t += SEL_THREADS) {
+            const Entry e = s_bent[t];
+            rlB[t] = e;
+            const Cell nbv = F::cell(e);
+            if (nbv) for_pairs_self<Cell>(nbv, nb, [&](int k) { atomicAdd(&cBB[k], 1u); });
+        }
+    // the map column -> matched index for the update blocks (one coalesced copy; pass 1 has completed: its last barrier)
+    for (int j = tid; j < n_out; j += SEL_THREADS) cmap[j] = (uint16_t)s_cm[j];
+    // the new row joins the lists of its columns
+    {
+        const unsigned long long refN = ref_pack(Nw, (uint32_t)m, offN);
+        for (int k = tid; k < m; k += SEL_THREADS) {
+            const int j = s_col[k], len = s_len[k];
+            if (len < lcap) {
+                collist[(size_t)j * lcap + len] = refN;
+                collen[j] = len + 1;
+            } else
+                g->error = E_LIST_CAPACITY;
+        }
+    }
+    __syncthreads();
+    SEL_TIMER_MARK(4)
+    SEL_TIMER_MARK(5)
+    // the exact counts of the six pairs among {A, B, new}: to the special-pair block of k_iter_update (all counters are final: the barrier above)
+    for (int k = tid; k < 6 * Kpad; k += SEL_THREADS) sp_cnt[k] = s_cnt[k];
+    // ---------------- (4) partner rows -- the rows that have digits in a substituted column -- into the partner list:
+    // OR of those columns' row bitmaps (A, B and the new row masked out: their bits are being changed by this very kernel).  Word w
+    // of the OR covers rows 32 w ..; the set bits are counted (DPP prefix sum), one LDS atomic per wave reserves the places, the
+    // row ids stay in LDS; then, one thread per partner, the list reference is attached (a parallel gather from rowoff).
+    {
+        const DA_GLOBAL uint32_t *cb = colbits;
+        const int nwords = (int)((Nw + 31) >> 5);
+        DA_GLOBAL uint32_t *ids = pl_ids;
+        for (int wb = wid * WAVE; wb < nwords; wb += SEL_THREADS) {  // wave-uniform trip count
+            const int w = wb + lane;
+            uint32_t bits = 0;
+            if (w < nwords) {
+                for (int k = 0; k < m; ++k) bits |= cb[(size_t)s_col[k] * cbw + w];
+                if ((int)(A >> 5) == w) bits &= ~(1u << (A & 31));
+                if ((int)(B >> 5) == w) bits &= ~(1u << (B & 31));
+                if ((int)(Nw >> 5) == w) bits &= ~(1u << (Nw & 31));
+            }
+            const int cnt = popc32(bits), inc = (int)wave_scan_add_u32((uint32_t)cnt);  // inclusive prefix inside the wave (DPP)
+            const int wave_total = __builtin_amdgcn_readlane(inc, WAVE - 1);
+            if (wave_total == 0) continue;
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&s_np, wave_total);
+            int at = __builtin_amdgcn_readfirstlane(base) + inc - cnt;
+            while (bits) {
+                const uint32_t id = (uint32_t)(w << 5) + (uint32_t)ctz32(bits);
+                if (at < IDS_LDS)
+                    s_ids[at] = id;
+                else
+                    ids[at] = id;
+                ++at;
+                bits &= bits - 1;
+            }
+        }
+    }
+    SEL_TIMER_MARK(6)
+    __syncthreads();
+    {  // partner ids -> partner list entries (row id, list length, list offset)
+        const int np = s_np;
+        const DA_GLOBAL uint32_t *ids = pl_ids;
+        for (int t = tid; t < np; t += 2 * SEL_THREADS) {  // two partners per thread and pass, their look-ups in flight together
+            const int t2 = t + SEL_THREADS;
+            const bool has2 = t2 < np;
+            const uint32_t r1 = t < IDS_LDS ? s_ids[t] : ids[t];
+            const uint32_t r2 = !has2 ? r1 : t2 < IDS_LDS ? s_ids[t2] : ids[t2];
+            const da_u2 ro1 = rowoff[r1], ro2 = rowoff[r2];
+            load_fence();
+            plist[t] = ref_pack(r1, ro1.y, ro1.x);
+            if (has2) plist[t2] = ref_pack(r2, ro2.y, ro2.x);
+        }
+    }
+    SEL_TIMER_MARK(7)
+    if (tid == 0) {
+        SEL_TIMER_FLUSH
+        rowoff[Nw] = da_u2{offN, (uint32_t)m};
+        g->rl_used = offN + (uint32_t)m;
+        g->m = m;
+        g->n_partners = s_np;
+        // statistics: atomics without a return value (a plain += is load -> add -> store: one more round trip at the very end)
+        atomicAdd(&g->st_matches, (unsigned long long)s_matches);
+        atomicAdd(&g->st_partners, (unsigned long long)s_np);
+        atomicAdd(&g->st_cells, (unsigned long long)s_np * (unsigned)m);
+        if (fast) atomicAdd(&g->st_fast, 1ull);
+        {
+            // algorithmic bytes of this step's substitution block: the list lengths of all columns, the pick (64 B),
+            // both row lists read and written back, the row bitmaps of the m substituted columns, per partner its id + list reference +
+            // partner-list entry, the hand-off (matched columns, consumed digits, new row's list, column map, column-list and bitmap
+            // updates), the six special-pair count vectors.  (The search block's bytes: st_rescans, and 17 B per group, priced by the host.)
+            const unsigned long long eb = sizeof(Entry), cb = sizeof(Cell);
+            const unsigned long long nwords = (Nw + 31) >> 5;
+            atomicAdd(&g->st_sel_bytes, 4ull * (unsigned)n_out + 64ull + 2ull * eb * (unsigned)(lenA + (same ? 0 : lenB)) + 4ull * (unsigned)m * nwords + 20ull * (unsigned)s_np +
+                                            (unsigned)m * (4ull + 2ull * cb + eb + 8ull + 12ull) + 2ull * (unsigned)n_out + 6ull * 4ull * (unsigned)Kpad);
+        }
+        g->A = A;
+        g->B = B;
+        g->Nw = Nw;
+        g->n_rows = (int)Nw + 1;
+        g->iter = iter + 1;
+    }
+    return 0;
+}
+// grid (chains padded to a multiple of 8, 2): the chain index is the fast grid dimension, so that the two blocks of a chain and its
+// k_iter_update blocks run on the same XCD (update_body); y = 0 the search block, y = 1 the substitution block.  `step` = the
+// number of the lockstep iteration = the `iter` of every chain of the launch that has not finished (kernel argument: the search
+// block must not read a field the substitution block writes during the launch).
+template <class Cell> __global__ void __launch_bounds__(SEL_THREADS) k_iter_select2(ChainDev *chains, int n_chains, unsigned int *n_done, int step) {
+    if ((int)blockIdx.x >= n_chains) return;
+    if (blockIdx.y == 0)
+        search_body<Cell>(&chains[blockIdx.x], step);
+    else
+        (void)pick_body<Cell>(&chains[blockIdx.x], n_done, step);
+}
+
 #ifndef DA_UPD_OCC
 #define DA_UPD_OCC 5  // blocks of 256 threads per CU the register budget is capped for (88 VGPRs, no spills)
 #endif
@@ -1401,6 +2086,10 @@ template <class Cell> __device__ __forceinline__ UpdStep<Cell> load_upd_step(Cha
     u.done = gq->done, u.n_partners = gq->n_partners, u.m = gq->m, u.n_in = gq->n_in;
     u.A = gq->A, u.B = gq->B, u.Nw = gq->Nw;
     u.c = make_ctx_raw(gq, 2 * iter - 1);
+    // the step being applied is iter - 1 (the selection has counted it): its search left the entry the next selection would like to take
+    // unseen in spec[(iter - 1) & 1]; whatever this launch writes that reaches it is folded into mword[(iter - 1) & 1] (group_note)
+    u.c.rword = gq->spec[(iter - 1) & 1].word;
+    u.c.mw = &gq->mword[(iter - 1) & 1];
     u.mcol = (const DA_GLOBAL int *)gq->mcol;
     u.mA = (const DA_GLOBAL Cell *)gq->mA, u.mB = (const DA_GLOBAL Cell *)gq->mB;
     u.cmap = (const DA_GLOBAL uint16_t *)gq->cmap;
@@ -1408,6 +2097,7 @@ template <class Cell> __device__ __forceinline__ UpdStep<Cell> load_upd_step(Cha
     u.plist = (const DA_GLOBAL unsigned long long *)gq->plist;
     pin_sgpr(u.done, u.n_partners, iter, u.m, u.n_in, u.A, u.B, u.Nw, u.mcol, u.mA, u.mB, u.cmap, u.rl, u.plist);
     pin_sgpr(u.c.n_out, u.c.n_bits, u.c.K, u.c.Kpad, u.c.method, u.c.gs_log2, u.c.pb_log2, u.c.cmask, u.c.windows, u.c.hkey, u.c.hrank, u.c.hblk, u.c.ub, u.c.gdirty, u.c.rows);
+    pin_sgpr(u.c.rword, u.c.mw);
     u.c.tomb = KEY_TOMB - (unsigned long long)((2 * iter - 1) & 3);
     ctx_finish(u.c);
     return u;
@@ -1608,6 +2298,47 @@ __device__ __forceinline__ void update_partners(ChainDev *g, const UpdStep<Cell>
     UPD_TIMER_FLUSH
 }
 
+// special_pairs: the pairs among the rows a step modified -- (A,A), (A,B), (B,B): their blocks are re-counted from scratch; (A,N), (B,N),
+// (N,N): new -- from the exact counts the substitution block left in sp_cnt (select_body used to write them itself: the table is now
+// written by this kernel only).  One wavefront per pair.  The new best entry of every one of them is folded into mword whether it
+// changed or not: the search of the step leaves these three old blocks out of what it certifies (search_body).
+template <class Cell> __device__ __forceinline__ void special_pairs(ChainDev *gq, const UpdStep<Cell> &u) {
+    const Ctx &c = u.c;
+    const uint32_t A = u.A, B = u.B, Nw = u.Nw;
+    const bool same = A == B;
+    const DA_GLOBAL uint32_t *spc = (const DA_GLOBAL uint32_t *)gq->sp_cnt;
+    const RowInfo ra = load_row(c.rows, A), rb = load_row(c.rows, B), rn = load_row(c.rows, Nw);
+    const int lane = lane_id();
+    for (int sp = wave_id(); sp < 6; sp += UPD_WAVES) {
+        uint32_t lo = A, hi = A;
+        bool active = true, existed = false;
+        switch (sp) {
+        case 0: lo = A, hi = A, existed = true; break;
+        case 1: lo = A, hi = B, existed = true, active = !same; break;
+        case 2: lo = B, hi = B, existed = true, active = !same; break;
+        case 3: lo = A, hi = Nw; break;
+        case 4: lo = B, hi = Nw, active = !same; break;
+        default: lo = Nw, hi = Nw; break;
+        }
+        if (!active) continue;
+        const DA_GLOBAL uint32_t *cnt = spc + (size_t)sp * c.Kpad;
+        const unsigned long long key = pack_pair(lo, hi);
+        const int slot = existed ? table_find(c, key, hash_pair(lo, hi)) : -1;
+        unsigned long long w = 0;
+        if (slot >= 0)
+            w = table_update(c, slot, key, [&](int k, uint32_t) { return cnt[k]; });
+        else {
+            int f = 0;
+            for (int k = lane; k < c.K; k += WAVE) f |= cnt[k] >= 2u;
+            if (__any(f)) {
+                const RowInfo xa = pick_row(lo == Nw, rn, pick_row(lo == A, ra, rb)), xb = pick_row(hi == Nw, rn, pick_row(hi == A, ra, rb));
+                table_insert(c, lo, hi, xa, xb, [&](int k) { return cnt[k]; }, &w);
+            }
+        }
+        if (lane == 0 && c.rword && w >= c.rword) atomicMax(c.mw, w);
+    }
+}
+
 // update_body: the partner rows [block_y * NWV * QN + ..., stride grid_y * NWV * QN) of chain `gq`'s current step, by a
 // workgroup of NWV wavefronts (k_iter_update: 256-thread blocks, grid = chains x blocks per chain).
 template <class Cell, int NWV>
@@ -1619,6 +2350,11 @@ __device__ __forceinline__ void update_body(ChainDev *gq, bool in_range, int blo
     // non-coherent L2s instead of being spread over all of them.
     const UpdStep<Cell> u = load_upd_step<Cell>(gq);
     if (!in_range || u.done) return;
+    if (block_y == grid_y - 1) {  // the last block of a chain: the six blocks of the pairs among {A, B, new row}
+        special_pairs<Cell>(gq, u);
+        return;
+    }
+    grid_y -= 1;
     // the grid is sized for the partner counts of the first steps of a chain (thousands); later most blocks have nothing
     // to do and leave before the hand-off is copied
     if (block_y * (NWV * QN) >= u.n_partners) return;
@@ -2145,6 +2881,7 @@ size_t carve_chain(unsigned char *base, const ChainJob &job, const Geometry &g, 
     d.mA = c.take<unsigned char>(n_out * cell);
     d.mB = c.take<unsigned char>(n_out * cell);
     d.plist = c.take<unsigned long long>(g.rcap);
+    d.sp_cnt = c.take<uint32_t>((size_t)6 * g.Kpad);
     d.picks = c.take<int4>(g.rcap);
     d.fin_row = c.take<uint32_t>(n_out * (size_t)g.lcap);
     d.fin_cell = c.take<unsigned long long>(n_out * (size_t)g.lcap);
@@ -2403,9 +3140,9 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
     }
     if (sel_lds[0] > 150 * 1024 || sel_lds[1] > 150 * 1024) throw std::runtime_error("selection kernel needs more than 150 KiB of LDS (n_out too large)");
     if (ranges[0].count)
-        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_iter_select<uint32_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sel_lds[0]));
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_iter_select2<uint32_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sel_lds[0]));
     if (ranges[1].count)
-        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_iter_select<uint64_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sel_lds[1]));
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_iter_select2<uint64_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sel_lds[1]));
 
     HIP_CHECK(hipStreamSynchronize(st));
     lap("arena + init kernels");
@@ -2432,18 +3169,22 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
         }
     }
     // One greedy iteration of one group = (select, update) on the group's stream.
-    auto launch_pair = [&](const Group &gr, hipEvent_t *se) {
+    // `step` = the number of the lockstep iteration = the iteration count of every chain that has not finished (every launch pair advances
+    // each of them by one): a kernel argument, because the search block of the selection must not read a field its sibling writes
+    auto launch_pair = [&](const Group &gr, hipEvent_t *se, int step) {
         ChainDev *base = d_desc + gr.first;
+        const dim3 sel_grid((gr.count + 7) & ~7, 2);  // y = 0 search block, y = 1 substitution block
         if (se) HIP_CHECK(hipEventRecord(se[0], gr.stream));
         if (gr.w == 0)
-            hipLaunchKernelGGL(k_iter_select<uint32_t>, dim3(gr.count), dim3(SEL_THREADS), sel_lds[0], gr.stream, base, im.d_done);
+            hipLaunchKernelGGL(k_iter_select2<uint32_t>, sel_grid, dim3(SEL_THREADS), sel_lds[0], gr.stream, base, gr.count, im.d_done, step);
         else
-            hipLaunchKernelGGL(k_iter_select<uint64_t>, dim3(gr.count), dim3(SEL_THREADS), sel_lds[1], gr.stream, base, im.d_done);
+            hipLaunchKernelGGL(k_iter_select2<uint64_t>, sel_grid, dim3(SEL_THREADS), sel_lds[1], gr.stream, base, gr.count, im.d_done, step);
         if (se) HIP_CHECK(hipEventRecord(se[1], gr.stream));
+        // (+ 1: the last block of a chain writes the six blocks of the pairs among the modified rows)
         if (gr.w == 0)
-            hipLaunchKernelGGL(k_iter_update<uint32_t>, dim3((gr.count + 7) & ~7, upd_blocks[0]), dim3(UPD_THREADS), upd_lds[0], gr.stream, base, gr.count);
+            hipLaunchKernelGGL(k_iter_update<uint32_t>, dim3((gr.count + 7) & ~7, upd_blocks[0] + 1), dim3(UPD_THREADS), upd_lds[0], gr.stream, base, gr.count);
         else
-            hipLaunchKernelGGL(k_iter_update<uint64_t>, dim3((gr.count + 7) & ~7, upd_blocks[1]), dim3(UPD_THREADS), upd_lds[1], gr.stream, base, gr.count);
+            hipLaunchKernelGGL(k_iter_update<uint64_t>, dim3((gr.count + 7) & ~7, upd_blocks[1] + 1), dim3(UPD_THREADS), upd_lds[1], gr.stream, base, gr.count);
         if (se) HIP_CHECK(hipEventRecord(se[2], gr.stream));
     };
     // Windows of up to WINDOW_ITERS iterations x all groups are queued eagerly; one event-bracketed iteration per window
@@ -2493,12 +3234,12 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
                 }
                 ++n_samples;
             }
-            launch_pair(groups[gi], sample ? se : nullptr);
+            launch_pair(groups[gi], sample ? se : nullptr, (int)launched_iters);
         }
         // small problems finish within a few iterations: start with short windows, double up to the full length
         const int this_window = (int)std::min<long long>(WINDOW_ITERS, (8ll << std::min<long long>(window, 8)) - 1);
         for (int it = 0; it < this_window; ++it)
-            for (const Group &gr : groups) launch_pair(gr, nullptr);
+            for (const Group &gr : groups) launch_pair(gr, nullptr, (int)launched_iters + 1 + it);
         launched_iters += this_window + 1;
         HIP_CHECK(hipGetLastError());
         const int p = (int)(window & 1);
@@ -2671,6 +3412,8 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
         o.stats.partners = (long long)d.st_partners;
         o.stats.matches = (long long)d.st_matches;
         for (int q = 0; q < 12; ++q) im.timings.phase_cycles[q] += (double)d.st_phase[q];
+        for (int q = 0; q < 4; ++q) im.timings.search_cycles[q] += (double)d.st_qphase[q];
+        im.timings.fast_steps += (long long)d.st_fast;
         im.timings.found += (long long)d.st_found;
         im.timings.inserts += (long long)d.st_inserts;
         im.timings.cell_reads += (long long)d.st_cells;
@@ -2678,7 +3421,8 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
         im.timings.cell_bytes += (geo[i].wide ? 8.0 : 4.0) * (double)d.st_cells;
         im.timings.iterations += d.iter;
         im.timings.rescans += (long long)d.st_rescans;
-        im.timings.select_bytes += (double)d.st_sel_bytes + (double)d.st_rescans * ((double)(4u << d.gs_log2) + 24.0);  // + every re-read group: its ranks, ~2 tied slots' key and index
+        // + the search block: bound, dirty flag and tie word of every group per step, and per re-read group its ranks and ~2 slots' key and index
+        im.timings.select_bytes += (double)d.st_sel_bytes + 17.0 * (double)d.n_groups * (double)d.iter + (double)d.st_rescans * ((double)(4u << d.gs_log2) + 24.0);
         im.timings.partners += (long long)d.st_partners;
         im.timings.table_bytes += (double)d.C * (8.0 + 4.0 + (double)(1 << d.pb_log2));
     }

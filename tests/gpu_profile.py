@@ -18,4 +18,8 @@ its = max(tm['iterations'], 1); pa = max(tm['partners'], 1)
 print('select cycles/iteration:', {k: round(v / its) for k, v in ph.items() if k.startswith('sel_')})
 print('update cycles/partner  :', {k: round(v / pa) for k, v in ph.items() if k.startswith('upd_')}, 'partners/iter', round(pa / its), 'found/partner %.2f' % (tm['found'] / pa), 'inserts/partner %.3f' % (tm['inserts'] / pa))
 sm = max(tm['samples'], 1)
+print('picks known a step ahead: %.1f %% of %d steps; group re-reads per step %.2f' % (100.0 * tm['fast_steps'] / its, its, tm['rescans'] / its))
+if tm['search_steps_timed']:
+    q = tm['search_steps_timed']
+    print('search block cycles/step: bounds %.0f, arg-max (per step of ALL steps) %.0f, excluded search %.0f' % (tm['search_bounds'] / q, tm['search_argmax'] / q, tm['search_excluded'] / q))
 print('sampled per-launch: select %.1f us, update %.1f us, chains/launch %.1f' % (1e3 * tm['select_ms_sampled'] / sm, 1e3 * tm['update_ms_sampled'] / sm, tm['sampled_chain_launches'] / sm))
