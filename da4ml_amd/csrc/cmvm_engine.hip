@@ -204,6 +204,10 @@ struct SpecPick {
     RowInfo ra, rb;           // their records
 };
 static_assert(sizeof(SpecPick) == 64, "SpecPick is read as sixteen words");
+struct CandEntry {  // a table entry by value: selection rank and tie word (id1, id0, key index)
+    unsigned long long rank, tie;
+};
+constexpr int CAND_CAP = 16, TOUCH_CAP = 16;  // measured (tools/spec_probe.cc, 64 / 128 square): never more than 8 of either
 
 // Per-chain descriptor in device memory.  Pointers are raw device addresses into the arena.
 struct ChainDev {
@@ -279,9 +283,12 @@ struct ChainDev {
     unsigned long long st_phase[12];  // shader-clock cycles per kernel phase (select: 0-6, update: 7-11)
     // ---- the next pick, known one step ahead (k_iter_select2: search_body / pick_body)
     SpecPick spec[2];              // [t & 1]: the best entry of the table of step t that touches neither row of step t's pick -- step t
-                                   // does not change it --, left by the search block of step t for step t + 1 (word 0: not usable)
-    unsigned long long mword[2];   // [t & 1]: the largest bound word among the entries the update of step t wrote (only those >= spec[t & 1].word
-                                   // are folded in); zeroed by the selection of step t
+                                   // does not change it --, left by the search block of step t for step t + 1 (word 0: none, or l_list overflowed)
+    unsigned int c_n[2], l_n[2];   // [t & 1]: entries in c_list / l_list (c_n counts on past the capacity: an overflow is visible)
+    CandEntry c_list[2][CAND_CAP]; // [t & 1]: every entry that touches a row of step t's pick or its new row and whose bound word reaches
+                                   // spec[t & 1].word, as it stands AFTER step t: appended by the update of step t (zeroed by the selection of step t)
+    CandEntry l_list[2][TOUCH_CAP];// [t & 1]: the entries of the table of step t that touch exactly one row of the pick and reach spec[t & 1].word,
+                                   // listed by the search block: the update of step t passes on those it does not re-evaluate
     SpecPick pick;                 // a step that cannot use spec[]: the pick, found and published by the search block for the substitution block
     unsigned int pick_flag;        // t + 1 once `pick` holds the pick of step t
     uint32_t *sp_cnt;              // [6][Kpad] exact counts of the six pairs among {A, B, new row}: select -> update
@@ -386,8 +393,9 @@ struct Ctx {
     const DA_GLOBAL RowInfo *rows;
     ChainDev *g;  // derived from the kernel argument: already known to be global
     unsigned long long tomb;  // this launch's tombstone value
-    unsigned long long rword;  // k_iter_update: bound word of the entry the next selection would like to take unseen (0: none);
-    unsigned long long *mw;    // every entry written with a bound word >= rword is folded into *mw (group_note)
+    unsigned long long rword;  // k_iter_update: bound word of the best entry this step leaves untouched (0: none); the best entry of every block
+    unsigned int *cn;          // written or re-evaluated whose bound word reaches it is appended to cl[(*cn)++] (fold_entry): together with that
+    CandEntry *cl;             // entry they are all the next selection has to compare
 };
 
 // launch_id: 2 * iteration for k_iter_select, 2 * iteration + 1 for k_iter_update (only the low two bits are used)
@@ -411,7 +419,8 @@ __device__ __forceinline__ Ctx make_ctx_raw(ChainDev *g, int launch_id) {
     c.rows = (const DA_GLOBAL RowInfo *)g->rows;
     c.g = g;
     c.rword = 0;
-    c.mw = nullptr;
+    c.cn = nullptr;
+    c.cl = nullptr;
     return c;
 }
 __device__ __forceinline__ void ctx_finish(Ctx &c) { c.windows = c.windows / WAVE ? c.windows / WAVE : 1; }  // after the fields are pinned
@@ -484,8 +493,21 @@ __device__ __forceinline__ void group_note(const Ctx &c, int slot, unsigned long
     const int grp = slot >> c.gs_log2;
     if (w_new > w_old) atomicMax(gen(&c.ub[grp]), w_new);
     c.gdirty[grp] = 1;
-    if (c.rword && w_new >= c.rword) atomicMax(c.mw, w_new);  // a changed entry that the next pick would have to beat (rare by construction)
 }
+// one lane: the best entry (rank > 0) of a block as it stands after this launch -- a candidate for the next pick if it reaches the
+// entry the step leaves untouched (rare by construction: at most a handful per step)
+__device__ __forceinline__ void fold_entry(const Ctx &c, uint32_t rank, unsigned long long tie) {
+    if (c.rword && bound_word(rank, tie) >= c.rword) {
+        const unsigned int at = atomicAdd(c.cn, 1u);
+        if (at < (unsigned int)CAND_CAP) {
+            c.cl[at].rank = rank;
+            c.cl[at].tie = tie;
+        }
+    }
+}
+// best-key index of every slot as a dense byte array behind hrank (the selection's search reads ranks, keys and indices of a whole
+// group in one round trip; the copy in the payload header is what the update kernel reads with the counts)
+__device__ __forceinline__ DA_GLOBAL uint8_t *hidx_ptr(const Ctx &c) { return reinterpret_cast<DA_GLOBAL uint8_t *>(c.hrank + ((size_t)c.cmask + 1)); }
 
 // Store a complete block.  cnt_of(k) gives the count of key k; returns false when the table is full.
 // Precondition: at least one count >= 2 (checked by the caller), key absent.  ra / rb: intervals of rows lo / hi.
@@ -517,7 +539,11 @@ __device__ bool table_insert(const Ctx &c, uint32_t lo, uint32_t hi, const RowIn
         uint32_t rank = (uint32_t)(best >> 8), idx = (uint32_t)(best & 0xFF);
         store_hdr(c, slot, ov, dl, rank, idx);
         c.hrank[slot] = rank;
-        if (rank) group_note(c, slot, 0ull, bound_word(rank, tie_word(lo, hi, (int)idx)));
+        hidx_ptr(c)[slot] = (uint8_t)idx;
+        if (rank) {
+            group_note(c, slot, 0ull, bound_word(rank, tie_word(lo, hi, (int)idx)));
+            fold_entry(c, rank, tie_word(lo, hi, (int)idx));
+        }
         atomicAdd(&c.g->n_live, 1u);  // no return value: fire-and-forget (the peak is sampled by k_iter_select)
     }
     return true;
@@ -536,8 +562,10 @@ __device__ __forceinline__ void block_commit(const Ctx &c, int slot, unsigned lo
     const uint32_t rank = (uint32_t)(best >> 8), idx = (uint32_t)(best & 0xFF);
     if (rank != h.rank) c.hrank[slot] = rank;
     if (rank != h.rank || idx != h.idx) store_best(c, slot, rank, idx);
+    if (idx != h.idx) hidx_ptr(c)[slot] = (uint8_t)idx;
     if (rank != h.rank || (rank && idx != h.idx))
         group_note(c, slot, w_old, rank ? bound_word(rank, tie_word((uint32_t)key, (uint32_t)(key >> 32), (int)idx)) : 0ull);
+    if (rank) fold_entry(c, rank, tie_word((uint32_t)key, (uint32_t)(key >> 32), (int)idx));  // changed or not: the block touches a row of the step
 }
 
 // Re-evaluate a block after its counts changed (new_cnt(k, old) -> new count); deletes it when no count >= 2.
@@ -1385,23 +1413,26 @@ template <class Cell, bool SHARDED = false> __global__ void __launch_bounds__(SE
 // ================================================================================= k_iter_select2: the next pick, one step ahead
 // A greedy step changes only table entries that touch the two rows of its pick (A, B) or the row it creates (N).  So the
 // best entry R_t of the table of step t that touches neither A_t nor B_t is still in the table of step t + 1, unchanged, and
-// the pick of step t + 1 is the larger of R_t and the best entry touching A_t, B_t or N_t.  The selection of a step is split
-// into two workgroups per chain that run side by side:
-//   * the SEARCH block (search_body, blockIdx.y == 0) looks for R_t -- the lazy arg-max over the group bounds with A_t / B_t
-//     excluded -- and for V_t, the best entry that touches exactly one of A_t / B_t (its value BEFORE step t's update).  It
-//     leaves R_t in spec[t & 1] if R_t beats V_t, "none" otherwise;
-//   * the update of step t folds every entry it writes whose bound word reaches R_t's into mword[t & 1] (group_note; the
-//     blocks of the three pairs among {A, B} are folded in whether they changed or not: they are not covered by V_t);
-//   * the SUBSTITUTION block (pick_body, blockIdx.y == 1) of step t + 1 takes R_t as its pick when spec[t & 1].word >
-//     mword[t & 1] -- no bounds, no arg-max in front of the substitution -- and waits for the search block to publish the
-//     pick otherwise (which then runs the arg-max first, as k_iter_select did, and its search afterwards).
-// Exactness: an entry of the table of step t + 1 is (i) untouched by step t: at most R_t; (ii) touches A_t or B_t and was
-// re-evaluated with a changed best (rank, key), or is new: folded into mword if it reaches R_t; (iii) touches A_t or B_t,
-// best (rank, key) unchanged: at most V_t < R_t, or one of the three special blocks: folded.  Bound words drop the low 23 bits
-// of the tie word, so equal words are treated as "cannot tell" (the step takes the slow path).
+// the pick of step t + 1 is the largest of R_t and the entries that touch A_t, B_t or N_t.  Of those only the ones that reach
+// R_t matter, and there are hardly ever any (tools/spec_probe.cc: none in 88 % of the steps, never more than 8).  The selection
+// of a step is split into two workgroups per chain that run side by side:
+//   * the SEARCH block (search_body, blockIdx.y == 0) looks for R_t -- the lazy arg-max over the group bounds with the entries
+//     of A_t / B_t left out -- and lists the entries that touch exactly one of A_t / B_t and reach R_t (l_list): spec[t & 1];
+//   * the update of step t appends the best entry of every block it writes or re-evaluates (partner blocks, the six blocks among
+//     {A, B, N}) that reaches R_t to c_list[t & 1], changed or not (fold_entry), and passes on the entries of l_list whose block
+//     it does not visit (the other row is not a partner row: the entry is unchanged);
+//   * the SUBSTITUTION block (pick_body, blockIdx.y == 1) of step t + 1 takes the largest of R_t and c_list[t & 1] as its pick:
+//     no bounds, no arg-max in front of the substitution.  Only when there is no R_t or a list overflowed does it wait for the
+//     search block, which then runs the arg-max first (as k_iter_select did), publishes the pick, and searches afterwards.
+// Exactness: an entry of the table of step t + 1 either touches none of A_t, B_t, N_t -- then it is at most R_t --, or its block
+// was written / re-evaluated by the update -- then its best entry is in c_list if it reaches R_t --, or it touches A_t or B_t
+// and its block was not visited -- then it is unchanged since the search saw it, and in l_list -> c_list if it reaches R_t.
+// "Reaches" is decided on bound words (rank << 32 | tie >> 23), which order coarser than (rank, tie): a superset; the pick is
+// the maximum by (rank, tie) of the listed entries and R_t.
 // Only the search block reads or writes group bounds; the table itself is not written by this kernel at all (the six special
 // blocks moved to k_iter_update), so the two blocks share nothing but the descriptor fields named above.
 constexpr uint32_t ROW_NONE = 0xFFFFFFFFu;
+constexpr int QL_CAP = 64;  // entries touching the pick's rows the search may meet above its rising floor before it gives up (LDS)
 
 #ifdef DA_PHASE_TIMERS
 #define Q_TIMER_DECL long long qp[4];
@@ -1411,27 +1442,59 @@ constexpr uint32_t ROW_NONE = 0xFFFFFFFFu;
 #define Q_TIMER_MARK(i)
 #endif
 
+// The pick of a step from what the previous step left: the best entry it did not touch (spec) against the candidates its update
+// listed.  Every wave computes the same (one round trip when there are candidates, none otherwise).  false: no such entry, or a list
+// overflowed -- the step finds its pick the long way.
+__device__ __forceinline__ bool resolve_pick(const DA_GLOBAL CandEntry *cl, unsigned long long sp_word, unsigned long long sp_tie, unsigned int cn, unsigned long long &tie,
+                                             bool &from_spec) {
+    tie = sp_tie;
+    from_spec = true;
+    if (sp_word == 0 || cn > (unsigned int)CAND_CAP) return false;
+    if (cn) {
+        const int lane = lane_id();
+        uint32_t r = 0;
+        unsigned long long t = 0;
+        if (lane < (int)cn) {
+            r = (uint32_t)cl[lane].rank;
+            t = cl[lane].tie;
+        }
+        const uint32_t br = wave_max_u32(r);
+        const unsigned long long bt = wave_max_u64(r == br ? t : 0ull);
+        const uint32_t rr = (uint32_t)(sp_word >> 32);
+        if (br > rr || (br == rr && bt > sp_tie)) {
+            tie = bt;
+            from_spec = false;
+        }
+    }
+    return true;
+}
+
 template <class Cell> __device__ __forceinline__ void search_body(ChainDev *g, int step) {
     constexpr int NW = SEL_THREADS / WAVE;
     const int par = step & 1;
     int was_done = g->done, had_error = g->error, n_groups = g->n_groups;
-    unsigned long long sp_word = g->spec[par ^ 1].word, sp_tie = g->spec[par ^ 1].tie, mw_prev = g->mword[par ^ 1];
+    unsigned long long sp_word = g->spec[par ^ 1].word, sp_tie = g->spec[par ^ 1].tie;
+    unsigned int cn_prev = g->c_n[par ^ 1];
     Ctx c = make_ctx_raw(g, 2 * step);
     DA_GLOBAL unsigned long long *gtie_arr = (DA_GLOBAL unsigned long long *)g->gtie;
     const DA_GLOBAL da_u2 *rowoff = (const DA_GLOBAL da_u2 *)g->rowoff;
-    pin_sgpr(was_done, had_error, n_groups, sp_word, sp_tie, mw_prev);
-    pin_sgpr(c.gs_log2, c.pb_log2, c.hkey, c.hrank, c.hblk, c.ub, c.gdirty, c.rows);
-    pin_sgpr(gtie_arr, rowoff);
+    const DA_GLOBAL CandEntry *cl_prev = (const DA_GLOBAL CandEntry *)&g->c_list[par ^ 1][0];
+    DA_GLOBAL CandEntry *ll_out = (DA_GLOBAL CandEntry *)&g->l_list[par][0];
+    pin_sgpr(was_done, had_error, n_groups, sp_word, sp_tie, cn_prev);
+    pin_sgpr(c.gs_log2, c.cmask, c.hkey, c.hrank, c.ub, c.gdirty, c.rows);
+    pin_sgpr(gtie_arr, rowoff, cl_prev, ll_out);
     if (was_done || had_error != E_OK) return;  // (the substitution block stops the chain)
-    const bool fast = sp_word != 0 && sp_word > mw_prev;
-    __shared__ unsigned long long q_floor, q_red_tie[NW], q_red_vtie[NW];
-    __shared__ uint32_t q_red_rank[NW], q_red_vrank[NW];
+    __shared__ unsigned long long q_floor, q_red_tie[NW];
+    __shared__ uint32_t q_red_rank[NW];
+    __shared__ CandEntry q_L[QL_CAP];
+    __shared__ unsigned int q_Ln, q_Lout;
     const int tid = threadIdx.x, lane = lane_id(), wid = wave_id();
     const int gs = 1 << c.gs_log2;
+    const DA_GLOBAL uint8_t *hidx = hidx_ptr(c);
     Q_TIMER_DECL
     Q_TIMER_MARK(0)
     // ---- ONE vector round trip: bound, dirty flag and stored tie word of this lane's (up to four) groups (wave w owns the groups
-    // [w * GPW, (w + 1) * GPW)); unconditional loads, index clamped (see select_body)
+    // [w * GPW, (w + 1) * GPW)); unconditional loads, index clamped (see select_body); the candidates of the previous update with them
     const int GPW = (n_groups + NW - 1) / NW;
     unsigned long long ubr[4], gtr[4];
     int dr[4];  // 0 clean (bound and tie word exact), 1 dirty, 3 absent, 4 read in this pass, 5 clean but its best entry touches an excluded row
@@ -1453,20 +1516,29 @@ template <class Cell> __device__ __forceinline__ void search_body(ChainDev *g, i
             dr[u] = in[u] ? (dv[u] ? 1 : 0) : 3;
         }
     }
+    unsigned long long pk_tie;
+    bool from_spec;
+    const bool fast = resolve_pick(cl_prev, sp_word, sp_tie, cn_prev, pk_tie, from_spec);
     Q_TIMER_MARK(1)
     uint32_t exA = ROW_NONE, exB = ROW_NONE;  // rows whose entries the pass leaves out
     if (fast) {
-        exA = (uint32_t)((sp_tie >> 7) & 0xFFFFFFu);
-        exB = (uint32_t)(sp_tie >> 31);
+        exA = (uint32_t)((pk_tie >> 7) & 0xFFFFFFu);
+        exB = (uint32_t)(pk_tie >> 31);
     }
     unsigned int rescans = 0;
     for (int pass = fast ? 1 : 0; pass < 2; ++pass) {
         // pass 0 (only when the pick is not known yet): the arg-max over the whole table -> the pick, published for the substitution block;
-        // pass 1: the same with the entries of the pick's rows left out -> R (and V, the best entry touching exactly one of the rows)
-        if (tid == 0) q_floor = 0;
-        uint32_t nr = 0, vr = 0;  // this lane's best candidates so far: outside / touching the excluded rows
-        unsigned long long nt = 0, vt = 0;
-        auto offer = [&](uint32_t r, unsigned long long tw) -> unsigned long long {  // returns the bound word if the entry counts towards the floor
+        // pass 1: the same with the entries of the pick's rows left out -> R; the entries that touch exactly one of the rows and reach the
+        // floor of the moment are collected on the way (q_L)
+        if (tid == 0) {
+            q_floor = 0;
+            q_Ln = 0;
+            q_Lout = 0;
+        }
+        uint32_t nr = 0;  // this lane's best entry so far outside the excluded rows
+        unsigned long long nt = 0;
+        // returns the entry's bound word if it counts towards the floor, else 0; fl = the floor at the time (entries of the excluded rows are listed from there on)
+        auto offer = [&](uint32_t r, unsigned long long tw, unsigned long long fl, bool list) -> unsigned long long {
             const uint32_t i0 = (uint32_t)((tw >> 7) & 0xFFFFFFu), i1 = (uint32_t)(tw >> 31);
             const bool t0 = i0 == exA || i0 == exB, t1 = i1 == exA || i1 == exB;
             if (!(t0 || t1)) {
@@ -1476,9 +1548,9 @@ template <class Cell> __device__ __forceinline__ void search_body(ChainDev *g, i
                 }
                 return bound_word(r, tw);
             }
-            if (!(t0 && t1) && (r > vr || (r == vr && tw > vt))) {
-                vr = r;
-                vt = tw;
+            if (list && t0 != t1 && bound_word(r, tw) >= fl) {
+                const unsigned int at = atomicAdd(&q_Ln, 1u);
+                if (at < (unsigned int)QL_CAP) q_L[at] = CandEntry{(unsigned long long)r, tw};
             }
             return 0ull;
         };
@@ -1487,7 +1559,7 @@ template <class Cell> __device__ __forceinline__ void search_body(ChainDev *g, i
         for (int u = 0; u < 4; ++u) {
             if (dr[u] == 4 || dr[u] == 5) dr[u] = 0;  // read (and, if it was dirty, verified) in the previous pass: exact values in the registers
             if (dr[u] == 0 && (uint32_t)(ubr[u] >> 32) != 0) {
-                const unsigned long long w = offer((uint32_t)(ubr[u] >> 32), gtr[u]);
+                const unsigned long long w = offer((uint32_t)(ubr[u] >> 32), gtr[u], 0ull, false);  // (an excluded best entry is listed when its group is read)
                 if (w)
                     cl = max(cl, w);
                 else
@@ -1517,54 +1589,50 @@ template <class Cell> __device__ __forceinline__ void search_body(ChainDev *g, i
             const int own_u = __builtin_amdgcn_readlane(top_u, owner);
             const bool own_dirty = __builtin_amdgcn_readlane(top_s, owner) == 1;
             const uint32_t grp = (uint32_t)(wid * GPW + owner + own_u * WAVE), base = grp * gs;
-            uint32_t rk[8], grank = 0;
+            // ---- ONE round trip: rank, key and best-key index of every slot of the group (dense arrays, coalesced; up to 8 slots per lane)
+            uint32_t rk[8], bi[8], grank = 0;
+            unsigned long long kk[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int o = lane + u * WAVE;
-                rk[u] = o < gs ? c.hrank[base + o] : 0u;
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) grank = max(grank, rk[u]);
-            for (int o = lane + 8 * WAVE; o < gs; o += WAVE) grank = max(grank, c.hrank[base + o]);
-            grank = wave_max_u32(grank);
-            // keys and best-key indices of every slot whose rank reaches the floor's (the floor's own rank included: the tie word decides)
-            const uint32_t fr = (uint32_t)(fl >> 32), thr = fr ? fr : 1u;
-            unsigned long long kk[8], gt = 0, lw = 0;
-            uint32_t bi[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int o = lane + u * WAVE;
-                kk[u] = 0;
-                bi[u] = 0;
-                if (o < gs && rk[u] >= thr) {
-                    kk[u] = c.hkey[base + o];
-                    bi[u] = load_best_idx(c, base + o);
-                }
+                const uint32_t sl = base + (o < gs ? o : 0);
+                rk[u] = c.hrank[sl];
+                kk[u] = c.hkey[sl];
+                bi[u] = hidx[sl];
             }
             load_fence();
 #pragma unroll
-            for (int u = 0; u < 8; ++u) pin_vgpr(kk[u], bi[u]);
-#pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int o = lane + u * WAVE;
-                if (o < gs && rk[u] >= thr) {
-                    const unsigned long long tw = tie_word((uint32_t)kk[u], (uint32_t)(kk[u] >> 32), (int)bi[u]);
-                    if (rk[u] == grank) gt = tw > gt ? tw : gt;
-                    lw = max(lw, offer(rk[u], tw));
-                }
+                pin_vgpr(rk[u], kk[u], bi[u]);
+                if (lane + u * WAVE >= gs) rk[u] = 0;
+                grank = max(grank, rk[u]);
             }
-            for (int o = lane + 8 * WAVE; o < gs; o += WAVE) {
-                const uint32_t r2 = c.hrank[base + o];
-                if (r2 >= thr) {
-                    const unsigned long long k2 = c.hkey[base + o];
-                    const unsigned long long tw = tie_word((uint32_t)k2, (uint32_t)(k2 >> 32), (int)load_best_idx(c, base + o));
-                    if (r2 == grank) gt = tw > gt ? tw : gt;
-                    lw = max(lw, offer(r2, tw));
+            for (int o = lane + 8 * WAVE; o < gs; o += WAVE) grank = max(grank, c.hrank[base + o]);
+            grank = wave_max_u32(grank);
+            // only slots whose rank reaches the floor's can matter (the floor's own rank included: the tie word decides)
+            const uint32_t fr = (uint32_t)(fl >> 32), thr = fr ? fr : 1u;
+            unsigned long long gt = 0, lw = 0;
+            if (grank >= thr) {  // (wave-uniform: a group whose stale bound promised more than it holds costs nothing beyond the ranks)
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (rk[u] >= thr) {
+                        const unsigned long long tw = tie_word((uint32_t)kk[u], (uint32_t)(kk[u] >> 32), (int)bi[u]);
+                        if (rk[u] == grank) gt = tw > gt ? tw : gt;
+                        lw = max(lw, offer(rk[u], tw, fl, pass != 0));
+                    }
+                for (int o = lane + 8 * WAVE; o < gs; o += WAVE) {
+                    const uint32_t r2 = c.hrank[base + o];
+                    if (r2 >= thr) {
+                        const unsigned long long k2 = c.hkey[base + o];
+                        const unsigned long long tw = tie_word((uint32_t)k2, (uint32_t)(k2 >> 32), (int)hidx[base + o]);
+                        if (r2 == grank) gt = tw > gt ? tw : gt;
+                        lw = max(lw, offer(r2, tw, fl, pass != 0));
+                    }
                 }
+                if (lw > fl) atomicMax(&q_floor, lw);
             }
-            if (lw > fl) atomicMax(&q_floor, lw);
             if (own_dirty) {
-                // tighten the group's bound.  Its best entry is known exactly when its rank reaches the floor's (the keys were read):
+                // tighten the group's bound.  Its best entry is known exactly when its rank reaches the floor's (the tie words were formed):
                 // the group becomes clean; otherwise (rank below the floor's) the bound drops to "that rank, any key" and the group stays dirty
                 const bool exact_known = grank >= thr || grank == 0;
                 if (exact_known) gt = wave_max_u64(gt);
@@ -1594,9 +1662,9 @@ template <class Cell> __device__ __forceinline__ void search_body(ChainDev *g, i
             ++rescans;
             lds_fence();
         }
-        // the wave's best entry outside / touching the excluded rows (highest rank, then highest tie word among its holders)
-        const uint32_t wnr = wave_max_u32(nr), wvr = wave_max_u32(vr);
-        const unsigned long long wnt = wave_max_u64(nr == wnr ? nt : 0ull), wvt = wave_max_u64(vr == wvr ? vt : 0ull);
+        // the wave's best entry outside the excluded rows (highest rank, then highest tie word among its holders)
+        const uint32_t wnr = wave_max_u32(nr);
+        const unsigned long long wnt = wave_max_u64(nr == wnr ? nt : 0ull);
         // every wave fetches list references and records of ITS candidate's rows now (in flight across the reduction)
         const uint32_t cA = wnr ? (uint32_t)((wnt >> 7) & 0xFFFFFFu) : 0u, cB = wnr ? (uint32_t)(wnt >> 31) : 0u;
         const RowInfo cand_ra = load_row(c.rows, cA), cand_rb = load_row(c.rows, cB);
@@ -1604,19 +1672,15 @@ template <class Cell> __device__ __forceinline__ void search_body(ChainDev *g, i
         if (lane == 0) {
             q_red_rank[wid] = wnr;
             q_red_tie[wid] = wnt;
-            q_red_vrank[wid] = wvr;
-            q_red_vtie[wid] = wvt;
         }
         __syncthreads();
-        uint32_t best_rank, v_rank;
-        unsigned long long best_tie, v_tie;
+        uint32_t best_rank;
+        unsigned long long best_tie;
         {
-            const uint32_t r = lane < NW ? q_red_rank[lane] : 0u, r2 = lane < NW ? q_red_vrank[lane] : 0u;
-            const unsigned long long t = lane < NW ? q_red_tie[lane] : 0ull, t2 = lane < NW ? q_red_vtie[lane] : 0ull;
+            const uint32_t r = lane < NW ? q_red_rank[lane] : 0u;
+            const unsigned long long t = lane < NW ? q_red_tie[lane] : 0ull;
             best_rank = wave_max_u32(r);
             best_tie = wave_max_u64(r == best_rank ? t : 0ull);
-            v_rank = wave_max_u32(r2);
-            v_tie = wave_max_u64(r2 == v_rank ? t2 : 0ull);
         }
         const bool mine = best_rank != 0 && wnr == best_rank && wnt == best_tie;  // exactly one wave holds the winner (tie words are unique)
         if (pass == 0) {
@@ -1627,6 +1691,7 @@ template <class Cell> __device__ __forceinline__ void search_body(ChainDev *g, i
                     __hip_atomic_store(&g->pick.word, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __hip_atomic_store(&g->pick_flag, (unsigned int)step + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
                     g->spec[par].word = 0;
+                    g->l_n[par] = 0;
                 }
                 if (lane == 0 && rescans) atomicAdd(&g->st_rescans, (unsigned long long)rescans);
                 return;  // the table holds nothing selectable: the chain ends
@@ -1648,19 +1713,39 @@ template <class Cell> __device__ __forceinline__ void search_body(ChainDev *g, i
             exA = (uint32_t)((best_tie >> 7) & 0xFFFFFFu);
             exB = (uint32_t)(best_tie >> 31);
         } else {
-            // R for the next step: usable only if it beats every entry that touches exactly one of the pick's rows (their values may change)
-            const bool usable = best_rank != 0 && (v_rank == 0 || best_rank > v_rank || (best_rank == v_rank && best_tie > v_tie));
+            // R for the next step, and with it the entries of the pick's rows that reach it (all scans ended before the barrier above: q_Ln is final)
+            const unsigned long long r0 = best_rank ? bound_word(best_rank, best_tie) : 0ull;
+            const unsigned int met = q_Ln;
+            if (best_rank != 0 && met != 0 && met <= (unsigned int)QL_CAP) {  // (block-uniform)
+                if (tid < (int)met) {
+                    const CandEntry e = q_L[tid];
+                    if (bound_word((uint32_t)e.rank, e.tie) >= r0) {
+                        const unsigned int at = atomicAdd(&q_Lout, 1u);
+                        if (at < (unsigned int)TOUCH_CAP) {
+                            ll_out[at].rank = e.rank;
+                            ll_out[at].tie = e.tie;
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+            const unsigned int kept = q_Lout;
+            const bool usable = best_rank != 0 && met <= (unsigned int)QL_CAP && kept <= (unsigned int)TOUCH_CAP;
             if (best_rank == 0) {
-                if (tid == 0) g->spec[par].word = 0;
+                if (tid == 0) {
+                    g->spec[par].word = 0;
+                    g->l_n[par] = 0;
+                }
             } else if (mine && lane == 0) {
                 SpecPick sp;
-                sp.word = usable ? bound_word(best_rank, best_tie) : 0ull;
+                sp.word = usable ? r0 : 0ull;
                 sp.tie = best_tie;
                 sp.refA = cand_refA;
                 sp.refB = cand_refB;
                 sp.ra = cand_ra;
                 sp.rb = cand_rb;
                 g->spec[par] = sp;
+                g->l_n[par] = usable ? kept : 0u;
             }
         }
     }
@@ -1692,7 +1777,9 @@ template <class Cell> __device__ __forceinline__ int pick_body(ChainDev *g, unsi
     const uint32_t *step_mant = g->step_mant;
     const float *step_tab = g->step_tab;
     int n_step_mant = g->n_step_mant;
-    unsigned long long sp_word = g->spec[par ^ 1].word, sp_tie = g->spec[par ^ 1].tie, mw_prev = g->mword[par ^ 1];
+    unsigned long long sp_word = g->spec[par ^ 1].word, sp_tie = g->spec[par ^ 1].tie;
+    unsigned int cn_prev = g->c_n[par ^ 1];
+    const DA_GLOBAL CandEntry *cl_prev = (const DA_GLOBAL CandEntry *)&g->c_list[par ^ 1][0];
     uint32_t sp_ax = g->spec[par ^ 1].refA.x, sp_ay = g->spec[par ^ 1].refA.y, sp_bx = g->spec[par ^ 1].refB.x, sp_by = g->spec[par ^ 1].refB.y;
     float sp_ra0 = g->spec[par ^ 1].ra.lo, sp_ra1 = g->spec[par ^ 1].ra.hi, sp_ra2 = g->spec[par ^ 1].ra.step, sp_ra3 = g->spec[par ^ 1].ra.lat;
     float sp_rb0 = g->spec[par ^ 1].rb.lo, sp_rb1 = g->spec[par ^ 1].rb.hi, sp_rb2 = g->spec[par ^ 1].rb.step, sp_rb3 = g->spec[par ^ 1].rb.lat;
@@ -1710,7 +1797,7 @@ template <class Cell> __device__ __forceinline__ int pick_body(ChainDev *g, unsi
     DA_GLOBAL da_i4 *picks = (DA_GLOBAL da_i4 *)g->picks;
     DA_GLOBAL uint32_t *sp_cnt = (DA_GLOBAL uint32_t *)g->sp_cnt;
     pin_sgpr(was_done, had_error, lcap, n_rows0, rcap, cbw, adder_size, carry_size, offN, rl_cap, n_live0, live_peak0, step_mant, step_tab, n_step_mant);
-    pin_sgpr(sp_word, sp_tie, mw_prev, sp_ax, sp_ay, sp_bx, sp_by, sp_ra0, sp_ra1, sp_ra2, sp_ra3, sp_rb0, sp_rb1, sp_rb2, sp_rb3);
+    pin_sgpr(sp_word, sp_tie, cn_prev, cl_prev, sp_ax, sp_ay, sp_bx, sp_by, sp_ra0, sp_ra1, sp_ra2, sp_ra3, sp_rb0, sp_rb1, sp_rb2, sp_rb3);
     pin_sgpr(c.n_out, c.n_bits, c.K, c.Kpad, c.rows);
     pin_sgpr(collen, rowoff, rl, mA, mB, mcol, collist, cmap, colbits, pl_ids, plist, picks, sp_cnt);
     const int n_out = c.n_out, Kpad = c.Kpad, nb = c.n_bits;
@@ -1745,7 +1832,20 @@ template <class Cell> __device__ __forceinline__ int pick_body(ChainDev *g, unsi
         }
         return 1;
     }
-    const bool fast = sp_word != 0 && sp_word > mw_prev;
+    // ---------------- (1) the pick: the best of what the previous step left (its untouched entry against the entries its update listed), or --
+    // when it left nothing usable -- awaited from the search block of this launch
+    unsigned long long best_tie;
+    bool from_spec;
+    const bool fast = resolve_pick(cl_prev, sp_word, sp_tie, cn_prev, best_tie, from_spec);
+    uint32_t A = (uint32_t)((best_tie >> 7) & 0xFFFFFFu), B = (uint32_t)(best_tie >> 31);
+    da_u2 refA = da_u2{sp_ax, sp_ay}, refB = da_u2{sp_bx, sp_by};
+    RowInfo ra = RowInfo{sp_ra0, sp_ra1, sp_ra2, sp_ra3}, rb = RowInfo{sp_rb0, sp_rb1, sp_rb2, sp_rb3};
+    if (fast && !from_spec) {  // (block-uniform) a listed entry won: its rows' list references and records (one round trip, broadcast loads)
+        refA = rowoff[A];
+        refB = rowoff[B];
+        ra = load_row(c.rows, A);
+        rb = load_row(c.rows, B);
+    }
     {
         // the list lengths of all columns (needed for the matched columns only, after the substitution) and the latency model's table
         const int clen0 = collen[tid < n_out ? tid : 0];
@@ -1754,7 +1854,7 @@ template <class Cell> __device__ __forceinline__ int pick_body(ChainDev *g, unsi
         if (tid == 0) {
             s_np = 0;
             s_matches = 0;
-            g->mword[par] = 0;  // this step's update folds into it (last read by the selection of step - 1)
+            g->c_n[par] = 0;  // this step's update appends to c_list[par] (last read by the selection of step - 1)
         }
         if (tid < n_out) {
             s_clen[tid] = clen0;
@@ -1769,18 +1869,30 @@ template <class Cell> __device__ __forceinline__ int pick_body(ChainDev *g, unsi
         }
     }
     SEL_TIMER_MARK(1)
-    // ---------------- (1) the pick: known from the descriptor, or awaited from the search block of this launch
     if (!fast && wid == 0) {
-        if (lane == 0)
-            while (__hip_atomic_load(&g->pick_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != (unsigned int)step + 1u) __builtin_amdgcn_s_sleep(2);
+        // (the search block of this chain is resident or will be: blocks of a launch are dispatched in order, it comes first, and a waiting
+        // block holds no resource the other needs.  The wait is bounded all the same -- seconds -- so that a fault ends in an error code.)
+        int timed_out = 0;
+        if (lane == 0) {
+            unsigned int spins = 0;
+            while (__hip_atomic_load(&g->pick_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != (unsigned int)step + 1u) {
+                if (++spins > (1u << 22)) {
+                    timed_out = 1;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+        }
         __builtin_amdgcn_wave_barrier();
         if (lane < 8) s_pick[lane] = __hip_atomic_load(reinterpret_cast<unsigned long long *>(&g->pick) + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (timed_out) {  // lane 0: no pick -> the chain stops below, with the error
+            s_pick[0] = 0;
+            g->error = E_PICK_TIMEOUT;
+        }
     }
     __syncthreads();
     SEL_TIMER_MARK(2)
-    unsigned long long pk_word = sp_word, best_tie = sp_tie;
-    da_u2 refA = da_u2{sp_ax, sp_ay}, refB = da_u2{sp_bx, sp_by};
-    RowInfo ra = RowInfo{sp_ra0, sp_ra1, sp_ra2, sp_ra3}, rb = RowInfo{sp_rb0, sp_rb1, sp_rb2, sp_rb3};
+    unsigned long long pk_word = 1;
     if (!fast) {
         pk_word = s_pick[0];
         best_tie = s_pick[1];
@@ -1788,18 +1900,19 @@ template <class Cell> __device__ __forceinline__ int pick_body(ChainDev *g, unsi
         refB = da_u2{(uint32_t)s_pick[3], (uint32_t)(s_pick[3] >> 32)};
         ra = RowInfo{u2f((uint32_t)s_pick[4]), u2f((uint32_t)(s_pick[4] >> 32)), u2f((uint32_t)s_pick[5]), u2f((uint32_t)(s_pick[5] >> 32))};
         rb = RowInfo{u2f((uint32_t)s_pick[6]), u2f((uint32_t)(s_pick[6] >> 32)), u2f((uint32_t)s_pick[7]), u2f((uint32_t)(s_pick[7] >> 32))};
+        A = (uint32_t)((best_tie >> 7) & 0xFFFFFFu);
+        B = (uint32_t)(best_tie >> 31);
     }
     const uint32_t Nw = (uint32_t)n_rows0;
     if (pk_word == 0 || (int)Nw >= rcap) {
         if (tid == 0) {
-            if (pk_word != 0) g->error = E_ROW_CAPACITY;
+            if (pk_word != 0) g->error = E_ROW_CAPACITY;  // (pk_word == 0 after a time-out: the error is set already)
             g->done = 1;
             g->n_partners = 0;
             atomicAdd(n_done, 1u);
         }
         return 1;
     }
-    const uint32_t A = (uint32_t)((best_tie >> 7) & 0xFFFFFFu), B = (uint32_t)(best_tie >> 31);
     const int idx = (int)(best_tie & 0x7F);
     int shift, sub;
     key_decode(idx, nb, shift, sub);
@@ -2086,10 +2199,11 @@ template <class Cell> __device__ __forceinline__ UpdStep<Cell> load_upd_step(Cha
     u.done = gq->done, u.n_partners = gq->n_partners, u.m = gq->m, u.n_in = gq->n_in;
     u.A = gq->A, u.B = gq->B, u.Nw = gq->Nw;
     u.c = make_ctx_raw(gq, 2 * iter - 1);
-    // the step being applied is iter - 1 (the selection has counted it): its search left the entry the next selection would like to take
-    // unseen in spec[(iter - 1) & 1]; whatever this launch writes that reaches it is folded into mword[(iter - 1) & 1] (group_note)
+    // the step being applied is iter - 1 (the selection has counted it): its search left the best entry the step does not touch in
+    // spec[(iter - 1) & 1]; the best entry of every block this launch writes that reaches it goes to c_list[(iter - 1) & 1] (fold_entry)
     u.c.rword = gq->spec[(iter - 1) & 1].word;
-    u.c.mw = &gq->mword[(iter - 1) & 1];
+    u.c.cn = &gq->c_n[(iter - 1) & 1];
+    u.c.cl = &gq->c_list[(iter - 1) & 1][0];
     u.mcol = (const DA_GLOBAL int *)gq->mcol;
     u.mA = (const DA_GLOBAL Cell *)gq->mA, u.mB = (const DA_GLOBAL Cell *)gq->mB;
     u.cmap = (const DA_GLOBAL uint16_t *)gq->cmap;
@@ -2097,7 +2211,7 @@ template <class Cell> __device__ __forceinline__ UpdStep<Cell> load_upd_step(Cha
     u.plist = (const DA_GLOBAL unsigned long long *)gq->plist;
     pin_sgpr(u.done, u.n_partners, iter, u.m, u.n_in, u.A, u.B, u.Nw, u.mcol, u.mA, u.mB, u.cmap, u.rl, u.plist);
     pin_sgpr(u.c.n_out, u.c.n_bits, u.c.K, u.c.Kpad, u.c.method, u.c.gs_log2, u.c.pb_log2, u.c.cmask, u.c.windows, u.c.hkey, u.c.hrank, u.c.hblk, u.c.ub, u.c.gdirty, u.c.rows);
-    pin_sgpr(u.c.rword, u.c.mw);
+    pin_sgpr(u.c.rword, u.c.cn, u.c.cl);
     u.c.tomb = KEY_TOMB - (unsigned long long)((2 * iter - 1) & 3);
     ctx_finish(u.c);
     return u;
@@ -2300,8 +2414,8 @@ __device__ __forceinline__ void update_partners(ChainDev *g, const UpdStep<Cell>
 
 // special_pairs: the pairs among the rows a step modified -- (A,A), (A,B), (B,B): their blocks are re-counted from scratch; (A,N), (B,N),
 // (N,N): new -- from the exact counts the substitution block left in sp_cnt (select_body used to write them itself: the table is now
-// written by this kernel only).  One wavefront per pair.  The new best entry of every one of them is folded into mword whether it
-// changed or not: the search of the step leaves these three old blocks out of what it certifies (search_body).
+// written by this kernel only).  One wavefront per pair.  Like every block this kernel re-evaluates they pass their best entry to fold_entry,
+// changed or not.
 template <class Cell> __device__ __forceinline__ void special_pairs(ChainDev *gq, const UpdStep<Cell> &u) {
     const Ctx &c = u.c;
     const uint32_t A = u.A, B = u.B, Nw = u.Nw;
@@ -2335,7 +2449,24 @@ template <class Cell> __device__ __forceinline__ void special_pairs(ChainDev *gq
                 table_insert(c, lo, hi, xa, xb, [&](int k) { return cnt[k]; }, &w);
             }
         }
-        if (lane == 0 && c.rword && w >= c.rword) atomicMax(c.mw, w);
+        (void)w;  // (both paths have passed the block's best entry to fold_entry)
+    }
+    // the entries the search listed (they touch exactly one of A / B and reach the untouched entry): a block whose other row is a partner
+    // row is re-evaluated by the partner waves of this launch, which pass its best entry on themselves; the others are unchanged -- passed on here.
+    // Partner row = a row with digits in a substituted column: bit r of the row bitmaps of those columns (A, B, N are never the other row)
+    if (c.rword) {
+        const int nl = (int)gq->l_n[(gq->iter - 1) & 1];
+        const CandEntry *ll = &gq->l_list[(gq->iter - 1) & 1][0];
+        const uint32_t *colbits = gq->colbits;
+        const int cbw = gq->cb_words;
+        for (int e = wave_id(); e < nl; e += UPD_WAVES) {
+            const unsigned long long tw = ll[e].tie;
+            const uint32_t i0 = (uint32_t)((tw >> 7) & 0xFFFFFFu), i1 = (uint32_t)(tw >> 31);
+            const uint32_t r = (i0 == A || i0 == B) ? i1 : i0;
+            int hit = 0;
+            for (int k = lane; k < u.m; k += WAVE) hit |= (int)((colbits[(size_t)u.mcol[k] * cbw + (r >> 5)] >> (r & 31)) & 1u);
+            if (!__any(hit) && lane == 0) fold_entry(c, (uint32_t)ll[e].rank, tw);
+        }
     }
 }
 
@@ -2869,7 +3000,7 @@ size_t carve_chain(unsigned char *base, const ChainJob &job, const Geometry &g, 
     d.collist = c.take<unsigned long long>(n_out * (size_t)g.lcap);
     d.collen = c.take<int>(n_out);
     d.hkey = c.take<unsigned long long>(g.C);
-    d.hrank = c.take<uint32_t>(g.C);
+    d.hrank = c.take<uint32_t>((size_t)g.C + ((size_t)g.C + 3) / 4);  // + the best-key indices, one byte per slot, right behind the ranks (hidx_ptr)
     d.hblk = c.take<unsigned char>((size_t)g.C << g.pb_log2);
     d.ub = c.take<unsigned long long>(g.n_groups);
     d.gtie = c.take<unsigned long long>(g.n_groups);

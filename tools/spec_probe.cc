@@ -60,6 +60,8 @@ int main(int argc, char **argv) {
     long q_steps[4] = {0, 0, 0, 0}, q_dis[4] = {0, 0, 0, 0}, q_old[4] = {0, 0, 0, 0};
     std::vector<char> rec_dis, rec_old;
     Cand prevR, prevV;
+    long prevL = 0;
+    std::vector<long> hist_c(65, 0), hist_l(65, 0);
     int64_t pA = -1, pB = -1, pN = -1;
     while (!s.table.empty() && steps < max_steps) {
         Cand best;
@@ -73,6 +75,21 @@ int main(int argc, char **argv) {
                 if (tA || tB || tN) M.offer(score_of(e), k);
                 const bool special = (k.id0 == pA || k.id0 == pB) && (k.id1 == pA || k.id1 == pB);
                 if (tN || special) Mnew.offer(score_of(e), k);
+            }
+            {  // sizes of the candidate lists an exact scheme needs: entries of T_{t+1} touching A / B / N whose bound word reaches R_t's
+                long cn = 0;
+                const uint64_t r0 = prevR.bw(s.n_bits);
+                if (r0)
+                    for (const auto &e : s.table) {
+                        const PairKey &k = e.first;
+                        if (!(k.id0 == pA || k.id1 == pA || k.id0 == pB || k.id1 == pB || k.id0 == pN || k.id1 == pN)) continue;
+                        // only the best entry of a block (row pair) counts: the engine folds one entry per block
+                        Cand c;
+                        c.offer(score_of(e), k);
+                        if (c.valid() && c.bw(s.n_bits) >= r0) ++cn;
+                    }
+                hist_c[std::min<long>(cn, 64)]++;
+                hist_l[std::min<long>(prevL, 64)]++;
             }
             const bool dis = prevR.valid() && prevR.beats(M);
             const bool viaR = best.key == prevR.key;
@@ -103,6 +120,16 @@ int main(int argc, char **argv) {
         }
         prevR = R;
         prevV = V;
+        prevL = 0;
+        if (R.valid())
+            for (const auto &e : s.table) {
+                const PairKey &k = e.first;
+                const bool t0 = k.id0 == pick.id0 || k.id0 == pick.id1, t1 = k.id1 == pick.id0 || k.id1 == pick.id1;
+                if (t0 == t1) continue;
+                Cand c;
+                c.offer(score_of(e), k);
+                if (c.valid() && c.bw(s.n_bits) >= R.bw(s.n_bits)) ++prevL;
+            }
         pA = pick.id0;
         pB = pick.id1;
         pN = (int64_t)s.expr.size();
@@ -123,6 +150,18 @@ int main(int argc, char **argv) {
     printf("decided on the bound word       %.4f\n", (double)bwok / T);
     printf("certifiable from old values     %.4f\n", (double)oldvals / T);
     printf("mean run of fast steps          %.2f (%ld runs)\n", runs ? (double)runsum / runs : 0.0, runs);
+    auto pct = [&](const std::vector<long> &h, const char *name) {
+        long tot = 0, acc = 0;
+        for (long v : h) tot += v;
+        printf("%s (entries, not blocks: an upper bound): ", name);
+        for (int i = 0; i <= 64; ++i) {
+            acc += h[i];
+            if (i == 0 || i == 1 || i == 2 || i == 4 || i == 8 || i == 16 || i == 32 || i == 63) printf("<=%d: %.4f  ", i, (double)acc / std::max<long>(tot, 1));
+        }
+        printf("\n");
+    };
+    pct(hist_c, "written/unchanged entries touching A,B,N with bound word >= R's");
+    pct(hist_l, "old entries touching exactly one of A,B with bound word >= R's");
     for (int q = 0; q < 4; ++q)
         printf("quarter %d: disjoint %.4f oldvals %.4f\n", q, q_steps[q] ? (double)q_dis[q] / q_steps[q] : 0.0, q_steps[q] ? (double)q_old[q] / q_steps[q] : 0.0);
     return 0;
