@@ -294,6 +294,8 @@ struct ChainDev {
     uint32_t *sp_cnt;              // [6][Kpad] exact counts of the six pairs among {A, B, new row}: select -> update
     unsigned long long st_fast;    // steps whose pick was known before the step began
     unsigned long long st_qphase[4];  // shader-clock cycles of the search block: bounds, arg-max (steps without a known pick), search, steps timed
+    unsigned long long st_qdiag[5];   // (phase-timer builds) group re-reads that found a stale bound below the floor / of clean groups with an excluded
+                                      // best entry; [2],[3] scratch; [4] sum over the steps of the longest wave's re-read rounds
 };
 
 __constant__ Log2Table c_log2;
@@ -1432,6 +1434,11 @@ template <class Cell, bool SHARDED = false> __global__ void __launch_bounds__(SE
 // Only the search block reads or writes group bounds; the table itself is not written by this kernel at all (the six special
 // blocks moved to k_iter_update), so the two blocks share nothing but the descriptor fields named above.
 constexpr uint32_t ROW_NONE = 0xFFFFFFFFu;
+#ifndef DA_SEL2_THREADS
+#define DA_SEL2_THREADS 512
+#endif
+constexpr int SEL2_THREADS = DA_SEL2_THREADS;  // threads of a k_iter_select2 block (both roles); MAX_GROUPS / SEL2_THREADS group bounds per lane of the search
+static_assert(MAX_GROUPS % SEL2_THREADS == 0 && SEL2_THREADS % WAVE == 0 && SEL2_THREADS >= 256, "k_iter_select2 geometry");
 constexpr int QL_CAP = 64;  // entries touching the pick's rows the search may meet above its rising floor before it gives up (LDS)
 
 #ifdef DA_PHASE_TIMERS
@@ -1470,7 +1477,7 @@ __device__ __forceinline__ bool resolve_pick(const DA_GLOBAL CandEntry *cl, unsi
 }
 
 template <class Cell> __device__ __forceinline__ void search_body(ChainDev *g, int step) {
-    constexpr int NW = SEL_THREADS / WAVE;
+    constexpr int NW = SEL2_THREADS / WAVE, GPL = MAX_GROUPS / SEL2_THREADS;  // waves; group bounds per lane
     const int par = step & 1;
     int was_done = g->done, had_error = g->error, n_groups = g->n_groups;
     unsigned long long sp_word = g->spec[par ^ 1].word, sp_tie = g->spec[par ^ 1].tie;
@@ -1484,7 +1491,7 @@ template <class Cell> __device__ __forceinline__ void search_body(ChainDev *g, i
     pin_sgpr(c.gs_log2, c.cmask, c.hkey, c.hrank, c.ub, c.gdirty, c.rows);
     pin_sgpr(gtie_arr, rowoff, cl_prev, ll_out);
     if (was_done || had_error != E_OK) return;  // (the substitution block stops the chain)
-    __shared__ unsigned long long q_floor, q_red_tie[NW];
+    __shared__ unsigned long long q_floor, q_red_tie[NW], q_ub[GPL][SEL2_THREADS];
     __shared__ uint32_t q_red_rank[NW];
     __shared__ CandEntry q_L[QL_CAP];
     __shared__ unsigned int q_Ln, q_Lout;
@@ -1493,39 +1500,19 @@ template <class Cell> __device__ __forceinline__ void search_body(ChainDev *g, i
     const DA_GLOBAL uint8_t *hidx = hidx_ptr(c);
     Q_TIMER_DECL
     Q_TIMER_MARK(0)
-    // ---- ONE vector round trip: bound, dirty flag and stored tie word of this lane's (up to four) groups (wave w owns the groups
-    // [w * GPW, (w + 1) * GPW)); unconditional loads, index clamped (see select_body); the candidates of the previous update with them
-    const int GPW = (n_groups + NW - 1) / NW;
-    unsigned long long ubr[4], gtr[4];
-    int dr[4];  // 0 clean (bound and tie word exact), 1 dirty, 3 absent, 4 read in this pass, 5 clean but its best entry touches an excluded row
-    {
-        bool in[4];
-        uint8_t dv[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int q = wid * GPW + lane + u * WAVE;
-            in[u] = lane + u * WAVE < GPW && q < n_groups;
-            const int qc = in[u] ? q : 0;
-            ubr[u] = c.ub[qc];
-            dv[u] = c.gdirty[qc];
-            gtr[u] = gtie_arr[qc];
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            ubr[u] = in[u] ? ubr[u] : 0ull;
-            dr[u] = in[u] ? (dv[u] ? 1 : 0) : 3;
-        }
-    }
+    const int GPW = (n_groups + NW - 1) / NW;  // wave w owns the groups [w * GPW, (w + 1) * GPW)
     unsigned long long pk_tie;
     bool from_spec;
     const bool fast = resolve_pick(cl_prev, sp_word, sp_tie, cn_prev, pk_tie, from_spec);
-    Q_TIMER_MARK(1)
     uint32_t exA = ROW_NONE, exB = ROW_NONE;  // rows whose entries the pass leaves out
     if (fast) {
         exA = (uint32_t)((pk_tie >> 7) & 0xFFFFFFu);
         exB = (uint32_t)(pk_tie >> 31);
     }
     unsigned int rescans = 0;
+#ifdef DA_PHASE_TIMERS
+    unsigned int q_stale = 0, q_touch = 0, q_rounds = 0;
+#endif
     for (int pass = fast ? 1 : 0; pass < 2; ++pass) {
         // pass 0 (only when the pick is not known yet): the arg-max over the whole table -> the pick, published for the substitution block;
         // pass 1: the same with the entries of the pick's rows left out -> R; the entries that touch exactly one of the rows and reach the
@@ -1554,18 +1541,50 @@ template <class Cell> __device__ __forceinline__ void search_body(ChainDev *g, i
             }
             return 0ull;
         };
-        unsigned long long cl = 0;
+        // ---- ONE vector round trip: bound, dirty flag and stored tie word of this lane's (up to GPL) groups; unconditional loads, index clamped
+        // (see select_body).  A clean group's bound and tie word are exact: its best entry is a candidate right away, or -- if it touches an
+        // excluded row -- the group has to be read.  (The second pass of a launch reads what the first one tightened: fenced below.)
+        // Groups that may have to be read -- dirty, or clean with an excluded best entry -- keep their bound in LDS (q_ub[u][tid], 0 = nothing to
+        // read); a lane holds only its highest one in registers (top, top_u) and one bit per group: dirty.
+        unsigned long long cl = 0, top = 0;
+        int top_u = 0;
+        uint32_t dmask = 0;
+        {
+            unsigned long long ubv[GPL], gtr[GPL];
+            uint8_t dv[GPL];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if (dr[u] == 4 || dr[u] == 5) dr[u] = 0;  // read (and, if it was dirty, verified) in the previous pass: exact values in the registers
-            if (dr[u] == 0 && (uint32_t)(ubr[u] >> 32) != 0) {
-                const unsigned long long w = offer((uint32_t)(ubr[u] >> 32), gtr[u], 0ull, false);  // (an excluded best entry is listed when its group is read)
-                if (w)
-                    cl = max(cl, w);
-                else
-                    dr[u] = 5;
+            for (int u = 0; u < GPL; ++u) {
+                const int q = wid * GPW + lane + u * WAVE;
+                const int qc = (lane + u * WAVE < GPW && q < n_groups) ? q : 0;
+                ubv[u] = c.ub[qc];
+                dv[u] = c.gdirty[qc];
+                gtr[u] = gtie_arr[qc];
+            }
+#pragma unroll
+            for (int u = 0; u < GPL; ++u) {
+                const int q = wid * GPW + lane + u * WAVE;
+                const bool in = lane + u * WAVE < GPW && q < n_groups;
+                unsigned long long cand = 0;  // bound of a group that may have to be read
+                if (in && ubv[u] != 0) {
+                    if (dv[u]) {
+                        cand = ubv[u];
+                        dmask |= 1u << u;
+                    } else {
+                        const unsigned long long w = offer((uint32_t)(ubv[u] >> 32), gtr[u], 0ull, false);  // (an excluded best entry is listed when its group is read)
+                        if (w)
+                            cl = max(cl, w);
+                        else
+                            cand = ubv[u];
+                    }
+                }
+                q_ub[u][tid] = cand;
+                if (cand > top) {
+                    top = cand;
+                    top_u = u;
+                }
             }
         }
+        if (pass == (fast ? 1 : 0)) { Q_TIMER_MARK(1) }
         __syncthreads();  // q_floor zeroed
         cl = wave_max_u64(cl);
         if (lane == 0 && cl) atomicMax(&q_floor, cl);
@@ -1574,20 +1593,11 @@ template <class Cell> __device__ __forceinline__ void search_body(ChainDev *g, i
             // ONE group per wave and round: the wave's highest group that is dirty (bound possibly stale) or whose best entry is excluded,
             // while its bound still reaches the rising floor = the best entry found so far
             const unsigned long long fl = __hip_atomic_load(&q_floor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            unsigned long long top = 0;
-            int top_u = 0, top_s = 0;
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if ((dr[u] == 1 || dr[u] == 5) && ubr[u] > top) {
-                    top = ubr[u];
-                    top_u = u;
-                    top_s = dr[u];
-                }
             const unsigned long long wtop = wave_max_u64(top);
             if (wtop == 0 || wtop < fl) break;
             const int owner = __ffsll((long long)__ballot(top == wtop)) - 1;
             const int own_u = __builtin_amdgcn_readlane(top_u, owner);
-            const bool own_dirty = __builtin_amdgcn_readlane(top_s, owner) == 1;
+            const bool own_dirty = (((uint32_t)__builtin_amdgcn_readlane((int)dmask, owner) >> own_u) & 1u) != 0;
             const uint32_t grp = (uint32_t)(wid * GPW + owner + own_u * WAVE), base = grp * gs;
             // ---- ONE round trip: rank, key and best-key index of every slot of the group (dense arrays, coalesced; up to 8 slots per lane)
             uint32_t rk[8], bi[8], grank = 0;
@@ -1638,15 +1648,7 @@ template <class Cell> __device__ __forceinline__ void search_body(ChainDev *g, i
                 if (exact_known) gt = wave_max_u64(gt);
                 const unsigned long long nb = grank == 0 ? 0ull : exact_known ? bound_word(grank, gt) : (((unsigned long long)grank << 32) | 0xFFFFFFFFull);
                 if (lane == owner) {
-#pragma unroll
-                    for (int u = 0; u < 4; ++u)
-                        if (u == own_u) {
-                            ubr[u] = nb < ubr[u] ? nb : ubr[u];
-                            if (exact_known) {
-                                gtr[u] = gt;
-                                dr[u] = 4;
-                            }
-                        }
+                    q_ub[own_u][tid] = exact_known ? 0ull : (nb < wtop ? nb : wtop);  // (a group that stays dirty keeps a bound below the floor: not read again in this pass)
                     if (exact_known) {
                         c.ub[grp] = nb;
                         gtie_arr[grp] = gt;
@@ -1654,12 +1656,25 @@ template <class Cell> __device__ __forceinline__ void search_body(ChainDev *g, i
                     } else if (nb < wtop)
                         c.ub[grp] = nb;
                 }
-            } else if (lane == owner) {
+            } else if (lane == owner)
+                q_ub[own_u][tid] = 0;
+            if (lane == owner) {  // the owner's next highest group (its own LDS column: no fence needed beyond program order)
+                top = 0;
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    if (u == own_u) dr[u] = 4;
+                for (int u = 0; u < GPL; ++u) {
+                    const unsigned long long v = q_ub[u][tid];
+                    if (v > top) {
+                        top = v;
+                        top_u = u;
+                    }
+                }
             }
             ++rescans;
+#ifdef DA_PHASE_TIMERS
+            q_stale += own_dirty && grank < thr;
+            q_touch += !own_dirty;
+            if (pass) ++q_rounds;
+#endif
             lds_fence();
         }
         // the wave's best entry outside the excluded rows (highest rank, then highest tie word among its holders)
@@ -1712,6 +1727,8 @@ template <class Cell> __device__ __forceinline__ void search_body(ChainDev *g, i
             }
             exA = (uint32_t)((best_tie >> 7) & 0xFFFFFFu);
             exB = (uint32_t)(best_tie >> 31);
+            __threadfence();  // the bounds this pass tightened are re-read by the next one: stores complete, this CU's L1 dropped
+            __syncthreads();
         } else {
             // R for the next step, and with it the entries of the pick's rows that reach it (all scans ended before the barrier above: q_Ln is final)
             const unsigned long long r0 = best_rank ? bound_word(best_rank, best_tie) : 0ull;
@@ -1759,6 +1776,17 @@ template <class Cell> __device__ __forceinline__ void search_body(ChainDev *g, i
         g->st_qphase[3] += 1;
 #endif
     }
+#ifdef DA_PHASE_TIMERS
+    if (lane == 0) {  // per wave: re-reads that found the bound stale and below the floor / of clean groups for an excluded best entry; the longest wave's rounds
+        atomicAdd(&g->st_qdiag[0], (unsigned long long)q_stale);
+        atomicAdd(&g->st_qdiag[1], (unsigned long long)q_touch);
+        atomicMax(&g->st_qdiag[2 + (step & 1)], (unsigned long long)q_rounds);  // (max over the waves of this step; folded by the next-but-one step below)
+    }
+    if (tid == 0) {
+        g->st_qdiag[4] += g->st_qdiag[2 + ((step + 1) & 1)];
+        g->st_qdiag[2 + ((step + 1) & 1)] = 0;
+    }
+#endif
 }
 
 // pick_body: the substitution block of a step (see above).  Phases (2)-(4) of select_body -- substitution of the pick in the
@@ -1811,7 +1839,7 @@ template <class Cell> __device__ __forceinline__ int pick_body(ChainDev *g, unsi
     int *s_bpos = s_col + n_out;                                                      // [n_out] 1 + position of a column in B's list, 0 = absent
     int *s_clen = s_bpos + n_out;                                                     // [n_out] list length of every column
     int *s_cm = s_clen + n_out;                                                       // [n_out] 1 + index among the matched columns, 0 = not matched
-    constexpr int NW = SEL_THREADS / WAVE;
+    constexpr int NW = SEL2_THREADS / WAVE;
     __shared__ int s_np, s_part[NW];
     __shared__ unsigned int s_matches;
     __shared__ RowInfo s_new;
@@ -1862,7 +1890,7 @@ template <class Cell> __device__ __forceinline__ int pick_body(ChainDev *g, unsi
             s_bpos[tid] = 0;
         }
         if (want_log2) reinterpret_cast<uint32_t *>(&s_log2)[tid] = l2w;
-        for (int j = tid + SEL_THREADS; j < n_out; j += SEL_THREADS) {
+        for (int j = tid + SEL2_THREADS; j < n_out; j += SEL2_THREADS) {
             s_clen[j] = collen[j];
             s_cm[j] = 0;
             s_bpos[j] = 0;
@@ -1940,7 +1968,7 @@ template <class Cell> __device__ __forceinline__ int pick_body(ChainDev *g, unsi
         rn.lat = (ra.lat < rb.lat ? rb.lat : ra.lat) + dlat;
         s_new = rn;
     }
-    for (int k = tid; k < 6 * Kpad; k += SEL_THREADS) s_cnt[k] = 0;
+    for (int k = tid; k < 6 * Kpad; k += SEL2_THREADS) s_cnt[k] = 0;
     if (tid >= lenA) eA0 = F::none();
     if (same || tid >= lenB) eB0 = F::none();
     pin_vgpr(eA0, eB0);  // both consumed (waited for) here, in front of thread 0's stores below
@@ -1949,7 +1977,7 @@ template <class Cell> __device__ __forceinline__ int pick_body(ChainDev *g, unsi
             s_bent[tid] = eB0;
             s_bpos[F::col(eB0)] = tid + 1;
         }
-        for (int t = tid + SEL_THREADS; t < lenB; t += SEL_THREADS) {
+        for (int t = tid + SEL2_THREADS; t < lenB; t += SEL2_THREADS) {
             const Entry e = rlB[t];
             s_bent[t] = e;
             s_bpos[F::col(e)] = t + 1;
@@ -1969,7 +1997,7 @@ template <class Cell> __device__ __forceinline__ int pick_body(ChainDev *g, unsi
     int m = 0;  // matched columns so far (block-uniform)
     // pass 1: one thread per entry of A (ascending columns); the matched columns are compacted in column order, which
     // is the order of the new row's list
-    for (int t0 = 0; t0 < lenA; t0 += SEL_THREADS) {
+    for (int t0 = 0; t0 < lenA; t0 += SEL2_THREADS) {
         const int t = t0 + tid;
         Cell a = 0, b = 0, ma = 0, mb = 0, na = 0, nbv = 0;
         uint32_t colA = 0;
@@ -2033,18 +2061,18 @@ template <class Cell> __device__ __forceinline__ int pick_body(ChainDev *g, unsi
     if (my_matches) atomicAdd(&s_matches, my_matches);  // LDS; added to the chain's statistics by thread 0 at the end
     // pass 2: B's list back to memory, self pairs of what is left of B
     if (!same)
-        for (int t = tid; t < lenB; t += SEL_THREADS) {
+        for (int t = tid; t < lenB; t += SEL2_THREADS) {
             const Entry e = s_bent[t];
             rlB[t] = e;
             const Cell nbv = F::cell(e);
             if (nbv) for_pairs_self<Cell>(nbv, nb, [&](int k) { atomicAdd(&cBB[k], 1u); });
         }
     // the map column -> matched index for the update blocks (one coalesced copy; pass 1 has completed: its last barrier)
-    for (int j = tid; j < n_out; j += SEL_THREADS) cmap[j] = (uint16_t)s_cm[j];
+    for (int j = tid; j < n_out; j += SEL2_THREADS) cmap[j] = (uint16_t)s_cm[j];
     // the new row joins the lists of its columns
     {
         const unsigned long long refN = ref_pack(Nw, (uint32_t)m, offN);
-        for (int k = tid; k < m; k += SEL_THREADS) {
+        for (int k = tid; k < m; k += SEL2_THREADS) {
             const int j = s_col[k], len = s_len[k];
             if (len < lcap) {
                 collist[(size_t)j * lcap + len] = refN;
@@ -2057,7 +2085,7 @@ template <class Cell> __device__ __forceinline__ int pick_body(ChainDev *g, unsi
     SEL_TIMER_MARK(4)
     SEL_TIMER_MARK(5)
     // the exact counts of the six pairs among {A, B, new}: to the special-pair block of k_iter_update (all counters are final: the barrier above)
-    for (int k = tid; k < 6 * Kpad; k += SEL_THREADS) sp_cnt[k] = s_cnt[k];
+    for (int k = tid; k < 6 * Kpad; k += SEL2_THREADS) sp_cnt[k] = s_cnt[k];
     // ---------------- (4) partner rows -- the rows that have digits in a substituted column -- into the partner list:
     // OR of those columns' row bitmaps (A, B and the new row masked out: their bits are being changed by this very kernel).  Word w
     // of the OR covers rows 32 w ..; the set bits are counted (DPP prefix sum), one LDS atomic per wave reserves the places, the
@@ -2066,7 +2094,7 @@ template <class Cell> __device__ __forceinline__ int pick_body(ChainDev *g, unsi
         const DA_GLOBAL uint32_t *cb = colbits;
         const int nwords = (int)((Nw + 31) >> 5);
         DA_GLOBAL uint32_t *ids = pl_ids;
-        for (int wb = wid * WAVE; wb < nwords; wb += SEL_THREADS) {  // wave-uniform trip count
+        for (int wb = wid * WAVE; wb < nwords; wb += SEL2_THREADS) {  // wave-uniform trip count
             const int w = wb + lane;
             uint32_t bits = 0;
             if (w < nwords) {
@@ -2097,8 +2125,8 @@ template <class Cell> __device__ __forceinline__ int pick_body(ChainDev *g, unsi
     {  // partner ids -> partner list entries (row id, list length, list offset)
         const int np = s_np;
         const DA_GLOBAL uint32_t *ids = pl_ids;
-        for (int t = tid; t < np; t += 2 * SEL_THREADS) {  // two partners per thread and pass, their look-ups in flight together
-            const int t2 = t + SEL_THREADS;
+        for (int t = tid; t < np; t += 2 * SEL2_THREADS) {  // two partners per thread and pass, their look-ups in flight together
+            const int t2 = t + SEL2_THREADS;
             const bool has2 = t2 < np;
             const uint32_t r1 = t < IDS_LDS ? s_ids[t] : ids[t];
             const uint32_t r2 = !has2 ? r1 : t2 < IDS_LDS ? s_ids[t2] : ids[t2];
@@ -2142,7 +2170,10 @@ template <class Cell> __device__ __forceinline__ int pick_body(ChainDev *g, unsi
 // k_iter_update blocks run on the same XCD (update_body); y = 0 the search block, y = 1 the substitution block.  `step` = the
 // number of the lockstep iteration = the `iter` of every chain of the launch that has not finished (kernel argument: the search
 // block must not read a field the substitution block writes during the launch).
-template <class Cell> __global__ void __launch_bounds__(SEL_THREADS) k_iter_select2(ChainDev *chains, int n_chains, unsigned int *n_done, int step) {
+#ifndef DA_SEL2_WAVES
+#define DA_SEL2_WAVES 4  // wavefronts per SIMD the register budget of k_iter_select2 is capped for
+#endif
+template <class Cell> __global__ void __launch_bounds__(SEL2_THREADS) __attribute__((amdgpu_waves_per_eu(DA_SEL2_WAVES, DA_SEL2_WAVES))) k_iter_select2(ChainDev *chains, int n_chains, unsigned int *n_done, int step) {
     if ((int)blockIdx.x >= n_chains) return;
     if (blockIdx.y == 0)
         search_body<Cell>(&chains[blockIdx.x], step);
@@ -3307,9 +3338,9 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
         const dim3 sel_grid((gr.count + 7) & ~7, 2);  // y = 0 search block, y = 1 substitution block
         if (se) HIP_CHECK(hipEventRecord(se[0], gr.stream));
         if (gr.w == 0)
-            hipLaunchKernelGGL(k_iter_select2<uint32_t>, sel_grid, dim3(SEL_THREADS), sel_lds[0], gr.stream, base, gr.count, im.d_done, step);
+            hipLaunchKernelGGL(k_iter_select2<uint32_t>, sel_grid, dim3(SEL2_THREADS), sel_lds[0], gr.stream, base, gr.count, im.d_done, step);
         else
-            hipLaunchKernelGGL(k_iter_select2<uint64_t>, sel_grid, dim3(SEL_THREADS), sel_lds[1], gr.stream, base, gr.count, im.d_done, step);
+            hipLaunchKernelGGL(k_iter_select2<uint64_t>, sel_grid, dim3(SEL2_THREADS), sel_lds[1], gr.stream, base, gr.count, im.d_done, step);
         if (se) HIP_CHECK(hipEventRecord(se[1], gr.stream));
         // (+ 1: the last block of a chain writes the six blocks of the pairs among the modified rows)
         if (gr.w == 0)
@@ -3544,6 +3575,7 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
         o.stats.matches = (long long)d.st_matches;
         for (int q = 0; q < 12; ++q) im.timings.phase_cycles[q] += (double)d.st_phase[q];
         for (int q = 0; q < 4; ++q) im.timings.search_cycles[q] += (double)d.st_qphase[q];
+        im.timings.search_diag[0] += (double)d.st_qdiag[0], im.timings.search_diag[1] += (double)d.st_qdiag[1], im.timings.search_diag[2] += (double)d.st_qdiag[4];
         im.timings.fast_steps += (long long)d.st_fast;
         im.timings.found += (long long)d.st_found;
         im.timings.inserts += (long long)d.st_inserts;

@@ -36,6 +36,7 @@ struct int4 {
     int x, y, z, w;
 };
 #define amdgpu_num_sgpr(n) unused  // register-budget attribute of the update kernel: meaningless on the host
+#define amdgpu_waves_per_eu(a, b) unused  // likewise (selection kernel)
 
 struct dim3 {
     unsigned x, y, z;

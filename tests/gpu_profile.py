@@ -21,5 +21,5 @@ sm = max(tm['samples'], 1)
 print('picks known a step ahead: %.1f %% of %d steps; group re-reads per step %.2f' % (100.0 * tm['fast_steps'] / its, its, tm['rescans'] / its))
 if tm['search_steps_timed']:
     q = tm['search_steps_timed']
-    print('search block cycles/step: bounds %.0f, arg-max (per step of ALL steps) %.0f, excluded search %.0f' % (tm['search_bounds'] / q, tm['search_argmax'] / q, tm['search_excluded'] / q))
+    print('search block cycles/step: bounds %.0f, arg-max (per step of ALL steps) %.0f, excluded search %.0f; re-reads/step: stale below the floor %.2f, clean with an excluded best entry %.2f; rounds of the longest wave %.2f' % (tm['search_bounds'] / q, tm['search_argmax'] / q, tm['search_excluded'] / q, tm['search_stale_rereads'] / q, tm['search_touch_rereads'] / q, tm['search_rounds'] / q))
 print('sampled per-launch: select %.1f us, update %.1f us, chains/launch %.1f' % (1e3 * tm['select_ms_sampled'] / sm, 1e3 * tm['update_ms_sampled'] / sm, tm['sampled_chain_launches'] / sm))
