@@ -410,7 +410,7 @@ def timings(reset: bool = False) -> dict:
              'select_ms_sampled', 'update_ms_sampled', 'samples', 'found', 'inserts', 'cell_reads', 'block_bytes', 'cell_bytes',
              'sel_load_bounds', 'sel_argmax', 'sel_newrow', 'sel_substitute', 'sel_prefix', 'sel_claims', 'sel_special',
              'upd_fetch', 'upd_probe', 'upd_cells', 'upd_blocks', 'upd_create', 'retries', 'sampled_chain_launches')
-    extra = ('select_bytes', 'host_launch_ms', 'fast_steps', 'search_bounds', 'search_argmax', 'search_excluded', 'search_steps_timed', 'search_stale_rereads', 'search_touch_rereads', 'search_rounds')
+    extra = ('select_bytes', 'host_launch_ms', 'fast_steps', 'search_bounds', 'search_argmax', 'search_excluded', 'search_steps_timed', 'search_stale_rereads', 'search_touch_rereads', 'search_rounds', 'search_long_lists', 'search_longest_list', 'search_full_passes', 'search_list_entries')
     return {**dict(zip(names, t.tolist())), **dict(zip(extra, e.tolist()))}
 
 

@@ -394,7 +394,7 @@ int da_engine_stats(double *out, int n) {
     std::lock_guard<LibraryMutex> lk(g_mutex);
     try {
         const da::gpu::GpuTimings &g = backend().timings();
-        const double v[16] = {g.select_bytes, g.host_launch_ms, (double)g.fast_steps, g.search_cycles[0], g.search_cycles[1], g.search_cycles[2], g.search_cycles[3], g.search_diag[0], g.search_diag[1], g.search_diag[2], 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        const double v[16] = {g.select_bytes, g.host_launch_ms, (double)g.fast_steps, g.search_cycles[0], g.search_cycles[1], g.search_cycles[2], g.search_cycles[3], g.search_diag[0], g.search_diag[1], g.search_diag[2], g.search_diag[3], g.search_diag[4], g.search_diag[5], g.search_diag[6], 0.0, 0.0};
         const int m = n < 16 ? (n < 0 ? 0 : n) : 16;
         for (int i = 0; i < m; ++i) out[i] = v[i];
         return m;

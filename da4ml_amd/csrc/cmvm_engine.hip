@@ -294,7 +294,7 @@ struct ChainDev {
     uint32_t *sp_cnt;              // [6][Kpad] exact counts of the six pairs among {A, B, new row}: select -> update
     unsigned long long st_fast;    // steps whose pick was known before the step began
     unsigned long long st_qphase[4];  // shader-clock cycles of the search block: bounds, arg-max (steps without a known pick), search, steps timed
-    unsigned long long st_qdiag[5];   // (phase-timer builds) group re-reads that found a stale bound below the floor / of clean groups with an excluded
+    unsigned long long st_qdiag[9];   // (phase-timer builds) [5] steps whose work list held > 32 groups, [6] the longest work list, [7] passes over the whole table (pick not known ahead), [8] work-list entries in all; group re-reads that found a stale bound below the floor / of clean groups with an excluded
                                       // best entry; [2],[3] scratch; [4] sum over the steps of the longest wave's re-read rounds
 };
 
@@ -1435,7 +1435,7 @@ template <class Cell, bool SHARDED = false> __global__ void __launch_bounds__(SE
 // blocks moved to k_iter_update), so the two blocks share nothing but the descriptor fields named above.
 constexpr uint32_t ROW_NONE = 0xFFFFFFFFu;
 #ifndef DA_SEL2_THREADS
-#define DA_SEL2_THREADS 512
+#define DA_SEL2_THREADS 1024  // measured (MI355X, round 5): 512 threads are slower, alone and in the batch (fewer waves share the group reads)
 #endif
 constexpr int SEL2_THREADS = DA_SEL2_THREADS;  // threads of a k_iter_select2 block (both roles); MAX_GROUPS / SEL2_THREADS group bounds per lane of the search
 static_assert(MAX_GROUPS % SEL2_THREADS == 0 && SEL2_THREADS % WAVE == 0 && SEL2_THREADS >= 256, "k_iter_select2 geometry");
@@ -1492,6 +1492,8 @@ template <class Cell> __device__ __forceinline__ void search_body(ChainDev *g, i
     pin_sgpr(gtie_arr, rowoff, cl_prev, ll_out);
     if (was_done || had_error != E_OK) return;  // (the substitution block stops the chain)
     __shared__ unsigned long long q_floor, q_red_tie[NW], q_ub[GPL][SEL2_THREADS];
+    __shared__ uint32_t q_work[MAX_GROUPS];  // groups still to be read after round 0: index into q_ub | dirty << 31
+    __shared__ unsigned int q_wn;
     __shared__ uint32_t q_red_rank[NW];
     __shared__ CandEntry q_L[QL_CAP];
     __shared__ unsigned int q_Ln, q_Lout;
@@ -1521,6 +1523,7 @@ template <class Cell> __device__ __forceinline__ void search_body(ChainDev *g, i
             q_floor = 0;
             q_Ln = 0;
             q_Lout = 0;
+            q_wn = 0;
         }
         uint32_t nr = 0;  // this lane's best entry so far outside the excluded rows
         unsigned long long nt = 0;
@@ -1589,31 +1592,23 @@ template <class Cell> __device__ __forceinline__ void search_body(ChainDev *g, i
         cl = wave_max_u64(cl);
         if (lane == 0 && cl) atomicMax(&q_floor, cl);
         __syncthreads();
-        while (true) {
-            // ONE group per wave and round: the wave's highest group that is dirty (bound possibly stale) or whose best entry is excluded,
-            // while its bound still reaches the rising floor = the best entry found so far
-            const unsigned long long fl = __hip_atomic_load(&q_floor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            const unsigned long long wtop = wave_max_u64(top);
-            if (wtop == 0 || wtop < fl) break;
-            const int owner = __ffsll((long long)__ballot(top == wtop)) - 1;
-            const int own_u = __builtin_amdgcn_readlane(top_u, owner);
-            const bool own_dirty = (((uint32_t)__builtin_amdgcn_readlane((int)dmask, owner) >> own_u) & 1u) != 0;
-            const uint32_t grp = (uint32_t)(wid * GPW + owner + own_u * WAVE), base = grp * gs;
-            // ---- ONE round trip: rank, key and best-key index of every slot of the group (dense arrays, coalesced; up to 8 slots per lane)
-            uint32_t rk[8], bi[8], grank = 0;
-            unsigned long long kk[8];
+        // read one group (by one wavefront): every slot whose rank reaches the floor's is a candidate (or, touching an excluded row, listed); a
+        // dirty group's bound is tightened.  (All ranks, keys and indices in ONE round trip was measured too: 114 registers per thread, and a
+        // 1024-thread block of this kernel then needs a CU without a single k_iter_update block -- in the batch 1 % of the launches waited
+        // > 200 us for one.  This form fits the 64 registers of eight waves per SIMD.)
+        auto read_group = [&](const uint32_t grp, const bool dirty, const unsigned long long bound, const unsigned long long fl) {
+            const uint32_t base = grp * gs;
+            // ---- round trip 1: the ranks of all slots (one dense array, coalesced; 8 slots per lane)
+            uint32_t rk[8], grank = 0;
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int o = lane + u * WAVE;
-                const uint32_t sl = base + (o < gs ? o : 0);
-                rk[u] = c.hrank[sl];
-                kk[u] = c.hkey[sl];
-                bi[u] = hidx[sl];
+                rk[u] = c.hrank[base + (o < gs ? o : 0)];
             }
             load_fence();
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                pin_vgpr(rk[u], kk[u], bi[u]);
+                pin_vgpr(rk[u]);
                 if (lane + u * WAVE >= gs) rk[u] = 0;
                 grank = max(grank, rk[u]);
             }
@@ -1623,13 +1618,25 @@ template <class Cell> __device__ __forceinline__ void search_body(ChainDev *g, i
             const uint32_t fr = (uint32_t)(fl >> 32), thr = fr ? fr : 1u;
             unsigned long long gt = 0, lw = 0;
             if (grank >= thr) {  // (wave-uniform: a group whose stale bound promised more than it holds costs nothing beyond the ranks)
+                // ---- round trip 2: key and best-key index of those slots -- a lane takes its slots one per turn, all lanes' loads of a turn in
+                // flight together (nearly always a single turn: a handful of the 512 slots qualify)
+                uint32_t want = 0;
 #pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    if (rk[u] >= thr) {
-                        const unsigned long long tw = tie_word((uint32_t)kk[u], (uint32_t)(kk[u] >> 32), (int)bi[u]);
-                        if (rk[u] == grank) gt = tw > gt ? tw : gt;
-                        lw = max(lw, offer(rk[u], tw, fl, pass != 0));
+                for (int u = 0; u < 8; ++u) want |= rk[u] >= thr ? 1u << u : 0u;
+                while (__any(want != 0)) {
+                    if (want) {
+                        const int u = ctz32(want);
+                        want &= want - 1;
+                        uint32_t r = rk[0];
+#pragma unroll
+                        for (int v = 1; v < 8; ++v) r = u == v ? rk[v] : r;
+                        const uint32_t sl = base + (uint32_t)(lane + u * WAVE);
+                        const unsigned long long k = c.hkey[sl];
+                        const unsigned long long tw = tie_word((uint32_t)k, (uint32_t)(k >> 32), (int)hidx[sl]);
+                        if (r == grank) gt = tw > gt ? tw : gt;
+                        lw = max(lw, offer(r, tw, fl, pass != 0));
                     }
+                }
                 for (int o = lane + 8 * WAVE; o < gs; o += WAVE) {
                     const uint32_t r2 = c.hrank[base + o];
                     if (r2 >= thr) {
@@ -1641,41 +1648,76 @@ template <class Cell> __device__ __forceinline__ void search_body(ChainDev *g, i
                 }
                 if (lw > fl) atomicMax(&q_floor, lw);
             }
-            if (own_dirty) {
+            unsigned long long left = 0;  // what the group may still hold for this pass: nothing once it has been read, unless it stays dirty below the floor
+            if (dirty) {
                 // tighten the group's bound.  Its best entry is known exactly when its rank reaches the floor's (the tie words were formed):
                 // the group becomes clean; otherwise (rank below the floor's) the bound drops to "that rank, any key" and the group stays dirty
                 const bool exact_known = grank >= thr || grank == 0;
                 if (exact_known) gt = wave_max_u64(gt);
                 const unsigned long long nb = grank == 0 ? 0ull : exact_known ? bound_word(grank, gt) : (((unsigned long long)grank << 32) | 0xFFFFFFFFull);
-                if (lane == owner) {
-                    q_ub[own_u][tid] = exact_known ? 0ull : (nb < wtop ? nb : wtop);  // (a group that stays dirty keeps a bound below the floor: not read again in this pass)
+                if (lane == 0) {
                     if (exact_known) {
                         c.ub[grp] = nb;
                         gtie_arr[grp] = gt;
                         c.gdirty[grp] = 0;
-                    } else if (nb < wtop)
+                    } else if (nb < bound)
                         c.ub[grp] = nb;
                 }
-            } else if (lane == owner)
-                q_ub[own_u][tid] = 0;
-            if (lane == owner) {  // the owner's next highest group (its own LDS column: no fence needed beyond program order)
-                top = 0;
-#pragma unroll
-                for (int u = 0; u < GPL; ++u) {
-                    const unsigned long long v = q_ub[u][tid];
-                    if (v > top) {
-                        top = v;
-                        top_u = u;
-                    }
-                }
+                if (!exact_known) left = nb < bound ? nb : bound;
             }
             ++rescans;
 #ifdef DA_PHASE_TIMERS
-            q_stale += own_dirty && grank < thr;
-            q_touch += !own_dirty;
-            if (pass) ++q_rounds;
+            q_stale += dirty && grank < thr;
+            q_touch += !dirty;
 #endif
-            lds_fence();
+            return left;
+        };
+        // ---- round 0: every wave reads its highest group that is dirty (bound possibly stale) or whose best entry is excluded, if that
+        // bound reaches the floor of the clean groups.  The floor rises to (nearly) the answer.
+        {
+            const unsigned long long fl = __hip_atomic_load(&q_floor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const unsigned long long wtop = wave_max_u64(top);
+            if (wtop != 0 && wtop >= fl) {
+                const int owner = __ffsll((long long)__ballot(top == wtop)) - 1;
+                const int own_u = __builtin_amdgcn_readlane(top_u, owner);
+                const bool own_dirty = (((uint32_t)__builtin_amdgcn_readlane((int)dmask, owner) >> own_u) & 1u) != 0;
+                const unsigned long long left = read_group((uint32_t)(wid * GPW + owner + own_u * WAVE), own_dirty, wtop, fl);
+                if (lane == owner) q_ub[own_u][tid] = left;
+            }
+        }
+        __syncthreads();
+        // ---- the groups that still reach the floor, from all waves into one work list, dealt out evenly: a wave that owns several of them
+        // no longer reads them one after the other while the others idle (the launch lasts as long as its slowest wave)
+        {
+            const unsigned long long fl = __hip_atomic_load(&q_floor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+            for (int u = 0; u < GPL; ++u) {
+                const unsigned long long v = q_ub[u][tid];
+                if (v != 0 && v >= fl) q_work[atomicAdd(&q_wn, 1u)] = (uint32_t)(u * SEL2_THREADS + tid) | (((dmask >> u) & 1u) << 31);
+            }
+        }
+        __syncthreads();
+        {
+            const unsigned int wn = q_wn;
+#ifdef DA_PHASE_TIMERS
+            if (tid == 0) {
+                if (wn > 32) g->st_qdiag[5] += 1;
+                if (wn > g->st_qdiag[6]) g->st_qdiag[6] = wn;
+                if (pass == 0) g->st_qdiag[7] += 1;
+                g->st_qdiag[8] += wn;
+            }
+#endif
+            for (unsigned int i = (unsigned int)wid; i < wn; i += NW) {  // (wave-uniform)
+                const uint32_t info = q_work[i], at = info & 0x7FFFFFFFu;
+                const int u = (int)(at / SEL2_THREADS), t = (int)(at % SEL2_THREADS);
+                const unsigned long long bound = q_ub[u][t];
+                const unsigned long long fl = __hip_atomic_load(&q_floor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (bound < fl) continue;  // the floor has risen past it meanwhile
+                (void)read_group((uint32_t)((t / WAVE) * GPW + (t % WAVE) + u * WAVE), (info >> 31) != 0, bound, fl);
+#ifdef DA_PHASE_TIMERS
+                if (pass) ++q_rounds;
+#endif
+            }
         }
         // the wave's best entry outside the excluded rows (highest rank, then highest tie word among its holders)
         const uint32_t wnr = wave_max_u32(nr);
@@ -2171,7 +2213,7 @@ template <class Cell> __device__ __forceinline__ int pick_body(ChainDev *g, unsi
 // number of the lockstep iteration = the `iter` of every chain of the launch that has not finished (kernel argument: the search
 // block must not read a field the substitution block writes during the launch).
 #ifndef DA_SEL2_WAVES
-#define DA_SEL2_WAVES 4  // wavefronts per SIMD the register budget of k_iter_select2 is capped for
+#define DA_SEL2_WAVES 8  // wavefronts per SIMD the register budget of k_iter_select2 is capped for: 64 registers, so that a 1024-thread block shares a CU with k_iter_update blocks
 #endif
 template <class Cell> __global__ void __launch_bounds__(SEL2_THREADS) __attribute__((amdgpu_waves_per_eu(DA_SEL2_WAVES, DA_SEL2_WAVES))) k_iter_select2(ChainDev *chains, int n_chains, unsigned int *n_done, int step) {
     if ((int)blockIdx.x >= n_chains) return;
@@ -3576,6 +3618,7 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
         for (int q = 0; q < 12; ++q) im.timings.phase_cycles[q] += (double)d.st_phase[q];
         for (int q = 0; q < 4; ++q) im.timings.search_cycles[q] += (double)d.st_qphase[q];
         im.timings.search_diag[0] += (double)d.st_qdiag[0], im.timings.search_diag[1] += (double)d.st_qdiag[1], im.timings.search_diag[2] += (double)d.st_qdiag[4];
+        im.timings.search_diag[3] += (double)d.st_qdiag[5], im.timings.search_diag[4] = std::max(im.timings.search_diag[4], (double)d.st_qdiag[6]), im.timings.search_diag[5] += (double)d.st_qdiag[7], im.timings.search_diag[6] += (double)d.st_qdiag[8];
         im.timings.fast_steps += (long long)d.st_fast;
         im.timings.found += (long long)d.st_found;
         im.timings.inserts += (long long)d.st_inserts;

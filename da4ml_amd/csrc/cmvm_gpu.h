@@ -34,7 +34,7 @@ struct GpuTimings {  // accumulated since the last reset; read by the benchmark 
     double select_bytes = 0;    // algorithmic bytes of k_iter_select, counted on the device
     double host_launch_ms = 0;  // host time spent queueing the greedy loop's launches (the launch thread's share of the loop)
     long long fast_steps = 0;   // greedy steps whose pick was known before the step began (k_iter_select2)
-    double search_diag[3] = {0};    // (phase-timer builds) re-reads of stale groups below the floor, of clean groups with an excluded best entry, rounds of the longest wave
+    double search_diag[7] = {0};    // (phase-timer builds) re-reads of stale groups below the floor, of clean groups with an excluded best entry, rounds of the longest wave
     double search_cycles[4] = {0};  // shader-clock cycles of the search block: bounds, arg-max of steps without a known pick, search; [3] = steps timed
 };
 

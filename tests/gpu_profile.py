@@ -22,4 +22,6 @@ print('picks known a step ahead: %.1f %% of %d steps; group re-reads per step %.
 if tm['search_steps_timed']:
     q = tm['search_steps_timed']
     print('search block cycles/step: bounds %.0f, arg-max (per step of ALL steps) %.0f, excluded search %.0f; re-reads/step: stale below the floor %.2f, clean with an excluded best entry %.2f; rounds of the longest wave %.2f' % (tm['search_bounds'] / q, tm['search_argmax'] / q, tm['search_excluded'] / q, tm['search_stale_rereads'] / q, tm['search_touch_rereads'] / q, tm['search_rounds'] / q))
+if tm['search_steps_timed']:
+    print('search work lists: %.2f groups per step, %d steps with more than 32, longest %d; passes over the whole table %d; steps with a known pick %d of %d' % (tm['search_list_entries'] / tm['search_steps_timed'], tm['search_long_lists'], tm['search_longest_list'], tm['search_full_passes'], tm['fast_steps'], its))
 print('sampled per-launch: select %.1f us, update %.1f us, chains/launch %.1f' % (1e3 * tm['select_ms_sampled'] / sm, 1e3 * tm['update_ms_sampled'] / sm, tm['sampled_chain_launches'] / sm))

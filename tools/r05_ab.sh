@@ -5,7 +5,7 @@ cd "$GRAFT_REPO_ROOT"; O=gpurun_out/r05_ab; mkdir -p $O
 names="$@"; [ -z "$names" ] && names=$(ls ab_libs/lib_*.so | sed 's|ab_libs/lib_||; s|\.so||')
 for n in $names; do
   export DA4ML_HIP_LIB=ab_libs/lib_$n.so
-  if [[ $n != *timers* ]]; then
+  if [[ $n != *timers* && -z "${SKIP_CHECKS:-}" ]]; then
     timeout 120 python tools/gpu_stress_small.py 100 > $O/$n.stress.log 2>&1
     timeout 240 python -m pytest tests/test_gpu_parity.py -x -q -k "random_small or c3_256 or c2_64 or capacity" > $O/$n.parity.log 2>&1
     echo "[$n] $(tail -1 $O/$n.stress.log) | $(tail -1 $O/$n.parity.log)"
