@@ -235,7 +235,10 @@ struct ChainDev {
     int pb_log2;
     unsigned long long *ub;
     unsigned long long *gtie;  // [n_groups] full tie word of the group's best entry (valid while the group is clean)
-    uint8_t *gdirty;           // [n_groups] a block's best (rank, key) changed since the group was last verified
+    unsigned long long *glow;  // [n_groups] the highest bound word a block's best entry had before an update LOWERED it, since the group was last
+                               // verified: reaching the group's bound it says the bound is stale (group_note)
+    uint32_t *gdirty;          // [n_groups] 0: the tie word of the group's best entry is exact (and the bound, unless glow reaches it); 1: an entry rose,
+                               // the tie word is unknown
     // per-iteration hand-off select -> update
     int *mcol;
     uint16_t *cmap;    // [n_out] 1 + index of a column among the substituted columns of this step, 0 = not substituted
@@ -391,7 +394,8 @@ struct Ctx {
     DA_GLOBAL uint32_t *hrank;
     DA_GLOBAL unsigned char *hblk;
     DA_GLOBAL unsigned long long *ub;
-    DA_GLOBAL uint8_t *gdirty;
+    DA_GLOBAL unsigned long long *glow;
+    DA_GLOBAL uint32_t *gdirty;
     const DA_GLOBAL RowInfo *rows;
     ChainDev *g;  // derived from the kernel argument: already known to be global
     unsigned long long tomb;  // this launch's tombstone value
@@ -417,7 +421,8 @@ __device__ __forceinline__ Ctx make_ctx_raw(ChainDev *g, int launch_id) {
     c.hrank = (DA_GLOBAL uint32_t *)g->hrank;
     c.hblk = (DA_GLOBAL unsigned char *)g->hblk;
     c.ub = (DA_GLOBAL unsigned long long *)g->ub;
-    c.gdirty = (DA_GLOBAL uint8_t *)g->gdirty;
+    c.glow = (DA_GLOBAL unsigned long long *)g->glow;
+    c.gdirty = (DA_GLOBAL uint32_t *)g->gdirty;
     c.rows = (const DA_GLOBAL RowInfo *)g->rows;
     c.g = g;
     c.rword = 0;
@@ -489,12 +494,31 @@ __device__ int table_claim(const Ctx &c, unsigned long long key, uint32_t h) {
     return -1;
 }
 
-// A block's best (rank, key) changed from bound word `w_old` to `w_new` (0 = not selectable): raise the group's bound if needed and
-// mark the group dirty
+// A block's best (rank, key) changed from bound word `w_old` to `w_new` (0 = not selectable).  Invariant kept: a group's bound is TIGHT (the
+// bound word of its best entry) unless glow[grp] reaches it; flags 0 = the stored tie word is exact too.
+//   * the entry rose: it may be the group's best now -- raise the bound, tie word unknown (flag);
+//   * it fell: remember the highest value that fell (glow).  If that reaches the group's bound, the group's best may have been lowered and the
+//     bound is stale -- the selection sees it when it reads the bounds and re-reads such groups early, in wavefronts that would idle otherwise.
+//     (Left to be found lazily, stale bounds pile up below the selection's floor and are all met together when the floor drops a rank class:
+//     work lists of up to 4000 groups, 1 % of the launches > 140 us, measured in round 5.  Deciding it HERE needs the group's bound in the update
+//     kernel: two more loads and four more registers per partner pass, + 1.5 .. 4 us per launch, measured.)
+// Fire-and-forget atomics, nothing is read.
 __device__ __forceinline__ void group_note(const Ctx &c, int slot, unsigned long long w_old, unsigned long long w_new) {
     const int grp = slot >> c.gs_log2;
-    if (w_new > w_old) atomicMax(gen(&c.ub[grp]), w_new);
-    c.gdirty[grp] = 1;
+    if (w_new > w_old) {
+        atomicMax(gen(&c.ub[grp]), w_new);
+#ifdef DA_AB_PLAIN_FLAG
+        c.gdirty[grp] = 1u;
+#else
+        atomicOr(gen(&c.gdirty[grp]), 1u);
+#endif
+    } else {
+#ifdef DA_AB_NO_GLOW  // (A/B: the lazy scheme -- still exact, stale bounds are found when the floor meets them)
+        c.gdirty[grp] = 1u;
+#else
+        atomicMax(gen(&c.glow[grp]), w_old);
+#endif
+    }
 }
 // one lane: the best entry (rank > 0) of a block as it stands after this launch -- a candidate for the next pick if it reaches the
 // entry the step leaves untouched (rare by construction: at most a handful per step)
@@ -552,8 +576,12 @@ __device__ bool table_insert(const Ctx &c, uint32_t lo, uint32_t hi, const RowIn
 }
 
 // lane 0: publish the re-evaluated best key of a block (or delete the block when no count >= 2 is left)
+// bound word of a block's best entry as its header holds it
+__device__ __forceinline__ unsigned long long hdr_word(unsigned long long key, uint32_t rank, uint32_t idx) {
+    return rank ? bound_word(rank, tie_word((uint32_t)key, (uint32_t)(key >> 32), (int)idx)) : 0ull;
+}
 __device__ __forceinline__ void block_commit(const Ctx &c, int slot, unsigned long long key, const BlkHdr &h, unsigned long long best, int alive) {
-    const unsigned long long w_old = h.rank ? bound_word(h.rank, tie_word((uint32_t)key, (uint32_t)(key >> 32), (int)h.idx)) : 0ull;
+    const unsigned long long w_old = hdr_word(key, h.rank, h.idx);
     if (!alive) {
         c.hrank[slot] = 0;
         c.hkey[slot] = c.tomb;
@@ -675,7 +703,8 @@ __global__ void __launch_bounds__(256) k_init_state(ChainDev *chains) {
     fill16(ch.hkey, sizeof(unsigned long long) * (size_t)ch.C, 0xFFFFFFFFu, t0, stride);
     fill16(ch.hrank, sizeof(uint32_t) * (size_t)ch.C, 0u, t0, stride);
     fill16(ch.ub, sizeof(unsigned long long) * (size_t)ch.n_groups, 0u, t0, stride);
-    fill16(ch.gdirty, (size_t)ch.n_groups, 0x01010101u, t0, stride);
+    fill16(ch.glow, sizeof(unsigned long long) * (size_t)ch.n_groups, 0u, t0, stride);
+    fill16(ch.gdirty, sizeof(uint32_t) * (size_t)ch.n_groups, 1u, t0, stride);
     fill16(ch.colbits, sizeof(uint32_t) * (size_t)ch.n_out * ch.cb_words, 0u, t0, stride);
 }
 
@@ -802,7 +831,7 @@ template <class Cell, bool SHARDED = false> __device__ __forceinline__ int selec
     DA_GLOBAL da_i4 *picks = (DA_GLOBAL da_i4 *)g->picks;
     DA_GLOBAL int32_t *cs_slab = (DA_GLOBAL int32_t *)g->cs_slab, *cs_flags = (DA_GLOBAL int32_t *)g->cs_flags;
     pin_sgpr(was_done, had_error, iter, n_groups, lcap, claim_words, n_rows0, rcap, cbw, adder_size, carry_size, offN, rl_cap, n_live0, live_peak0, step_mant, step_tab, n_step_mant);
-    pin_sgpr(c.n_out, c.n_bits, c.K, c.Kpad, c.method, c.gs_log2, c.pb_log2, c.cmask, c.windows, c.hkey, c.hrank, c.hblk, c.ub, c.gdirty, c.rows);
+    pin_sgpr(c.n_out, c.n_bits, c.K, c.Kpad, c.method, c.gs_log2, c.pb_log2, c.cmask, c.windows, c.hkey, c.hrank, c.hblk, c.ub, c.glow, c.gdirty, c.rows);
     pin_sgpr(collen, gtie_arr, rowoff, rl, mA, mB, mcol, collist, cmap, colbits, pl_ids, plist, picks);
     if constexpr (SHARDED) pin_sgpr(cs_slab, cs_flags);
     ctx_finish(c);
@@ -886,7 +915,7 @@ template <class Cell, bool SHARDED = false> __device__ __forceinline__ int selec
         const bool want_log2 = (adder_size >= 0 || carry_size >= 0) && tid < (int)(sizeof(Log2Table) / 4);
         const uint32_t l2w = want_log2 ? reinterpret_cast<const uint32_t *>(&c_log2)[tid] : 0u;
         bool in[4];
-        uint8_t dv[4];
+        uint32_t dv[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int q = wid * GPW + lane + u * WAVE;
@@ -895,6 +924,8 @@ template <class Cell, bool SHARDED = false> __device__ __forceinline__ int selec
             ubr[u] = c.ub[qc];
             dv[u] = c.gdirty[qc];
             gtr[u] = gtie_arr[qc];  // the stored tie word (exact while the group is clean): with the bounds, not a round trip later
+            const unsigned long long gl = c.glow[qc];
+            if (ubr[u] != 0 && gl >= ubr[u]) dv[u] |= 2u;  // an entry that had reached the bound was lowered (group_note): not clean
         }
         if (tid < n_out) {
             s_clen[tid] = clen0;
@@ -1013,6 +1044,7 @@ template <class Cell, bool SHARDED = false> __device__ __forceinline__ int selec
                 c.ub[grp] = exact;
                 gtie_arr[grp] = gt;
                 c.gdirty[grp] = 0;
+                c.glow[grp] = 0;
                 if (exact) atomicMax(&s_floor, exact);
             }
             if (grank > wrank || (grank == wrank && gt > wtie)) {
@@ -1488,12 +1520,13 @@ template <class Cell> __device__ __forceinline__ void search_body(ChainDev *g, i
     const DA_GLOBAL CandEntry *cl_prev = (const DA_GLOBAL CandEntry *)&g->c_list[par ^ 1][0];
     DA_GLOBAL CandEntry *ll_out = (DA_GLOBAL CandEntry *)&g->l_list[par][0];
     pin_sgpr(was_done, had_error, n_groups, sp_word, sp_tie, cn_prev);
-    pin_sgpr(c.gs_log2, c.cmask, c.hkey, c.hrank, c.ub, c.gdirty, c.rows);
+    pin_sgpr(c.gs_log2, c.cmask, c.hkey, c.hrank, c.ub, c.glow, c.gdirty, c.rows);
     pin_sgpr(gtie_arr, rowoff, cl_prev, ll_out);
     if (was_done || had_error != E_OK) return;  // (the substitution block stops the chain)
     __shared__ unsigned long long q_floor, q_red_tie[NW], q_ub[GPL][SEL2_THREADS];
     __shared__ uint32_t q_work[MAX_GROUPS];  // groups still to be read after round 0: index into q_ub | dirty << 31
-    __shared__ unsigned int q_wn;
+    __shared__ uint32_t q_sl[MAX_GROUPS];    // groups whose bound is stale (their best entry was lowered): index into q_ub
+    __shared__ unsigned int q_wn, q_sn, q_stake;
     __shared__ uint32_t q_red_rank[NW];
     __shared__ CandEntry q_L[QL_CAP];
     __shared__ unsigned int q_Ln, q_Lout;
@@ -1524,6 +1557,8 @@ template <class Cell> __device__ __forceinline__ void search_body(ChainDev *g, i
             q_Ln = 0;
             q_Lout = 0;
             q_wn = 0;
+            q_sn = 0;
+            q_stake = 0;
         }
         uint32_t nr = 0;  // this lane's best entry so far outside the excluded rows
         unsigned long long nt = 0;
@@ -1551,10 +1586,10 @@ template <class Cell> __device__ __forceinline__ void search_body(ChainDev *g, i
         // read); a lane holds only its highest one in registers (top, top_u) and one bit per group: dirty.
         unsigned long long cl = 0, top = 0;
         int top_u = 0;
-        uint32_t dmask = 0;
+        uint32_t dmask = 0, rmask = 0;  // per group of this lane: not verified (a read tightens it) / bound stale (read in any case)
         {
-            unsigned long long ubv[GPL], gtr[GPL];
-            uint8_t dv[GPL];
+            unsigned long long ubv[GPL], gtr[GPL], glv[GPL];
+            uint32_t dv[GPL];
 #pragma unroll
             for (int u = 0; u < GPL; ++u) {
                 const int q = wid * GPW + lane + u * WAVE;
@@ -1562,13 +1597,18 @@ template <class Cell> __device__ __forceinline__ void search_body(ChainDev *g, i
                 ubv[u] = c.ub[qc];
                 dv[u] = c.gdirty[qc];
                 gtr[u] = gtie_arr[qc];
+                glv[u] = c.glow[qc];
             }
 #pragma unroll
             for (int u = 0; u < GPL; ++u) {
                 const int q = wid * GPW + lane + u * WAVE;
                 const bool in = lane + u * WAVE < GPW && q < n_groups;
                 unsigned long long cand = 0;  // bound of a group that may have to be read
-                if (in && ubv[u] != 0) {
+                if (in && ubv[u] != 0 && glv[u] >= ubv[u]) {  // an entry that had reached the bound was lowered: the bound may be stale.  Read by a wave that has nothing else to do (or, like any
+                    cand = ubv[u] ? ubv[u] : 1ull;  // group, when the bound reaches the floor): the backlog stays short and never arrives all at once
+                    dmask |= 1u << u;
+                    rmask |= 1u << u;
+                } else if (in && ubv[u] != 0) {
                     if (dv[u]) {
                         cand = ubv[u];
                         dmask |= 1u << u;
@@ -1581,22 +1621,25 @@ template <class Cell> __device__ __forceinline__ void search_body(ChainDev *g, i
                     }
                 }
                 q_ub[u][tid] = cand;
-                if (cand > top) {
+                if (cand > top && !(rmask >> u & 1u)) {  // (round 0 takes the highest group that has to reach the floor; the stale ones go to the work list)
                     top = cand;
                     top_u = u;
                 }
             }
         }
         if (pass == (fast ? 1 : 0)) { Q_TIMER_MARK(1) }
-        __syncthreads();  // q_floor zeroed
+        __syncthreads();  // q_floor and the list counters zeroed
         cl = wave_max_u64(cl);
         if (lane == 0 && cl) atomicMax(&q_floor, cl);
+#pragma unroll
+        for (int u = 0; u < GPL; ++u)
+            if (rmask >> u & 1u) q_sl[atomicAdd(&q_sn, 1u)] = (uint32_t)(u * SEL2_THREADS + tid);
         __syncthreads();
         // read one group (by one wavefront): every slot whose rank reaches the floor's is a candidate (or, touching an excluded row, listed); a
         // dirty group's bound is tightened.  (All ranks, keys and indices in ONE round trip was measured too: 114 registers per thread, and a
         // 1024-thread block of this kernel then needs a CU without a single k_iter_update block -- in the batch 1 % of the launches waited
         // > 200 us for one.  This form fits the 64 registers of eight waves per SIMD.)
-        auto read_group = [&](const uint32_t grp, const bool dirty, const unsigned long long bound, const unsigned long long fl) {
+        auto read_group = [&](const uint32_t grp, const bool dirty, const unsigned long long /*bound*/, const unsigned long long fl) {
             const uint32_t base = grp * gs;
             // ---- round trip 1: the ranks of all slots (one dense array, coalesced; 8 slots per lane)
             uint32_t rk[8], grank = 0;
@@ -1615,9 +1658,10 @@ template <class Cell> __device__ __forceinline__ void search_body(ChainDev *g, i
             for (int o = lane + 8 * WAVE; o < gs; o += WAVE) grank = max(grank, c.hrank[base + o]);
             grank = wave_max_u32(grank);
             // only slots whose rank reaches the floor's can matter (the floor's own rank included: the tie word decides)
-            const uint32_t fr = (uint32_t)(fl >> 32), thr = fr ? fr : 1u;
+            // (a group that is not verified is left exact: at least its best slots are read)
+            const uint32_t fr = (uint32_t)(fl >> 32), thr0 = fr ? fr : 1u, thr = dirty && grank != 0 && grank < thr0 ? grank : thr0;
             unsigned long long gt = 0, lw = 0;
-            if (grank >= thr) {  // (wave-uniform: a group whose stale bound promised more than it holds costs nothing beyond the ranks)
+            if (grank >= thr) {  // (wave-uniform: a clean group whose excluded best entry was all it held that high costs nothing beyond the ranks)
                 // ---- round trip 2: key and best-key index of those slots -- a lane takes its slots one per turn, all lanes' loads of a turn in
                 // flight together (nearly always a single turn: a handful of the 512 slots qualify)
                 uint32_t want = 0;
@@ -1648,29 +1692,20 @@ template <class Cell> __device__ __forceinline__ void search_body(ChainDev *g, i
                 }
                 if (lw > fl) atomicMax(&q_floor, lw);
             }
-            unsigned long long left = 0;  // what the group may still hold for this pass: nothing once it has been read, unless it stays dirty below the floor
-            if (dirty) {
-                // tighten the group's bound.  Its best entry is known exactly when its rank reaches the floor's (the tie words were formed):
-                // the group becomes clean; otherwise (rank below the floor's) the bound drops to "that rank, any key" and the group stays dirty
-                const bool exact_known = grank >= thr || grank == 0;
-                if (exact_known) gt = wave_max_u64(gt);
-                const unsigned long long nb = grank == 0 ? 0ull : exact_known ? bound_word(grank, gt) : (((unsigned long long)grank << 32) | 0xFFFFFFFFull);
+            if (dirty) {  // the group's bound and tie word, exact again
+                gt = wave_max_u64(gt);
                 if (lane == 0) {
-                    if (exact_known) {
-                        c.ub[grp] = nb;
-                        gtie_arr[grp] = gt;
-                        c.gdirty[grp] = 0;
-                    } else if (nb < bound)
-                        c.ub[grp] = nb;
+                    c.ub[grp] = grank ? bound_word(grank, gt) : 0ull;
+                    gtie_arr[grp] = gt;
+                    c.gdirty[grp] = 0;
+                    c.glow[grp] = 0;
                 }
-                if (!exact_known) left = nb < bound ? nb : bound;
             }
             ++rescans;
 #ifdef DA_PHASE_TIMERS
-            q_stale += dirty && grank < thr;
+            q_stale += dirty && grank < thr0;
             q_touch += !dirty;
 #endif
-            return left;
         };
         // ---- round 0: every wave reads its highest group that is dirty (bound possibly stale) or whose best entry is excluded, if that
         // bound reaches the floor of the clean groups.  The floor rises to (nearly) the answer.
@@ -1681,8 +1716,17 @@ template <class Cell> __device__ __forceinline__ void search_body(ChainDev *g, i
                 const int owner = __ffsll((long long)__ballot(top == wtop)) - 1;
                 const int own_u = __builtin_amdgcn_readlane(top_u, owner);
                 const bool own_dirty = (((uint32_t)__builtin_amdgcn_readlane((int)dmask, owner) >> own_u) & 1u) != 0;
-                const unsigned long long left = read_group((uint32_t)(wid * GPW + owner + own_u * WAVE), own_dirty, wtop, fl);
-                if (lane == owner) q_ub[own_u][tid] = left;
+                read_group((uint32_t)(wid * GPW + owner + own_u * WAVE), own_dirty, wtop, fl);
+                if (lane == owner) q_ub[own_u][tid] = 0;
+            } else {  // nothing of its own to read: one of the groups with a stale bound, if there are any
+                unsigned int k = 0;
+                if (lane == 0) k = atomicAdd(&q_stake, 1u);
+                k = (unsigned int)__builtin_amdgcn_readfirstlane((int)k);
+                if (k < q_sn) {
+                    const uint32_t at = q_sl[k];
+                    const int u = (int)(at / SEL2_THREADS), t = (int)(at % SEL2_THREADS);
+                    read_group((uint32_t)((t / WAVE) * GPW + (t % WAVE) + u * WAVE), true, 0ull, fl);
+                }
             }
         }
         __syncthreads();
@@ -1693,7 +1737,7 @@ template <class Cell> __device__ __forceinline__ void search_body(ChainDev *g, i
 #pragma unroll
             for (int u = 0; u < GPL; ++u) {
                 const unsigned long long v = q_ub[u][tid];
-                if (v != 0 && v >= fl) q_work[atomicAdd(&q_wn, 1u)] = (uint32_t)(u * SEL2_THREADS + tid) | (((dmask >> u) & 1u) << 31);
+                if (v != 0 && v >= fl && !(rmask >> u & 1u)) q_work[atomicAdd(&q_wn, 1u)] = (uint32_t)(u * SEL2_THREADS + tid) | (((dmask >> u) & 1u) << 31);
             }
         }
         __syncthreads();
@@ -1707,13 +1751,17 @@ template <class Cell> __device__ __forceinline__ void search_body(ChainDev *g, i
                 g->st_qdiag[8] += wn;
             }
 #endif
-            for (unsigned int i = (unsigned int)wid; i < wn; i += NW) {  // (wave-uniform)
-                const uint32_t info = q_work[i], at = info & 0x7FFFFFFFu;
+            // the work list, then the stale groups round 0 left: those ride in the rounds the work list needs anyway (waves that would idle), beyond
+            // that only the ones whose bound reaches the floor are read now
+            const unsigned int sn = q_sn, taken = min(q_stake, sn), rounds = max((wn + NW - 1) / NW, min(2u, (sn - taken) / 48u));  // (a long backlog -- the first steps of a chain -- gets rounds of its own)
+            for (unsigned int i = (unsigned int)wid; i < wn + (sn - taken); i += NW) {  // (wave-uniform)
+                const bool listed = i < wn;
+                const uint32_t info = listed ? q_work[i] : q_sl[taken + (i - wn)], at = info & 0x7FFFFFFFu;
                 const int u = (int)(at / SEL2_THREADS), t = (int)(at % SEL2_THREADS);
                 const unsigned long long bound = q_ub[u][t];
                 const unsigned long long fl = __hip_atomic_load(&q_floor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (bound < fl) continue;  // the floor has risen past it meanwhile
-                (void)read_group((uint32_t)((t / WAVE) * GPW + (t % WAVE) + u * WAVE), (info >> 31) != 0, bound, fl);
+                if (bound < fl && (listed || i / NW >= rounds)) continue;  // the floor has risen past it meanwhile / a stale group that can wait
+                read_group((uint32_t)((t / WAVE) * GPW + (t % WAVE) + u * WAVE), !listed || (info >> 31) != 0, bound, fl);
 #ifdef DA_PHASE_TIMERS
                 if (pass) ++q_rounds;
 #endif
@@ -2213,7 +2261,7 @@ template <class Cell> __device__ __forceinline__ int pick_body(ChainDev *g, unsi
 // number of the lockstep iteration = the `iter` of every chain of the launch that has not finished (kernel argument: the search
 // block must not read a field the substitution block writes during the launch).
 #ifndef DA_SEL2_WAVES
-#define DA_SEL2_WAVES 8  // wavefronts per SIMD the register budget of k_iter_select2 is capped for: 64 registers, so that a 1024-thread block shares a CU with k_iter_update blocks
+#define DA_SEL2_WAVES 4  // wavefronts per SIMD the register budget of k_iter_select2 is capped for (measured 4 .. 8: the spills of 5 and more cost more than the smaller footprint gains)
 #endif
 template <class Cell> __global__ void __launch_bounds__(SEL2_THREADS) __attribute__((amdgpu_waves_per_eu(DA_SEL2_WAVES, DA_SEL2_WAVES))) k_iter_select2(ChainDev *chains, int n_chains, unsigned int *n_done, int step) {
     if ((int)blockIdx.x >= n_chains) return;
@@ -2283,7 +2331,7 @@ template <class Cell> __device__ __forceinline__ UpdStep<Cell> load_upd_step(Cha
     u.rl = (const DA_GLOBAL Entry *)gq->rlist;
     u.plist = (const DA_GLOBAL unsigned long long *)gq->plist;
     pin_sgpr(u.done, u.n_partners, iter, u.m, u.n_in, u.A, u.B, u.Nw, u.mcol, u.mA, u.mB, u.cmap, u.rl, u.plist);
-    pin_sgpr(u.c.n_out, u.c.n_bits, u.c.K, u.c.Kpad, u.c.method, u.c.gs_log2, u.c.pb_log2, u.c.cmask, u.c.windows, u.c.hkey, u.c.hrank, u.c.hblk, u.c.ub, u.c.gdirty, u.c.rows);
+    pin_sgpr(u.c.n_out, u.c.n_bits, u.c.K, u.c.Kpad, u.c.method, u.c.gs_log2, u.c.pb_log2, u.c.cmask, u.c.windows, u.c.hkey, u.c.hrank, u.c.hblk, u.c.ub, u.c.glow, u.c.gdirty, u.c.rows);
     pin_sgpr(u.c.rword, u.c.cn, u.c.cl);
     u.c.tomb = KEY_TOMB - (unsigned long long)((2 * iter - 1) & 3);
     ctx_finish(u.c);
@@ -3077,7 +3125,8 @@ size_t carve_chain(unsigned char *base, const ChainJob &job, const Geometry &g, 
     d.hblk = c.take<unsigned char>((size_t)g.C << g.pb_log2);
     d.ub = c.take<unsigned long long>(g.n_groups);
     d.gtie = c.take<unsigned long long>(g.n_groups);
-    d.gdirty = c.take<uint8_t>(g.n_groups);
+    d.glow = c.take<unsigned long long>(g.n_groups);
+    d.gdirty = c.take<uint32_t>(g.n_groups);
     d.mcol = c.take<int>(n_out);
     d.cmap = c.take<uint16_t>(n_out);
     d.colbits = c.take<uint32_t>(n_out * (size_t)((g.rcap + 31) / 32));
@@ -3743,7 +3792,8 @@ class HipShardEngine : public ShardEngine {
         HIP_CHECK(hipMemsetAsync(d_.hkey, 0xFF, sizeof(unsigned long long) * (size_t)g.C, st_));
         HIP_CHECK(hipMemsetAsync(d_.hrank, 0, sizeof(uint32_t) * (size_t)g.C, st_));
         HIP_CHECK(hipMemsetAsync(d_.ub, 0, sizeof(unsigned long long) * (size_t)g.n_groups, st_));
-        HIP_CHECK(hipMemsetAsync(d_.gdirty, 1, (size_t)g.n_groups, st_));
+        HIP_CHECK(hipMemsetAsync(d_.glow, 0, sizeof(unsigned long long) * (size_t)g.n_groups, st_));
+        HIP_CHECK(hipMemsetAsync(d_.gdirty, 1, sizeof(uint32_t) * (size_t)g.n_groups, st_));  // (any non-zero value: not verified)
         d_.cb_words = (g.rcap + 31) / 32;
         HIP_CHECK(hipMemsetAsync(d_.colbits, 0, sizeof(uint32_t) * (size_t)n_loc_ * d_.cb_words, st_));
         {
