@@ -456,17 +456,19 @@ def main():
     #   k_iter_update: per partner row its cells in the substituted columns and two 8-byte pair keys; per touched count block its
     #     interval record, rank and K u16 counts read + written; per created block key + record + rank + index + K counts + the
     #     partner's interval
-    #   k_iter_select: bounds, dirty flags and tie words of all groups, every re-read group, both row lists read and written back,
-    #     the row bitmaps of the substituted columns, partner ids / references, the hand-off stores (st_sel_bytes in the kernel)
+    #   k_iter_select2 (two workgroups per chain: search + substitution): bound, flags, tie word and lowered-value mark of all groups,
+    #     every re-read group, the pick (64 B), both row lists read and written back, the row bitmaps of the substituted columns,
+    #     partner ids / references, the hand-off stores, the six special-pair count vectors (st_sel_bytes in the kernel + the host's
+    #     pricing of the search, HipBackend::run_chains)
     K = 2 * (2 * 8 - 1)
     alg = {'k_iter_update': tm['cell_bytes'] + 16.0 * tm['partners'] + tm['found'] * (12.0 + 4.0 * K) + tm['inserts'] * (37.0 + 2.0 * K),
-           'k_iter_select': tm['select_bytes']}
-    avg_us = {'k_iter_update': upd_avg_us, 'k_iter_select': sel_avg_us}
+           'k_iter_select2': tm['select_bytes']}
+    avg_us = {'k_iter_update': upd_avg_us, 'k_iter_select2': sel_avg_us}
     tag, meta = newest_pmc_meta()
     fresh = bool(meta) and meta.get('src_sha256') == source_digest()
     launches = tm['lockstep_iters'] * max(1.0, round(batch / max(chains_per_launch, 1.0)))
     kernels = {}
-    for name in ('k_iter_select', 'k_iter_update'):
+    for name in ('k_iter_select2', 'k_iter_update'):
         per_launch = alg[name] / iters * chains_per_launch
         ach = per_launch / (avg_us[name] * 1e-6) / 1e9 if avg_us[name] > 0 else 0.0
         k = {'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS, 'alg_bytes_per_launch': per_launch,
@@ -492,7 +494,7 @@ def main():
                 'traffic_source': f'profiles/{tag}_pmc_*: (2 x FETCH_SIZE + WRITE_SIZE) KiB per dispatch (gfx950 correction of MI355X_MICROARCH.md), scaled to the live chains per launch' if fresh else None,
                 # the chain groups' launches overlap (4 streams): the algorithmic bytes of both kernels over the whole greedy loop
                 'whole_loop': {'achieved': sum(alg.values()) / loop_s / 1e9, 'unit': 'GB/s', 'frac': sum(alg.values()) / loop_s / 1e9 / HBM_PEAK_GBS,
-                               'what': 'algorithmic bytes of all k_iter_select + k_iter_update launches of the timed steps / their greedy-loop time (concurrent chain groups included)'},
+                               'what': 'algorithmic bytes of all k_iter_select2 + k_iter_update launches of the timed steps / their greedy-loop time (concurrent chain groups included)'},
                 'note': 'bound by dependent memory round trips into an HBM-resident pair table and by wave slots, not by bytes or VALU; see DESIGN.md section 5'}  # fmt: skip
     line = {
         'metric': 'CMVM solves/sec, 256x256 int8 matrix' if n_in == 256 else f'CMVM solves/sec, {n_in}x{n_out} int8 matrix',
@@ -517,6 +519,10 @@ def main():
                    # the launch thread: host time spent queueing the loop's launches vs the time the device needed for them
                    'host_launch_us_per_iter': 1e3 * tm['host_launch_ms'] / max(tm['lockstep_iters'], 1.0),
                    'host_launch_share_of_loop': tm['host_launch_ms'] / max(tm['loop_ms'], 1e-9),
+                   # k_iter_select2: steps whose pick was known before the step began (the best entry the previous step left untouched, or one of
+                   # the few entries its update listed): no bounds, no arg-max in front of the substitution
+                   'picks_known_a_step_ahead': tm['fast_steps'] / max(tm['iterations'], 1.0),
+                   'group_rereads_per_chain_step': tm['rescans'] / max(tm['iterations'], 1.0),
                    'source_digest': source_digest()},  # fmt: skip
         'check': check,
     }

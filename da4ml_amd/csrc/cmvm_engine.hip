@@ -3676,8 +3676,8 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
         im.timings.cell_bytes += (geo[i].wide ? 8.0 : 4.0) * (double)d.st_cells;
         im.timings.iterations += d.iter;
         im.timings.rescans += (long long)d.st_rescans;
-        // + the search block: bound, dirty flag and tie word of every group per step, and per re-read group its ranks and ~2 slots' key and index
-        im.timings.select_bytes += (double)d.st_sel_bytes + 17.0 * (double)d.n_groups * (double)d.iter + (double)d.st_rescans * ((double)(4u << d.gs_log2) + 24.0);
+        // + the search block: bound, flags, tie word and lowered-value mark of every group per step (28 B), and per re-read group its ranks and ~2 slots' key and index
+        im.timings.select_bytes += (double)d.st_sel_bytes + 28.0 * (double)d.n_groups * (double)d.iter + (double)d.st_rescans * ((double)(4u << d.gs_log2) + 24.0);
         im.timings.partners += (long long)d.st_partners;
         im.timings.table_bytes += (double)d.C * (8.0 + 4.0 + (double)(1 << d.pb_log2));
     }

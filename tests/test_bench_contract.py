@@ -54,12 +54,12 @@ def test_pmc_traffic_helper_reads_the_committed_passes():
 
     tag, meta = bench.newest_pmc_meta()
     assert tag and meta and meta['chains_per_dispatch'] >= 1
-    for kernel in ('k_iter_select', 'k_iter_update'):
+    for kernel in ('k_iter_select2', 'k_iter_update'):
         tr = bench.pmc_traffic(kernel, tag)
         assert tr and tr[0] > tr[1] > 0  # corrected (2 x FETCH_SIZE + WRITE_SIZE) above the raw sum
     r = _last_bench_line()['roofline']
     if 'kernels' in r:
-        assert set(r['kernels']) == {'k_iter_select', 'k_iter_update'} and r['kernel'] in r['kernels']
+        assert set(r['kernels']) == {'k_iter_select2', 'k_iter_update'} and r['kernel'] in r['kernels']
         for name, k in r['kernels'].items():
             assert abs(k['frac'] - k['achieved'] / k['peak']) < 1e-12
             assert abs(k['achieved'] - k['alg_bytes_per_launch'] / (k['avg_launch_us'] * 1e-6) / 1e9) < 1e-6 * max(k['achieved'], 1e-9)
