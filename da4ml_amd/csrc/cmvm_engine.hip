@@ -3059,6 +3059,7 @@ struct HipBackend::Impl {
     hipStream_t stream = nullptr;
     static constexpr int MAX_LANES = 8;
     hipStream_t lanes[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // greedy-loop streams of the chain groups
+    int launch_threads = 2;  // host threads queueing the greedy loop's launches (each its share of the chain groups); DA4ML_HIP_LAUNCH_THREADS
     int n_lanes = 4;  // chain groups = greedy-loop streams.  Measured (C3 batch 64, loop ms): 2 -> 880, 3 -> 871, 4 -> 838, 5..8 -> 1470:
                       // four hardware queues; the poll stream's rare copies share one of them at no visible cost
     int upd_total_blocks = 2560;  // k_iter_update blocks over all chains of a batch (4 waves x 4 groups each); measured (C3 batch 64,
@@ -3080,6 +3081,7 @@ HipBackend::HipBackend(int device) : impl_(new Impl) {
     if (const char *e = std::getenv("DA4ML_HIP_TABLE_SCALE")) impl_->table_scale = std::max(1e-4, std::atof(e));
     if (const char *e = std::getenv("DA4ML_HIP_ROW_SCALE")) row_scale_ = std::max(1e-4, std::atof(e));
     if (const char *e = std::getenv("DA4ML_HIP_UPD_BLOCKS")) impl_->upd_total_blocks = std::max(2, std::atoi(e));
+    if (const char *e = std::getenv("DA4ML_HIP_LAUNCH_THREADS")) impl_->launch_threads = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("DA4ML_HIP_LANES")) impl_->n_lanes = std::max(1, std::min((int)Impl::MAX_LANES, std::atoi(e)));
     HIP_CHECK(hipMalloc(&impl_->d_done, sizeof(unsigned int)));
     HIP_CHECK(hipHostMalloc(&impl_->h_done, 2 * sizeof(unsigned int), hipHostMallocDefault));
@@ -3441,9 +3443,7 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
         if (se) HIP_CHECK(hipEventRecord(se[2], gr.stream));
     };
     // Windows of up to WINDOW_ITERS iterations x all groups are queued eagerly; one event-bracketed iteration per window
-    // samples the kernel durations.  (A hipGraph replay of the window and one launching host thread per group were
-    // re-measured in round 2 with the shorter kernels: no gain at batch 64 or 8 -- the host keeps the queues full at
-    // ~8 us per launch -- and were removed.)
+    // samples the kernel durations.  (A hipGraph replay of the window was re-measured in round 2: no gain.)
     constexpr int WINDOW_ITERS = 63, MAX_SAMPLES = 4096;
     std::vector<hipEvent_t> sample_ev;
     int n_samples = 0;
@@ -3473,33 +3473,84 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
             (void)hipStreamSynchronize(poll);
         }
     } drain{groups, im.poll_stream};
+    // A second launching thread takes every other chain group: with the shorter kernels of round 5 one thread queueing all launches
+    // (2.85 us each, 8 per lockstep iteration of 4 groups) is the bound for small problems (64x64: 22.9 of 24.6 us per iteration, measured).
+    // It follows the windows of this thread: (first step, iterations) in, its groups' end-of-window events recorded out.
+    struct Helper {
+        std::atomic<long long> seq{0}, ack{0};
+        std::atomic<bool> quit{false};
+        long long first_step = 0;
+        int iters = 0, parity = 0;
+        std::exception_ptr err;
+        std::thread th;
+    } helper;
+    const bool two_threads = im.launch_threads >= 2 && groups.size() >= 2;
+    auto mine = [&](size_t gi, int who) { return !two_threads || (int)(gi & 1) == who; };
+    auto window_launches = [&](int who, long long first_step, int iters, int parity, hipEvent_t *se0) {
+        for (int it = 0; it < iters; ++it)
+            for (size_t gi = 0; gi < groups.size(); ++gi)
+                if (mine(gi, who)) launch_pair(groups[gi], it == 0 && gi == 0 ? se0 : nullptr, (int)(first_step + it));
+        HIP_CHECK(hipGetLastError());
+        for (size_t gi = 0; gi < groups.size(); ++gi)
+            if (mine(gi, who)) HIP_CHECK(hipEventRecord(win_ev[parity][gi], groups[gi].stream));
+    };
+    if (two_threads)
+        helper.th = std::thread([&] {
+            long long seen = 0;
+            try {
+                HIP_CHECK(hipSetDevice(im.device));
+                while (true) {
+                    long long s;
+                    while ((s = helper.seq.load(std::memory_order_acquire)) == seen && !helper.quit.load(std::memory_order_acquire)) __builtin_ia32_pause();
+                    if (s == seen) break;
+                    seen = s;
+                    if (!helper.err) window_launches(1, helper.first_step, helper.iters, helper.parity, nullptr);
+                    helper.ack.store(seen, std::memory_order_release);
+                }
+            } catch (...) {
+                helper.err = std::current_exception();
+                helper.ack.store(helper.seq.load(), std::memory_order_release);  // (whatever window was being served: the main thread rethrows)
+                while (!helper.quit.load(std::memory_order_acquire)) {  // keep acknowledging until told to leave
+                    helper.ack.store(helper.seq.load(), std::memory_order_release);
+                    __builtin_ia32_pause();
+                }
+            }
+        });
+    struct JoinHelper {
+        Helper &h;
+        ~JoinHelper() {
+            h.quit.store(true, std::memory_order_release);
+            if (h.th.joinable()) h.th.join();
+        }
+    } join_helper{helper};
     while (active > 0) {
         const auto t_q0 = std::chrono::steady_clock::now();
         if (launched_iters > iter_cap + 2 * poll_every) throw std::runtime_error("greedy loop did not terminate within its row capacity (internal error)");
-        // sampled eager iteration (all groups; the first group's kernels are bracketed by events on its stream)
-        for (size_t gi = 0; gi < groups.size(); ++gi) {
-            hipEvent_t se[3];
-            const bool sample = gi == 0 && n_samples < MAX_SAMPLES;
-            if (sample) {
-                for (auto &e : se) {
-                    e = events.make();
-                    sample_ev.push_back(e);
-                }
-                ++n_samples;
-            }
-            launch_pair(groups[gi], sample ? se : nullptr, (int)launched_iters);
-        }
         // small problems finish within a few iterations: start with short windows, double up to the full length
         const int this_window = (int)std::min<long long>(WINDOW_ITERS, (8ll << std::min<long long>(window, 8)) - 1);
-        for (int it = 0; it < this_window; ++it)
-            for (const Group &gr : groups) launch_pair(gr, nullptr, (int)launched_iters + 1 + it);
-        launched_iters += this_window + 1;
-        HIP_CHECK(hipGetLastError());
         const int p = (int)(window & 1);
-        for (size_t gi = 0; gi < groups.size(); ++gi) {
-            HIP_CHECK(hipEventRecord(win_ev[p][gi], groups[gi].stream));
-            HIP_CHECK(hipStreamWaitEvent(im.poll_stream, win_ev[p][gi], 0));
+        if (two_threads) {
+            helper.first_step = launched_iters, helper.iters = this_window + 1, helper.parity = p;
+            helper.seq.fetch_add(1, std::memory_order_release);
         }
+        // the first iteration of a window is the sampled one: the first group's kernels are bracketed by events on its stream
+        hipEvent_t se[3];
+        const bool sample = n_samples < MAX_SAMPLES;
+        if (sample) {
+            for (auto &e : se) {
+                e = events.make();
+                sample_ev.push_back(e);
+            }
+            ++n_samples;
+        }
+        window_launches(0, launched_iters, this_window + 1, p, sample ? se : nullptr);
+        launched_iters += this_window + 1;
+        if (two_threads) {
+            const long long want = helper.seq.load(std::memory_order_relaxed);
+            while (helper.ack.load(std::memory_order_acquire) != want) __builtin_ia32_pause();
+            if (helper.err) std::rethrow_exception(helper.err);
+        }
+        for (size_t gi = 0; gi < groups.size(); ++gi) HIP_CHECK(hipStreamWaitEvent(im.poll_stream, win_ev[p][gi], 0));
         HIP_CHECK(hipMemcpyAsync(&im.h_done[p], im.d_done, sizeof(unsigned int), hipMemcpyDeviceToHost, im.poll_stream));
         HIP_CHECK(hipEventRecord(copy_ev[p], im.poll_stream));
         host_launch_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_q0).count();
