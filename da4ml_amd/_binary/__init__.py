@@ -361,9 +361,6 @@ class RawBatch:
             arr = [np.zeros(k, np.int64) for k in (n_in, n_out, n_out, n_out)]
             oi, of = np.zeros((n, 4), np.int64), np.zeros((n, 5), np.float32)
             L.da_stage_copy(h, s, *arr, oi, of)
-            c = np.float32(0)
-            for v in of[:, 4]:  # float32 accumulation in op order, like the reference's candidate cost (api.cc:222-229)
-                c = np.float32(c + v)
             cost += float(of[:, 4].astype(np.float64).sum())
             adders += int(np.isin(oi[:, 2], (0, 1)).sum())
             n_ops.append(n)

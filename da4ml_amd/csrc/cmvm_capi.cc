@@ -35,24 +35,34 @@ thread_local int g_err_code = DA_OK;  // DA_ERR_* of the calling thread's last f
 struct LibraryMutex {
     std::mutex m;
     static thread_local bool mine;
+    static std::atomic<bool> busy;      // some thread is inside a library call
+    static std::atomic<bool> poisoned;  // this process is the child of a fork taken while ANOTHER thread was inside a call: the copied
+                                        // state (backend, host pool, device buffers) was caught mid-update -- every later call says so
     void lock() {
         m.lock();
         mine = true;
+        busy.store(true, std::memory_order_relaxed);
     }
     void unlock() {
+        busy.store(false, std::memory_order_relaxed);
         mine = false;
         m.unlock();
     }
     LibraryMutex() {
         pthread_atfork(nullptr, nullptr, [] {
-            if (!mine) new (&instance->m) std::mutex();  // (the inherited one may be locked by a thread that was not copied; it is never
-                                                         // destroyed.  Held by the forking thread itself: it exists in the child and goes on holding it)
+            if (!mine) {
+                if (busy.load(std::memory_order_relaxed)) poisoned.store(true, std::memory_order_relaxed);
+                new (&instance->m) std::mutex();  // (the inherited one may be locked by a thread that was not copied; it is never
+                busy.store(false, std::memory_order_relaxed);  // destroyed.  Held by the forking thread itself: it exists in the child and goes on holding it)
+            }
         });
         instance = this;
     }
     static LibraryMutex *instance;
 };
 thread_local bool LibraryMutex::mine = false;
+std::atomic<bool> LibraryMutex::busy{false};
+std::atomic<bool> LibraryMutex::poisoned{false};
 LibraryMutex *LibraryMutex::instance = nullptr;
 LibraryMutex g_mutex;
 int g_device = 0;
@@ -60,6 +70,8 @@ std::unique_ptr<da::gpu::HipBackend> g_backend;
 int g_backend_device = -1;
 
 da::gpu::HipBackend &backend() {
+    if (LibraryMutex::poisoned.load(std::memory_order_relaxed))
+        throw std::runtime_error("libda4ml_hip: this process was forked while another thread was inside a solve; the copied library state is unusable here (fork between solves, or exec)");
     if (!g_backend || g_backend_device != g_device) {
         if (da::gpu::device_count() <= g_device) throw std::runtime_error("no HIP device " + std::to_string(g_device) + " available (libda4ml_hip has no CPU path)");
         g_backend.reset(new da::gpu::HipBackend(g_device));

@@ -70,7 +70,9 @@ void ShardedBackend::run_one(const ChainJob &job, ChainOut &out) {
         // this rank's own error if it has one; else what the summed status says about the others: a rank with a non-capacity error, or ranks
         // out of step (fewer than `world` stopped together) -> E_REMOTE_ERROR, which no caller retries; only a pure capacity failure (the
         // retries above are used up) is reported as one
-        out.error = own.error ? own.error : (status[2] != 0 || status[0] != comm_.world) ? E_REMOTE_ERROR : E_TABLE_CAPACITY;
+        // (decided on the error words first: a pure capacity failure stops only the failing rank, so status[0] != world there too -- every
+        // rank reports it as a capacity error then; "out of step" is what is left when no rank raised an error flag)
+        out.error = own.error ? own.error : status[2] != 0 ? E_REMOTE_ERROR : status[1] != 0 ? E_TABLE_CAPACITY : E_REMOTE_ERROR;
         out.n_bits = own.n_bits;
         return;
     }

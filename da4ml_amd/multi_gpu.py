@@ -71,16 +71,18 @@ def shutdown():
     exception'), which a launcher reports as a failed job."""
     import torch.distributed as dist
 
-    if _rccl_ids:  # communicators of the library's own RCCL transport: destroyed while the group is alive (every rank gets here)
-        from . import _binary
+    try:
+        if _rccl_ids:  # communicators of the library's own RCCL transport: destroyed while the group is alive (every rank gets here)
+            from . import _binary
 
-        _rccl_ids.clear()
-        _binary.rccl_shutdown()
-    if dist.is_available() and dist.is_initialized():
-        try:
-            dist.barrier()
-        finally:
-            dist.destroy_process_group()
+            _rccl_ids.clear()
+            _binary.rccl_shutdown()
+    finally:  # (a failing RCCL teardown must not leave the process group alive: that exit is what this function exists to prevent)
+        if dist.is_available() and dist.is_initialized():
+            try:
+                dist.barrier()
+            finally:
+                dist.destroy_process_group()
 
 
 def shard_bounds(n_items: int, rank: int, world: int) -> tuple[int, int]:
@@ -247,8 +249,9 @@ def pipeline_cost_f32(pipe) -> float:
 
     acc = np.float32(0.0)
     for sol in pipe.solutions:
-        for op in sol.ops:
-            acc = np.float32(acc + np.float32(op.cost))
+        costs = sol.ops._column('cost') if hasattr(sol.ops, '_column') else [op.cost for op in sol.ops]  # (a lazy OpList: no Op is built)
+        for c in costs:
+            acc = np.float32(acc + np.float32(c))
     return float(acc)
 
 
@@ -389,9 +392,19 @@ def solve_column_sharded(kernel, method0: str = 'wmc', method1: str = 'auto', ha
                 dist.broadcast(t, src=0)
                 raw = t.cpu().numpy().tobytes()
             _rccl_ids[key] = raw
-        pipe, stats = _binary.solve_sharded_rccl(kernel, raw, method0=method0, method1=method1, hard_dc=hard_dc, decompose_dc=decompose_dc, qintervals=qintervals,
-                                                 latencies=latencies, adder_size=adder_size, carry_size=carry_size, search_all_decompose_dc=search_all_decompose_dc,
-                                                 rank=rank, world=world)  # fmt: skip
+        try:
+            pipe, stats = _binary.solve_sharded_rccl(kernel, raw, method0=method0, method1=method1, hard_dc=hard_dc, decompose_dc=decompose_dc, qintervals=qintervals,
+                                                     latencies=latencies, adder_size=adder_size, carry_size=carry_size, search_all_decompose_dc=search_all_decompose_dc,
+                                                     rank=rank, world=world)  # fmt: skip
+        except BaseException:
+            # a failed solve may leave the communicator of this id wedged: forget the id (and the library's communicators), so that the next
+            # call -- on every rank: they all failed or were aborted together -- broadcasts a fresh one instead of re-using it
+            _rccl_ids.pop(key, None)
+            try:
+                _binary.rccl_shutdown()
+            except Exception:
+                pass
+            raise
         return (pipe, stats) if return_stats else pipe
     if transport != 'callback':
         raise ValueError(f"transport must be 'callback' or 'rccl', not {transport!r}")

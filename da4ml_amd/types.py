@@ -20,11 +20,12 @@ import os
 from functools import reduce
 from math import ceil, log2
 from pathlib import Path
+from collections.abc import Sequence
 from typing import NamedTuple
 
 import numpy as np
 
-__all__ = ['QInterval', 'Precision', 'Op', 'Pair', 'DAState', 'CombLogic', 'Pipeline', 'minimal_kif', 'JSONEncoder']
+__all__ = ['QInterval', 'Precision', 'Op', 'OpList', 'Pair', 'DAState', 'CombLogic', 'Pipeline', 'minimal_kif', 'JSONEncoder']
 
 
 class QInterval(NamedTuple):
@@ -51,6 +52,134 @@ class Op(NamedTuple):
     qint: QInterval
     latency: float
     cost: float
+
+
+class OpList(Sequence):
+    """The statements of a solver result as a sequence of ``Op``, built on access from the C ABI's arrays.
+
+    The reference's binding creates one Python ``Op`` (and one ``QInterval``) per statement while the result is returned
+    (reference ``_binary/cmvm/bindings.cc:106-139``): 130 k objects, 26 ms of interpreter time for a 256x256 matrix -- a batch of
+    64 results costs twice what the solve itself takes on the GPU.  Here a result keeps its two arrays (``[n, 4]`` int64 =
+    id0, id1, opcode, data; ``[n, 5]`` float64 = qint.min, qint.max, qint.step, latency, cost) and
+    this view over them: ``len``, indexing and the summaries of ``CombLogic`` (cost, adders, latencies) read the arrays; iterating,
+    slicing, comparing with a list or mutating builds the ``Op`` objects once and keeps them.  Equal to a ``list`` of the same
+    ``Op`` values, serialised as one."""
+
+    __slots__ = ('_ci', '_ff', '_ops')
+
+    def __init__(self, ci, ff):
+        self._ci, self._ff, self._ops = ci, ff, None
+
+    @classmethod
+    def from_ops(cls, ops):
+        o = cls(None, None)
+        o._ops = list(ops)
+        return o
+
+    # -- materialisation (the collector is paused: none of these tuples of numbers can be part of a cycle, and every allocation
+    # threshold crossed would start a collection that walks everything alive -- 3 x slower, measured in round 3)
+    def _all(self) -> list:
+        if self._ops is None:
+            import gc
+
+            ci = self._ci.T.tolist()
+            ff = self._ff
+            new = tuple.__new__  # what the NamedTuple constructors end in; the field order is that of the arrays
+            paused = gc.isenabled()
+            gc.disable()
+            try:
+                qints = [new(QInterval, t) for t in map(tuple, ff[:, :3].tolist())]
+                self._ops = [new(Op, t) for t in zip(ci[0], ci[1], ci[2], ci[3], qints, ff[:, 3].tolist(), ff[:, 4].tolist())] if len(ff) else []
+            finally:
+                if paused:
+                    gc.enable()
+        return self._ops
+
+    def _lazy(self) -> bool:
+        return self._ops is None
+
+    def _mutable(self) -> list:
+        ops = self._all()
+        self._ci = self._ff = None  # the arrays no longer describe the list
+        return ops
+
+    # -- Sequence
+    def __len__(self):
+        return len(self._ci) if self._ops is None else len(self._ops)
+
+    def __getitem__(self, i):
+        if self._ops is not None or isinstance(i, slice):
+            return self._all()[i]
+        r, f = self._ci[i].tolist(), self._ff[i].tolist()  # (IndexError for an index out of range, negative indices as in a list)
+        return Op(r[0], r[1], r[2], r[3], QInterval(f[0], f[1], f[2]), f[3], f[4])
+
+    def __iter__(self):
+        return iter(self._all())
+
+    def __reversed__(self):
+        return reversed(self._all())
+
+    def __contains__(self, x):
+        return x in self._all()
+
+    def __eq__(self, other):
+        if isinstance(other, OpList):
+            if self._ops is None and other._ops is None:
+                return np.array_equal(self._ci, other._ci) and np.array_equal(self._ff, other._ff)
+            return self._all() == other._all()
+        if isinstance(other, list):
+            return self._all() == other
+        return NotImplemented
+
+    def __ne__(self, other):
+        r = self.__eq__(other)
+        return r if r is NotImplemented else not r
+
+    __hash__ = None  # (a list is not hashable either)
+
+    def __repr__(self):
+        return repr(self._all())
+
+    def to_dict(self):  # the JSON encoders write the list
+        return self._all()
+
+    def copy(self):
+        return list(self._all())
+
+    def __add__(self, other):
+        return self._all() + list(other)
+
+    def __radd__(self, other):
+        return list(other) + self._all()
+
+    # -- what a caller may do to the ``ops`` list of a reference result
+    def append(self, x):
+        self._mutable().append(x)
+
+    def extend(self, xs):
+        self._mutable().extend(xs)
+
+    def insert(self, i, x):
+        self._mutable().insert(i, x)
+
+    def pop(self, i=-1):
+        return self._mutable().pop(i)
+
+    def clear(self):
+        self._mutable().clear()
+
+    def __setitem__(self, i, x):
+        self._mutable()[i] = x
+
+    def __delitem__(self, i):
+        del self._mutable()[i]
+
+    # -- summaries straight from the arrays (same arithmetic, same order as the loops over Op objects they replace)
+    def _column(self, name: str) -> list:
+        if self._ops is None:
+            j = Op._fields.index(name)
+            return self._ci[:, j].tolist() if j < 4 else self._ff[:, j - 2].tolist()  # (latency, cost = columns 3, 4 of the float array)
+        return [getattr(op, name) for op in self._ops]
 
 
 class Pair(NamedTuple):
@@ -251,11 +380,15 @@ class CombLogic(NamedTuple):
     # ------------------------------------------------------------------ summaries
     @property
     def cost(self) -> float:
+        if isinstance(self.ops, OpList):
+            return float(sum(self.ops._column('cost')))  # (the same left-to-right sum)
         return float(sum(op.cost for op in self.ops))
 
     @property
     def n_adders(self) -> int:
         """Number of two-input adders/subtractors (opcode 0 or 1)."""
+        if isinstance(self.ops, OpList):
+            return sum(1 for c in self.ops._column('opcode') if c in (0, 1))
         return sum(1 for op in self.ops if op.opcode in (0, 1))
 
     @property
@@ -285,6 +418,8 @@ class CombLogic(NamedTuple):
 
     @property
     def inp_latency(self) -> list[float]:
+        if isinstance(self.ops, OpList):
+            return [lat for lat, c in zip(self.ops._column('latency'), self.ops._column('opcode')) if c == -1]
         return [op.latency for op in self.ops if op.opcode == -1]
 
     @property

@@ -119,23 +119,41 @@ def fork_after_use():
         os._exit(0 if hip.solve_many(ks, **SINGLE) == a else 3)
     _, st = os.waitpid(pid, 0)
     # fork() while ANOTHER thread is inside a solve returns at once (the library takes no lock around the fork: a prepare handler that
-    # waited for the solve-long library lock would stall here for the whole solve -- holding the GIL)
+    # waited for the solve-long library lock would stall here for the whole solve -- holding the GIL).  Measured against the duration of
+    # the solve itself (both scale with the load of the host), and the busy thread says when it has started.
     import threading
     import time
 
     big = [int_matrix(s, 28, 28, -128, 128) for s in range(3)]
-    busy = threading.Thread(target=lambda: hip.solve_many(big, **SINGLE))
+    t0 = time.time()
+    hip.solve_many(big, **SINGLE)
+    t_solve = time.time() - t0
+    started = threading.Event()
+
+    def work():
+        started.set()
+        for _ in range(3):
+            hip.solve_many(big, **SINGLE)
+
+    busy = threading.Thread(target=work)
     busy.start()
-    time.sleep(0.3)
-    in_solve = busy.is_alive()
+    started.wait()
+    time.sleep(min(0.3, 0.25 * t_solve))
     t0 = time.time()
     pid2 = os.fork()
     if pid2 == 0:
-        os._exit(0)
+        # the child of a fork taken in mid-solve: the library says that its copied state is unusable, instead of touching it
+        try:
+            hip.solve_many(ks, **SINGLE)
+            os._exit(4)
+        except RuntimeError as e:
+            os._exit(0 if 'forked while another thread' in str(e) else 5)
     fork_seconds = time.time() - t0
-    os.waitpid(pid2, 0)
+    in_solve = busy.is_alive()
+    _, st2 = os.waitpid(pid2, 0)
     busy.join()
-    out(child=os.WEXITSTATUS(st), parent=hip.solve_many(ks, **SINGLE) == a, fork_during_solve_ok=bool(in_solve and fork_seconds < 0.25))
+    out(child=os.WEXITSTATUS(st), parent=hip.solve_many(ks, **SINGLE) == a, fork_during_solve_ok=bool(in_solve and fork_seconds < max(0.5, 1.5 * t_solve)),
+        child_of_busy_fork=os.WEXITSTATUS(st2), fork_seconds=fork_seconds, solve_seconds=t_solve)
 
 
 def retry():

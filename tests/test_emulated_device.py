@@ -65,7 +65,8 @@ def test_wide_host_pool(emu):
 
 
 def test_fork_after_use(emu):
-    assert emu('fork', timeout=300) == {'child': 0, 'parent': True, 'fork_during_solve_ok': True}
+    r = emu('fork', timeout=600)
+    assert (r['child'], r['parent'], r['fork_during_solve_ok'], r['child_of_busy_fork']) == (0, True, True, 0), r
 
 
 def test_capacity_retry(emu):

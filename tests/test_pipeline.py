@@ -154,3 +154,50 @@ def test_larger_solver_outputs_by_digest(oracle):
                 assert hashlib.sha256(json.dumps(dump(p), separators=(',', ':')).encode()).hexdigest() == g['sha256'], (name, cut, retiming)
                 seen += 1
     assert seen == len(GOLDEN['big']) == 14
+
+
+@pytest.mark.gpu
+def test_passes_on_hip_solver_output_match_the_reference_python():
+    """SURVEY.md section 8f rank 4 on the product path: the HIP solver's own output (through the C ABI) goes through
+    to_pipeline / retime_pipeline / dead_statement_elimination and is compared with what the reference's Python produced from the
+    reference build's solver output (tests/golden/pipeline_golden.json.gz) -- the large cases by digest, the small ones whole."""
+    import hashlib
+
+    from da4ml_amd import _binary as hip
+
+    want = {(g['solve'], g['cutoff'], g['retiming']): g for g in GOLDEN['big']}
+    seen = 0
+    for name, recipe, opts, cuts in BIG:  # 64x64 and 48x40 solver outputs, two or three cutoffs, with and without retiming
+        k, _ = solve_inputs((name, recipe, opts))
+        comb = hip.solve(k, **opts).solutions[0]
+        for cut in cuts:
+            for retiming in (False, True):
+                g = want[(name, cut, retiming)]
+                p = to_pipeline(comb, cut, retiming=retiming, verbose=False)
+                if g.get('reference_hangs'):
+                    assert np.array_equal(p.kernel, comb.kernel)
+                else:
+                    assert hashlib.sha256(json.dumps(dump(p), separators=(',', ':')).encode()).hexdigest() == g['sha256'], (name, cut, retiming)
+                seen += 1
+    assert seen == 14
+    solved = {}
+    for spec in SOLVES:
+        k, opts = solve_inputs(spec)
+        solved[spec[0]] = hip.solve(k, **opts)
+    ok = sum(_check(lambda: to_pipeline(solved[it['solve']].solutions[it['stage']], it['cutoff'], retiming=False), it) for it in GOLDEN['split'] if it['solve'] in solved)
+    for it in GOLDEN['retime']:
+        if it['solve'] not in solved:
+            continue
+        with contextlib.redirect_stdout(io.StringIO()):
+            if it['stage'] == 'pipeline':
+                ok += _check(lambda: retime_pipeline(solved[it['solve']]), it)
+            else:
+                ok += _check(lambda: to_pipeline(solved[it['solve']].solutions[it['stage']], it['cutoff']), it)
+    for it in GOLDEN['dce']:
+        if it['solve'] not in solved:
+            continue
+        comb = solved[it['solve']].solutions[it['stage']]
+        comb = comb._replace(out_idxs=[i if j % 2 == 0 else -1 for j, i in enumerate(comb.out_idxs)])
+        assert dump(dead_statement_elimination(comb, it['keep_dead_inputs'])) == it['result'], (it['solve'], it['stage'])
+        ok += 1
+    assert ok >= 200

@@ -1,6 +1,7 @@
 """Result data model: replay, JSON round trip, DAIS binary header (reference src/da4ml/types.py)."""
 
 import numpy as np
+import pytest
 
 from cases import int_matrix
 from da4ml_amd.types import CombLogic, Op, Pipeline, QInterval, minimal_kif
@@ -120,3 +121,51 @@ def test_predict_default_threads_from_environment(monkeypatch, oracle):
     s.predict(x)
     s.predict(x, n_threads=2)
     assert seen == [3, 2]
+
+
+def test_lazy_op_list_behaves_like_the_list_it_replaces():
+    """types.OpList: the statements of a solver result are built on access; everything a caller
+    can do with the reference's ``list[Op]`` gives the same answers, and the summaries do not build a single Op"""
+    import json
+
+    from da4ml_amd._marshal import stage_from_arrays
+    from da4ml_amd.types import JSONEncoder, OpList
+
+    rng = np.random.default_rng(0)
+    n_in, n_out, n_ops = 3, 2, 9
+    oi = np.zeros((n_ops, 4), np.int64)
+    of = np.zeros((n_ops, 5), np.float32)
+    for i in range(n_ops):
+        oi[i] = (i, -1, -1, 0) if i < n_in else (int(rng.integers(0, i)), int(rng.integers(0, i)), int(rng.integers(0, 2)), int(rng.integers(-3, 4)))
+        of[i] = (-8.0, 7.5, 0.5, float(i // 2), 0.0 if i < n_in else 1.0 + i / 4)
+    args = (n_in, n_out, [0, 1, -1], [7, 8], [0, 2], [False, True], oi, of, -1, 1)
+    comb = stage_from_arrays(*args)
+    assert isinstance(comb.ops, OpList) and comb.ops._lazy()
+    plain = [Op(*(int(v) for v in oi[i]), QInterval(*(float(v) for v in of[i, :3])), float(of[i, 3]), float(of[i, 4])) for i in range(n_ops)]
+    ref = comb._replace(ops=plain)
+    # summaries: from the arrays, nothing built
+    assert (comb.cost, comb.n_adders, comb.latency, comb.out_latency, comb.inp_latency) == (ref.cost, ref.n_adders, ref.latency, ref.out_latency, ref.inp_latency)
+    assert len(comb.ops) == n_ops and comb.ops[4] == plain[4] and comb.ops[-1] == plain[-1] and isinstance(comb.ops[4], Op) and isinstance(comb.ops[4].qint, QInterval)
+    assert comb.ops._lazy()
+    with pytest.raises(IndexError):
+        comb.ops[n_ops]
+    # equality in both directions, with lists and with another lazy view; inequality
+    other = stage_from_arrays(*args)
+    assert comb == other and comb.ops._lazy() and other.ops._lazy()
+    assert comb == ref and ref == comb and not (comb != ref) and comb.ops == plain and plain == comb.ops
+    of2 = of.copy()
+    of2[5, 4] += 1
+    assert stage_from_arrays(*args[:7], of2, -1, 1) != comb and stage_from_arrays(*args[:7], of2, -1, 1).ops != plain
+    # iteration, slices, membership, concatenation, serialisation
+    assert list(comb.ops) == plain and comb.ops[2:5] == plain[2:5] and plain[3] in comb.ops and comb.ops + [plain[0]] == plain + [plain[0]]
+    assert json.dumps(comb, cls=JSONEncoder) == json.dumps(ref, cls=JSONEncoder)
+    assert CombLogic.deserialize(json.loads(json.dumps(comb, cls=JSONEncoder))) == ref
+    assert np.array_equal(comb.to_binary(), ref.to_binary())
+    assert np.array_equal(comb(np.arange(3.0)), ref(np.arange(3.0)))
+    # mutation works on the built list
+    fresh = stage_from_arrays(*args)
+    fresh.ops.append(plain[0])
+    assert len(fresh.ops) == n_ops + 1 and fresh.ops[-1] == plain[0] and fresh.ops != plain
+    fresh.ops.pop()
+    assert fresh.ops == plain
+    assert stage_from_arrays(n_in, 0, [0, 0, 0], [], [], [], np.zeros((0, 4), np.int64), np.zeros((0, 5), np.float32), -1, -1).ops == []
