@@ -50,6 +50,8 @@ WORKLOADS = {
     'c3_256x256_int8_batch8_default_search': (256, 256, 8, dict()),
     'c2_64x64_int8_batch64_single_chain': (64, 64, 64, SINGLE_CHAIN),
     'c5_model_batch': None,  # see run_c5
+    # plumbing check of the multi-rank path (tests/test_bench_contract.py runs it at 8 ranks on the emulated device): not a benchmark
+    't0_plumbing_12x10_batch3_single_chain': (12, 10, 3, SINGLE_CHAIN),
 }
 # BASELINE configs[4] stand-in (JEDI-linear's weights are not in the reference tree and there is no network): a documented
 # synthetic layer stack; every layer is applied to C5_ROWS row vectors with their own input intervals / latencies, which is

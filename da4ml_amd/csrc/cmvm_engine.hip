@@ -93,13 +93,20 @@ constexpr int MAX_GROUPS = 4096;   // 16 waves x 64 lanes x 4 register-resident 
     u1 = clock64();       \
     up[i] += u1 - u0;     \
     u0 = u1;
+#ifndef DA_TIMER_STEP_LO
+#define DA_TIMER_STEP_LO 0  // the phase timers accumulate over the steps [LO, HI) of a chain (a window of the chain: -DDA_TIMER_STEP_LO=.. -DDA_TIMER_STEP_HI=..)
+#endif
+#ifndef DA_TIMER_STEP_HI
+#define DA_TIMER_STEP_HI 0x7FFFFFFF
+#endif
+#define DA_TIMED_STEP(t) ((t) >= DA_TIMER_STEP_LO && (t) < DA_TIMER_STEP_HI)
 #define UPD_TIMER_FLUSH \
-    if (lane == 0)      \
+    if (lane == 0 && DA_TIMED_STEP(g->iter - 1))      \
         for (int q = 0; q < 5; ++q) atomicAdd(&g->st_phase[7 + q], (unsigned long long)up[q]);
 #define SEL_TIMER_DECL long long tp[8];
 #define SEL_TIMER_MARK(i) tp[i] = clock64();
 #define SEL_TIMER_FLUSH \
-    for (int q = 0; q < 7; ++q) g->st_phase[q] += (unsigned long long)(tp[q + 1] - tp[q]);
+    if (DA_TIMED_STEP(iter)) for (int q = 0; q < 7; ++q) g->st_phase[q] += (unsigned long long)(tp[q + 1] - tp[q]);
 #else
 #define UPD_TIMER_DECL
 #define UPD_TIMER_MARK(i)
@@ -1471,6 +1478,9 @@ constexpr uint32_t ROW_NONE = 0xFFFFFFFFu;
 #endif
 constexpr int SEL2_THREADS = DA_SEL2_THREADS;  // threads of a k_iter_select2 block (both roles); MAX_GROUPS / SEL2_THREADS group bounds per lane of the search
 static_assert(MAX_GROUPS % SEL2_THREADS == 0 && SEL2_THREADS % WAVE == 0 && SEL2_THREADS >= 256, "k_iter_select2 geometry");
+#ifndef DA_AB_REPAIR_ROUNDS
+#define DA_AB_REPAIR_ROUNDS 8  // measured (MI355X, C3 batch / one chain, us per step): 0: 36.0 / 24.9, 1: 35.5 / 24.0, 2: 34.9 / 23.6, 4: 34.4 / 23.1, 8: 34.4 / 22.9
+#endif
 constexpr int QL_CAP = 64;  // entries touching the pick's rows the search may meet above its rising floor before it gives up (LDS)
 
 #ifdef DA_PHASE_TIMERS
@@ -1612,7 +1622,7 @@ template <class Cell> __device__ __forceinline__ void search_body(ChainDev *g, i
                     if (dv[u]) {
                         cand = ubv[u];
                         dmask |= 1u << u;
-                    } else {
+                    } else if (ubv[u] >= cl) {  // (a clean group below this lane's best so far cannot matter, whatever rows its best entry touches)
                         const unsigned long long w = offer((uint32_t)(ubv[u] >> 32), gtr[u], 0ull, false);  // (an excluded best entry is listed when its group is read)
                         if (w)
                             cl = max(cl, w);
@@ -1718,7 +1728,9 @@ template <class Cell> __device__ __forceinline__ void search_body(ChainDev *g, i
                 const bool own_dirty = (((uint32_t)__builtin_amdgcn_readlane((int)dmask, owner) >> own_u) & 1u) != 0;
                 read_group((uint32_t)(wid * GPW + owner + own_u * WAVE), own_dirty, wtop, fl);
                 if (lane == owner) q_ub[own_u][tid] = 0;
-            } else {  // nothing of its own to read: one of the groups with a stale bound, if there are any
+            }
+#ifndef DA_AB_NO_IDLE_REPAIR
+            else {  // nothing of its own to read: one of the groups with a stale bound, if there are any
                 unsigned int k = 0;
                 if (lane == 0) k = atomicAdd(&q_stake, 1u);
                 k = (unsigned int)__builtin_amdgcn_readfirstlane((int)k);
@@ -1728,6 +1740,7 @@ template <class Cell> __device__ __forceinline__ void search_body(ChainDev *g, i
                     read_group((uint32_t)((t / WAVE) * GPW + (t % WAVE) + u * WAVE), true, 0ull, fl);
                 }
             }
+#endif
         }
         __syncthreads();
         // ---- the groups that still reach the floor, from all waves into one work list, dealt out evenly: a wave that owns several of them
@@ -1753,7 +1766,7 @@ template <class Cell> __device__ __forceinline__ void search_body(ChainDev *g, i
 #endif
             // the work list, then the stale groups round 0 left: those ride in the rounds the work list needs anyway (waves that would idle), beyond
             // that only the ones whose bound reaches the floor are read now
-            const unsigned int sn = q_sn, taken = min(q_stake, sn), rounds = max((wn + NW - 1) / NW, min(2u, (sn - taken) / 48u));  // (a long backlog -- the first steps of a chain -- gets rounds of its own)
+            const unsigned int sn = q_sn, taken = min(q_stake, sn), rounds = max((wn + NW - 1) / NW, min((unsigned int)DA_AB_REPAIR_ROUNDS, (sn - taken) / 48u));  // (a long backlog -- the first steps of a chain -- may get rounds of its own)
             for (unsigned int i = (unsigned int)wid; i < wn + (sn - taken); i += NW) {  // (wave-uniform)
                 const bool listed = i < wn;
                 const uint32_t info = listed ? q_work[i] : q_sl[taken + (i - wn)], at = info & 0x7FFFFFFFu;
@@ -1860,10 +1873,12 @@ template <class Cell> __device__ __forceinline__ void search_body(ChainDev *g, i
     if (lane == 0 && rescans) atomicAdd(&g->st_rescans, (unsigned long long)rescans);
     if (tid == 0) {
 #ifdef DA_PHASE_TIMERS
-        g->st_qphase[0] += (unsigned long long)(qp[1] - qp[0]);
-        if (!fast) g->st_qphase[1] += (unsigned long long)(qp[2] - qp[1]);
-        g->st_qphase[2] += (unsigned long long)(qp[3] - (fast ? qp[1] : qp[2]));
-        g->st_qphase[3] += 1;
+        if (DA_TIMED_STEP(step)) {
+            g->st_qphase[0] += (unsigned long long)(qp[1] - qp[0]);
+            if (!fast) g->st_qphase[1] += (unsigned long long)(qp[2] - qp[1]);
+            g->st_qphase[2] += (unsigned long long)(qp[3] - (fast ? qp[1] : qp[2]));
+            g->st_qphase[3] += 1;
+        }
 #endif
     }
 #ifdef DA_PHASE_TIMERS
@@ -1889,7 +1904,7 @@ template <class Cell> __device__ __forceinline__ int pick_body(ChainDev *g, unsi
     using Entry = typename F::Entry;
     const int par = step & 1, iter = step;
     // ---- ONE scalar round trip: every descriptor field the block needs, the entry left by the previous step's search included
-    int was_done = g->done, had_error = g->error, lcap = g->lcap;
+    int was_done = g->done, had_error = g->error, lcap = g->lcap, claim_words = g->claim_words;
     int n_rows0 = g->n_rows, rcap = g->rcap, cbw = g->cb_words, adder_size = g->adder_size, carry_size = g->carry_size;
     uint32_t offN = g->rl_used, rl_cap = g->rl_cap, n_live0 = g->n_live, live_peak0 = g->live_peak;
     const uint32_t *step_mant = g->step_mant;
@@ -1914,7 +1929,7 @@ template <class Cell> __device__ __forceinline__ int pick_body(ChainDev *g, unsi
     DA_GLOBAL unsigned long long *plist = (DA_GLOBAL unsigned long long *)g->plist;
     DA_GLOBAL da_i4 *picks = (DA_GLOBAL da_i4 *)g->picks;
     DA_GLOBAL uint32_t *sp_cnt = (DA_GLOBAL uint32_t *)g->sp_cnt;
-    pin_sgpr(was_done, had_error, lcap, n_rows0, rcap, cbw, adder_size, carry_size, offN, rl_cap, n_live0, live_peak0, step_mant, step_tab, n_step_mant);
+    pin_sgpr(was_done, had_error, lcap, claim_words, n_rows0, rcap, cbw, adder_size, carry_size, offN, rl_cap, n_live0, live_peak0, step_mant, step_tab, n_step_mant);
     pin_sgpr(sp_word, sp_tie, cn_prev, cl_prev, sp_ax, sp_ay, sp_bx, sp_by, sp_ra0, sp_ra1, sp_ra2, sp_ra3, sp_rb0, sp_rb1, sp_rb2, sp_rb3);
     pin_sgpr(c.n_out, c.n_bits, c.K, c.Kpad, c.rows);
     pin_sgpr(collen, rowoff, rl, mA, mB, mcol, collist, cmap, colbits, pl_ids, plist, picks, sp_cnt);
@@ -1929,6 +1944,7 @@ template <class Cell> __device__ __forceinline__ int pick_body(ChainDev *g, unsi
     int *s_bpos = s_col + n_out;                                                      // [n_out] 1 + position of a column in B's list, 0 = absent
     int *s_clen = s_bpos + n_out;                                                     // [n_out] list length of every column
     int *s_cm = s_clen + n_out;                                                       // [n_out] 1 + index among the matched columns, 0 = not matched
+    uint32_t *s_or = reinterpret_cast<uint32_t *>(s_cm + n_out);                      // [claim_words] OR of the substituted columns' row bitmaps (if it fits)
     constexpr int NW = SEL2_THREADS / WAVE;
     __shared__ int s_np, s_part[NW];
     __shared__ unsigned int s_matches;
@@ -1980,6 +1996,7 @@ template <class Cell> __device__ __forceinline__ int pick_body(ChainDev *g, unsi
             s_bpos[tid] = 0;
         }
         if (want_log2) reinterpret_cast<uint32_t *>(&s_log2)[tid] = l2w;
+        for (int w = tid; w < claim_words; w += SEL2_THREADS) s_or[w] = 0;
         for (int j = tid + SEL2_THREADS; j < n_out; j += SEL2_THREADS) {
             s_clen[j] = collen[j];
             s_cm[j] = 0;
@@ -2182,13 +2199,30 @@ template <class Cell> __device__ __forceinline__ int pick_body(ChainDev *g, unsi
     // row ids stay in LDS; then, one thread per partner, the list reference is attached (a parallel gather from rowoff).
     {
         const DA_GLOBAL uint32_t *cb = colbits;
-        const int nwords = (int)((Nw + 31) >> 5);
+        const int nwords = (int)((Nw + 31) >> 5), chunks = (nwords + WAVE - 1) / WAVE;
         DA_GLOBAL uint32_t *ids = pl_ids;
+        // While the chain is young the bitmaps are a few 64-word chunks long and many columns are substituted (tens): one wave per chunk
+        // would OR them one load after the other while the others idle (20 k of the 34 k cycles of an early step, measured).  The waves of
+        // a chunk share its columns then and combine their parts in LDS.
+        const bool split = chunks * 4 <= NW && m >= 8 && nwords <= claim_words;  // (at least four waves per chunk and two columns each: else the barrier costs more than it saves)
+        if (split) {
+            const int c = wid % chunks, part = wid / chunks, ways = (NW - c + chunks - 1) / chunks;  // waves c, c + chunks, ... serve chunk c
+            const int w = c * WAVE + lane;
+            if (w < nwords) {
+                uint32_t bits = 0;
+                for (int k = part; k < m; k += ways) bits |= cb[(size_t)s_col[k] * cbw + w];
+                if (bits) atomicOr(&s_or[w], bits);
+            }
+            __syncthreads();
+        }
         for (int wb = wid * WAVE; wb < nwords; wb += SEL2_THREADS) {  // wave-uniform trip count
             const int w = wb + lane;
             uint32_t bits = 0;
             if (w < nwords) {
-                for (int k = 0; k < m; ++k) bits |= cb[(size_t)s_col[k] * cbw + w];
+                if (split)
+                    bits = s_or[w];
+                else
+                    for (int k = 0; k < m; ++k) bits |= cb[(size_t)s_col[k] * cbw + w];
                 if ((int)(A >> 5) == w) bits &= ~(1u << (A & 31));
                 if ((int)(B >> 5) == w) bits &= ~(1u << (B & 31));
                 if ((int)(Nw >> 5) == w) bits &= ~(1u << (Nw & 31));
@@ -2537,26 +2571,30 @@ __device__ __forceinline__ void update_partners(ChainDev *g, const UpdStep<Cell>
 // (N,N): new -- from the exact counts the substitution block left in sp_cnt (select_body used to write them itself: the table is now
 // written by this kernel only).  One wavefront per pair.  Like every block this kernel re-evaluates they pass their best entry to fold_entry,
 // changed or not.
-template <class Cell> __device__ __forceinline__ void special_pairs(ChainDev *gq, const UpdStep<Cell> &u) {
+// Two workgroups per chain share the work, one pair per wavefront and ONE turn each (find -> re-count / create: the longest dependent chain
+// of this kernel; with all six in one workgroup of four waves it took two turns): part 0 the four pairs with A, part 1 (B,N), (N,N) and the
+// listed entries.
+template <class Cell> __device__ __forceinline__ void special_pairs(ChainDev *gq, const UpdStep<Cell> &u, int part) {
     const Ctx &c = u.c;
     const uint32_t A = u.A, B = u.B, Nw = u.Nw;
     const bool same = A == B;
     const DA_GLOBAL uint32_t *spc = (const DA_GLOBAL uint32_t *)gq->sp_cnt;
     const RowInfo ra = load_row(c.rows, A), rb = load_row(c.rows, B), rn = load_row(c.rows, Nw);
     const int lane = lane_id();
-    for (int sp = wave_id(); sp < 6; sp += UPD_WAVES) {
+    for (int sp = part * UPD_WAVES + wave_id(); sp < min(6, (part + 1) * UPD_WAVES); sp += UPD_WAVES) {
         uint32_t lo = A, hi = A;
         bool active = true, existed = false;
+        int row = 0;  // row of the count vectors left by the substitution block: (A,A) (A,B) (B,B) (A,N) (B,N) (N,N)
         switch (sp) {
-        case 0: lo = A, hi = A, existed = true; break;
-        case 1: lo = A, hi = B, existed = true, active = !same; break;
-        case 2: lo = B, hi = B, existed = true, active = !same; break;
-        case 3: lo = A, hi = Nw; break;
-        case 4: lo = B, hi = Nw, active = !same; break;
-        default: lo = Nw, hi = Nw; break;
+        case 0: lo = A, hi = A, existed = true, row = 0; break;
+        case 1: lo = A, hi = B, existed = true, active = !same, row = 1; break;
+        case 2: lo = A, hi = Nw, row = 3; break;
+        case 3: lo = B, hi = B, existed = true, active = !same, row = 2; break;
+        case 4: lo = B, hi = Nw, active = !same, row = 4; break;
+        default: lo = Nw, hi = Nw, row = 5; break;
         }
         if (!active) continue;
-        const DA_GLOBAL uint32_t *cnt = spc + (size_t)sp * c.Kpad;
+        const DA_GLOBAL uint32_t *cnt = spc + (size_t)row * c.Kpad;
         const unsigned long long key = pack_pair(lo, hi);
         const int slot = existed ? table_find(c, key, hash_pair(lo, hi)) : -1;
         unsigned long long w = 0;
@@ -2575,12 +2613,12 @@ template <class Cell> __device__ __forceinline__ void special_pairs(ChainDev *gq
     // the entries the search listed (they touch exactly one of A / B and reach the untouched entry): a block whose other row is a partner
     // row is re-evaluated by the partner waves of this launch, which pass its best entry on themselves; the others are unchanged -- passed on here.
     // Partner row = a row with digits in a substituted column: bit r of the row bitmaps of those columns (A, B, N are never the other row)
-    if (c.rword) {
+    if (c.rword && part == 1) {
         const int nl = (int)gq->l_n[(gq->iter - 1) & 1];
         const CandEntry *ll = &gq->l_list[(gq->iter - 1) & 1][0];
         const uint32_t *colbits = gq->colbits;
         const int cbw = gq->cb_words;
-        for (int e = wave_id(); e < nl; e += UPD_WAVES) {
+        for (int e = (wave_id() + 2) % UPD_WAVES; e < nl; e += UPD_WAVES) {  // (waves 2 and 3 first: 0 and 1 had a pair)
             const unsigned long long tw = ll[e].tie;
             const uint32_t i0 = (uint32_t)((tw >> 7) & 0xFFFFFFu), i1 = (uint32_t)(tw >> 31);
             const uint32_t r = (i0 == A || i0 == B) ? i1 : i0;
@@ -2602,11 +2640,11 @@ __device__ __forceinline__ void update_body(ChainDev *gq, bool in_range, int blo
     // non-coherent L2s instead of being spread over all of them.
     const UpdStep<Cell> u = load_upd_step<Cell>(gq);
     if (!in_range || u.done) return;
-    if (block_y == grid_y - 1) {  // the last block of a chain: the six blocks of the pairs among {A, B, new row}
-        special_pairs<Cell>(gq, u);
+    if (block_y >= grid_y - 2) {  // the last two blocks of a chain: the six blocks of the pairs among {A, B, new row}
+        special_pairs<Cell>(gq, u, block_y - (grid_y - 2));
         return;
     }
-    grid_y -= 1;
+    grid_y -= 2;
     // the grid is sized for the partner counts of the first steps of a chain (thousands); later most blocks have nothing
     // to do and leave before the hand-off is copied
     if (block_y * (NWV * QN) >= u.n_partners) return;
@@ -3435,11 +3473,11 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
         else
             hipLaunchKernelGGL(k_iter_select2<uint64_t>, sel_grid, dim3(SEL2_THREADS), sel_lds[1], gr.stream, base, gr.count, im.d_done, step);
         if (se) HIP_CHECK(hipEventRecord(se[1], gr.stream));
-        // (+ 1: the last block of a chain writes the six blocks of the pairs among the modified rows)
+        // (+ 2: the last two blocks of a chain write the six blocks of the pairs among the modified rows)
         if (gr.w == 0)
-            hipLaunchKernelGGL(k_iter_update<uint32_t>, dim3((gr.count + 7) & ~7, upd_blocks[0] + 1), dim3(UPD_THREADS), upd_lds[0], gr.stream, base, gr.count);
+            hipLaunchKernelGGL(k_iter_update<uint32_t>, dim3((gr.count + 7) & ~7, upd_blocks[0] + 2), dim3(UPD_THREADS), upd_lds[0], gr.stream, base, gr.count);
         else
-            hipLaunchKernelGGL(k_iter_update<uint64_t>, dim3((gr.count + 7) & ~7, upd_blocks[1] + 1), dim3(UPD_THREADS), upd_lds[1], gr.stream, base, gr.count);
+            hipLaunchKernelGGL(k_iter_update<uint64_t>, dim3((gr.count + 7) & ~7, upd_blocks[1] + 2), dim3(UPD_THREADS), upd_lds[1], gr.stream, base, gr.count);
         if (se) HIP_CHECK(hipEventRecord(se[2], gr.stream));
     };
     // Windows of up to WINDOW_ITERS iterations x all groups are queued eagerly; one event-bracketed iteration per window

@@ -237,7 +237,11 @@ constexpr unsigned hipStreamNonBlocking = 1, hipHostMallocDefault = 0, hipEventD
 inline const char *hipGetErrorString(hipError_t) { return "emulated HIP runtime"; }
 inline hipError_t hipGetLastError() { return hipSuccess; }
 inline hipError_t hipSetDevice(int) { return hipSuccess; }
-inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
+inline hipError_t hipGetDeviceCount(int *n) {  // HIPEMU_DEVICES: the multi-rank tests give every rank "its own" emulated device
+    const char *e = std::getenv("HIPEMU_DEVICES");
+    *n = e && std::atoi(e) > 0 ? std::atoi(e) : 1;
+    return hipSuccess;
+}
 inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 struct hipDeviceProp_t {
     int multiProcessorCount;

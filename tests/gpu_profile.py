@@ -15,6 +15,11 @@ print(f'{n}x{n} batch {B}: {dt:.3f}s  -> {B/dt:.2f} solves/s; loop {tm["loop_ms"
 print(res[0][1])
 ph = {k: v for k, v in tm.items() if k.startswith('sel_') or k.startswith('upd_')}
 its = max(tm['iterations'], 1); pa = max(tm['partners'], 1)
+import os
+if os.environ.get('TIMER_WINDOW_STEPS'):  # a phase-timer build restricted to a window of steps (DA_TIMER_STEP_LO / HI): per step of the window
+    w = float(os.environ['TIMER_WINDOW_STEPS']) * B
+    print('window: select cycles/step', {k: round(v / w) for k, v in ph.items() if k.startswith('sel_')}, '| search', {k: round(tm[k] / max(tm['search_steps_timed'], 1)) for k in ('search_bounds', 'search_argmax', 'search_excluded')},
+          '| update wave-cycles/step', {k: round(v / w) for k, v in ph.items() if k.startswith('upd_')})
 print('select cycles/iteration:', {k: round(v / its) for k, v in ph.items() if k.startswith('sel_')})
 print('update cycles/partner  :', {k: round(v / pa) for k, v in ph.items() if k.startswith('upd_')}, 'partners/iter', round(pa / its), 'found/partner %.2f' % (tm['found'] / pa), 'inserts/partner %.3f' % (tm['inserts'] / pa))
 sm = max(tm['samples'], 1)
