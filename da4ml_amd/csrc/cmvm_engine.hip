@@ -6,7 +6,9 @@
 //   k_prepare        _center + global digit width            bit_decompose.hh:25-34, bit_decompose.cc:22-27
 //   k_init_cells     CSD recoding + SparseExpr build          bit_decompose.cc:28-42, state_opr.cc:93-112
 //   k_init_pairs     all-pairs enumeration / FreqMap::initialize   state_opr.cc:117-143, types.hh:73-100
-//   k_iter_select    idx_mc / idx_mc_dc / idx_wmc / idx_wmc_dc + update_expr   indexers.cc:6-90, state_opr.cc:227-283
+//   k_iter_select2   idx_mc / idx_mc_dc / idx_wmc / idx_wmc_dc + update_expr   indexers.cc:6-90, state_opr.cc:227-283
+//                    (two workgroups per chain: the search finds the next pick one step AHEAD, beside the substitution of the current one;
+//                    k_iter_select: the one-block form of rounds 1-4, kept for the column-sharded chain)
 //   k_iter_update    update_stats (purge + regenerate) as an exact incremental update   state_opr.cc:285-345
 //   k_extract        digit gather of to_solution             cmvm_core.cc:103-113
 //   k_col_dist       stage-1 CSD Hamming distances           mat_decompose.cc:75-93
@@ -27,15 +29,19 @@
 //             hkey[C] u64 (16 keys = one 128-byte line = one probe bucket), hrank[C] u32 (selection rank of the block's
 //             best key, 0 = none; the array the selection re-reads), hblk[C] one PAYLOAD LINE per slot:
 //             {n_overlap, |dlat|, rank copy, index of the best key, K x u16 exact occurrence counts} -- a block update
-//             reads and writes ONE line instead of four arrays
-//   ub      [C / GS]       u64     upper bound of (rank << 32 | tie_word >> 23) over a group of GS consecutive slots
+//             reads and writes ONE line instead of four arrays; hidx[C] u8 behind hrank: the best key's index once more, dense (the search
+//             reads rank, key and index of a whole group from three dense arrays)
+//   ub      [C / GS]       u64     bound word (rank << 32 | tie_word >> 23) of the best entry of a group of GS consecutive slots; gtie its
+//                                  exact tie word, glow the highest value an update lowered in the group, gdirty "tie word unknown"
 //
 // The reference keeps a sorted table of all pairs with count >= 2, purges every entry touching the two
 // substituted rows and regenerates their pairs against ALL rows every iteration.  Here the counts are
 // maintained exactly by subtracting, for every "partner" row that shares a substituted column, the pair
 // occurrences of the consumed digits, and by creating the blocks of the new row -- O(consumed digits x
 // column population) instead of O(row digits x all rows) per iteration.  Selection never scans the table:
-// it keeps per-group upper bounds of the rank, which only ever need tightening for the top groups.
+// it keeps per-group bounds of the rank -- tight ones: an update that lowers a group's best entry leaves a mark (glow) that the next
+// selection acts on --, and a step changes only entries of its pick's rows, so the best entry it leaves untouched is the next pick unless
+// one of the few entries the update lists beats it (k_iter_select2).
 
 #include <hip/hip_runtime.h>
 
@@ -800,18 +806,14 @@ template <class Cell> __global__ void __launch_bounds__(256) k_init_pairs(ChainD
     table_insert(c, lo, hi, load_row(c.rows, lo), load_row(c.rows, hi), [&](int k) { return cnt[k]; });
 }
 
-// ------------------------------------------------------------------------------------------------ k_iter_select
-// One block per chain: (1) arg-max of the pair table via lazily tightened group upper bounds, (2) substitution
-// of the chosen pair in the lists of rows A and B (the new row's list is their match set), (3) exact recount of the
-// pairs among the modified rows {A, B, new}, (4) the de-duplicated list of partner rows (rows sharing a substituted
-// column) for k_iter_update.
-// SHARDED (column-sharded chain, cmvm_shard.h): the chain holds a slice of the columns and a replica of the pair table.
-// The arg-max and the substitution are the same; the counts of the pairs among {A, B, new} are only PARTIAL here and go to
-// the head of the exchange slab instead of the table, and instead of a partner list the kernel leaves one flag per row.
-// select_body: one greedy step's selection + substitution of chain `g` by a 1024-thread workgroup; returns 1 when the chain
-// is (or just became) finished, 0 after an ordinary step (hand-off for the update written).  Called by the k_iter_select
-// wrapper, one launch per step.
-template <class Cell, bool SHARDED = false> __device__ __forceinline__ int select_body(ChainDev *g, unsigned int *n_done) {
+// ------------------------------------------------------------------------------------------------ k_iter_select (column-sharded chains)
+// The one-block selection of rounds 1-4, kept for the column-sharded chain (cmvm_shard.h; ordinary chains use k_iter_select2 below): the chain
+// holds a slice of the columns and a replica of the pair table.  One block per chain: (1) arg-max of the pair table via lazily tightened group
+// upper bounds, (2) substitution of the chosen pair in the lists of rows A and B (the new row's list is their match set), (3) exact recount of
+// the pairs among the modified rows {A, B, new} -- only PARTIAL here: they go to the head of the exchange slab --, (4) one flag per row that
+// shares a substituted column (read from the column lists) instead of a partner list.  Returns 1 when the chain is (or just became) finished.
+template <class Cell, bool SHARDED = true> __device__ __forceinline__ int select_body(ChainDev *g, unsigned int *n_done) {
+    static_assert(SHARDED, "the one-block selection serves the column-sharded chain only (cmvm_shard.h); ordinary chains: k_iter_select2");
     using O = CellOps<Cell>;
     using F = RowFmt<Cell>;
     using Entry = typename F::Entry;
@@ -879,8 +881,6 @@ template <class Cell, bool SHARDED = false> __device__ __forceinline__ int selec
     __shared__ unsigned int s_matches;
     __shared__ RowInfo s_new, s_ra, s_rb;
     __shared__ da_u2 s_refA, s_refB;
-    constexpr int IDS_LDS = DA_IDS_LDS;
-    __shared__ uint32_t s_ids[IDS_LDS];  // the first partner row ids of the step (the rest, if any, goes through pl_ids in HBM)
     __shared__ Log2Table s_log2;  // copy of c_log2 (fetched with the bounds; the latency model's look-up then stays off the memory path)
 
     const int tid = threadIdx.x, lane = lane_id(), wid = wave_id();
@@ -1327,87 +1327,18 @@ template <class Cell, bool SHARDED = false> __device__ __forceinline__ int selec
                 const uint32_t row = ref_row(collist[(size_t)s_col[lo] * lcap + (f - s_len[lo])]);
                 if (row != A && row != B) atomicOr(&s_bits[row >> 5], 1u << (row & 31));
             }
-        } else {
-            // Partner rows = rows that have digits in a substituted column = OR of those columns' row bitmaps (A, B and the
-            // new row masked out: their bits are being changed by this very kernel).  Word w of the OR covers rows 32 w ..;
-            // the set bits are counted (DPP prefix sum), one LDS atomic per wave reserves the places, the row ids go to pl_ids;
-            // then, one thread per partner, the list reference is attached (a parallel gather from rowoff).
-            const DA_GLOBAL uint32_t *cb = colbits;
-            const int nwords = (int)((Nw + 31) >> 5);
-            DA_GLOBAL uint32_t *ids = pl_ids;
-            for (int wb = wid * WAVE; wb < nwords; wb += CLAIM_THREADS) {  // wave-uniform trip count
-                const int w = wb + lane;
-                uint32_t bits = 0;
-                if (w < nwords) {
-                    for (int k = 0; k < m; ++k) bits |= cb[(size_t)s_col[k] * cbw + w];
-                    if ((int)(A >> 5) == w) bits &= ~(1u << (A & 31));
-                    if ((int)(B >> 5) == w) bits &= ~(1u << (B & 31));
-                    if ((int)(Nw >> 5) == w) bits &= ~(1u << (Nw & 31));
-                }
-                const int cnt = popc32(bits), inc = (int)wave_scan_add_u32((uint32_t)cnt);  // inclusive prefix inside the wave (DPP)
-                const int wave_total = __builtin_amdgcn_readlane(inc, WAVE - 1);
-                if (wave_total == 0) continue;
-                int base = 0;
-                if (lane == 0) base = atomicAdd(&s_np, wave_total);
-                int at = __builtin_amdgcn_readfirstlane(base) + inc - cnt;
-                while (bits) {  // ids stay in LDS (a store to HBM followed by a load after the barrier was two round trips)
-                    const uint32_t id = (uint32_t)(w << 5) + (uint32_t)ctz32(bits);
-                    if (at < IDS_LDS)
-                        s_ids[at] = id;
-                    else
-                        ids[at] = id;
-                    ++at;
-                    bits &= bits - 1;
-                }
-            }
-            // the list references are attached after the block barrier below, one thread per partner: a parallel gather
-            // from rowoff (attaching them here, lane by lane inside the bit loop, serialises the look-ups: +3.6 us measured)
         }
     } else {
-        const int sp = wid - CLAIM_WAVES;
-        uint32_t lo = A, hi = A;
+        const int sp = wid - CLAIM_WAVES;  // (A,A) (A,B) (B,B) (A,N) (B,N) (N,N): the pairs with B do not exist when the pick is a row with itself
         const uint32_t *cnt = s_cnt + sp * Kpad;
-        bool active = true, existed = false;
-        switch (sp) {
-        case 0: lo = A, hi = A, existed = true; break;
-        case 1: lo = A, hi = B, existed = true, active = !same; break;
-        case 2: lo = B, hi = B, existed = true, active = !same; break;
-        case 3: lo = A, hi = Nw; break;
-        case 4: lo = B, hi = Nw, active = !same; break;
-        default: lo = Nw, hi = Nw; break;
-        }
+        const bool active = !(same && (sp == 1 || sp == 2 || sp == 4));
         if constexpr (SHARDED) {  // partial counts of the six special pairs: head of the exchange slab, [6][K]
             DA_GLOBAL int32_t *spec = cs_slab + (size_t)sp * c.K;
             for (int k = lane; k < c.K; k += WAVE) spec[k] = active ? (int32_t)cnt[k] : 0;
-        } else if (active) {
-            unsigned long long key = pack_pair(lo, hi);
-            int slot = existed ? table_find(c, key, hash_pair(lo, hi)) : -1;
-            if (slot >= 0)
-                table_update(c, slot, key, [&](int k, uint32_t) { return cnt[k]; });
-            else if (wave_any_ge2(cnt, c.K)) {
-                // the records of the two rows: A's and B's were fetched with the list references, the new row's is in LDS
-                const RowInfo sn = s_new;
-                const RowInfo xa = pick_row(lo == Nw, sn, pick_row(lo == A, ra, rb)), xb = pick_row(hi == Nw, sn, pick_row(hi == A, ra, rb));
-                table_insert(c, lo, hi, xa, xb, [&](int k) { return cnt[k]; });
-            }
         }
     }
     SEL_TIMER_MARK(6)
     __syncthreads();
-    if constexpr (!SHARDED) {  // partner ids -> partner list entries (row id, list length, list offset)
-        const int np = s_np;
-        const DA_GLOBAL uint32_t *ids = pl_ids;
-        for (int t = tid; t < np; t += 2 * SEL_THREADS) {  // two partners per thread and pass, their look-ups in flight together
-            const int t2 = t + SEL_THREADS;
-            const bool has2 = t2 < np;
-            const uint32_t r1 = t < IDS_LDS ? s_ids[t] : ids[t];
-            const uint32_t r2 = !has2 ? r1 : t2 < IDS_LDS ? s_ids[t2] : ids[t2];
-            const da_u2 ro1 = rowoff[r1], ro2 = rowoff[r2];
-            load_fence();
-            plist[t] = ref_pack(r1, ro1.y, ro1.x);
-            if (has2) plist[t2] = ref_pack(r2, ro2.y, ro2.x);
-        }
-    }
     SEL_TIMER_MARK(7)
     if constexpr (SHARDED) {  // claim bitmap -> 8-bit flag fields, four rows per word (summed over the ranks without carry)
         DA_GLOBAL int32_t *flags = cs_flags;
@@ -1446,7 +1377,7 @@ template <class Cell, bool SHARDED = false> __device__ __forceinline__ int selec
     }
     return 0;
 }
-template <class Cell, bool SHARDED = false> __global__ void __launch_bounds__(SEL_THREADS) k_iter_select(ChainDev *chains, unsigned int *n_done) {
+template <class Cell, bool SHARDED = true> __global__ void __launch_bounds__(SEL_THREADS) k_iter_select(ChainDev *chains, unsigned int *n_done) {
     (void)select_body<Cell, SHARDED>(&chains[blockIdx.x], n_done);
 }
 
