@@ -220,7 +220,10 @@ static_assert(sizeof(SpecPick) == 64, "SpecPick is read as sixteen words");
 struct CandEntry {  // a table entry by value: selection rank and tie word (id1, id0, key index)
     unsigned long long rank, tie;
 };
-constexpr int CAND_CAP = 16, TOUCH_CAP = 16;  // measured (tools/spec_probe.cc, 64 / 128 square): never more than 8 of either
+#ifndef DA_CAND_CAP
+#define DA_CAND_CAP 16  // measured (tools/spec_probe.cc, 64 / 128 square): never more than 8 of either.  (tests/emu builds with 2: its steps
+#endif                  // overflow the lists often, so that the path on which the search block publishes the pick runs there all the time)
+constexpr int CAND_CAP = DA_CAND_CAP, TOUCH_CAP = DA_CAND_CAP;
 
 // Per-chain descriptor in device memory.  Pointers are raw device addresses into the arena.
 struct ChainDev {
@@ -1412,7 +1415,7 @@ static_assert(MAX_GROUPS % SEL2_THREADS == 0 && SEL2_THREADS % WAVE == 0 && SEL2
 #ifndef DA_AB_REPAIR_ROUNDS
 #define DA_AB_REPAIR_ROUNDS 8  // measured (MI355X, C3 batch / one chain, us per step): 0: 36.0 / 24.9, 1: 35.5 / 24.0, 2: 34.9 / 23.6, 4: 34.4 / 23.1, 8: 34.4 / 22.9
 #endif
-constexpr int QL_CAP = 64;  // entries touching the pick's rows the search may meet above its rising floor before it gives up (LDS)
+constexpr int QL_CAP = DA_CAND_CAP * 4;  // entries touching the pick's rows the search may meet above its rising floor before it gives up (LDS)
 
 #ifdef DA_PHASE_TIMERS
 #define Q_TIMER_DECL long long qp[4];
