@@ -37,6 +37,14 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    # the greedy loop's launches are queued by two host threads that never block (csrc/cmvm_engine.hip, HipBackend::run_chains): with
+    # fewer than three cores to run on they would take turns on one another's time slices -- one thread then (the backend reads this when
+    # it is created; an explicit setting wins)
+    try:
+        if len(_os.sched_getaffinity(0)) < 3:
+            _os.environ.setdefault('DA4ML_HIP_LAUNCH_THREADS', '1')
+    except (AttributeError, OSError):
+        pass
     csrc = Path(__file__).resolve().parent.parent / 'csrc'
     sources = [p for p in csrc.glob('*') if p.suffix in ('.hip', '.cc', '.h') or p.name == 'Makefile'] + [_LIB_PATH.parent.parent / 'include' / 'da4ml_hip.h']
     def _stale():
