@@ -467,7 +467,10 @@ def main():
            'k_iter_select2': tm['select_bytes']}
     avg_us = {'k_iter_update': upd_avg_us, 'k_iter_select2': sel_avg_us}
     tag, meta = newest_pmc_meta()
-    fresh = bool(meta) and meta.get('src_sha256') == source_digest()
+    same_sources = bool(meta) and meta.get('src_sha256') == source_digest()
+    # the PMC passes are taken on the headline workload (tools/collect_profiles.sh): their per-launch traffic says nothing about another one
+    same_workload = bool(meta) and meta.get('workload', 'c3_256x256_int8_batch64_single_chain') == args.workload
+    fresh = same_sources and same_workload
     launches = tm['lockstep_iters'] * max(1.0, round(batch / max(chains_per_launch, 1.0)))
     kernels = {}
     for name in ('k_iter_select2', 'k_iter_update'):
@@ -492,7 +495,7 @@ def main():
     loop_s = max(tm['loop_ms'] * 1e-3, 1e-9)
     roofline = {'kernel': dominant, **{k: v for k, v in kernels[dominant].items() if k != 'valu'}, 'chains_per_launch': chains_per_launch,
                 'kernels': kernels,
-                'profiles': {'tag': tag, 'fresh': fresh, 'note': None if fresh else 'stale_profiles: the committed PMC passes were taken on other sources than the loaded library; traffic / valu withheld'},
+                'profiles': {'tag': tag, 'fresh': fresh, 'note': None if fresh else ('stale_profiles: the committed PMC passes were taken on other sources than the loaded library; traffic / valu withheld' if not same_sources else 'stale_profiles: the committed PMC passes were taken on another workload (' + str(meta.get('workload', 'c3_256x256_int8_batch64_single_chain')) + '); traffic / valu withheld')},
                 'traffic_source': f'profiles/{tag}_pmc_*: (2 x FETCH_SIZE + WRITE_SIZE) KiB per dispatch (gfx950 correction of MI355X_MICROARCH.md), scaled to the live chains per launch' if fresh else None,
                 # the chain groups' launches overlap (4 streams): the algorithmic bytes of both kernels over the whole greedy loop
                 'whole_loop': {'achieved': sum(alg.values()) / loop_s / 1e9, 'unit': 'GB/s', 'frac': sum(alg.values()) / loop_s / 1e9 / HBM_PEAK_GBS,

@@ -20,7 +20,7 @@ import json, subprocess, sys
 sys.path.insert(0, '.')
 import bench
 rev = subprocess.run(['git', 'rev-parse', 'HEAD'], capture_output=True, text=True).stdout.strip() or None  # (no .git on the GPU box)
-print(json.dumps({'batch': 64, 'groups': 4, 'chains_per_dispatch': 16.0, 'src_sha256': bench.source_digest(), 'git': rev}))
+print(json.dumps({'batch': 64, 'groups': 4, 'chains_per_dispatch': 16.0, 'workload': 'c3_256x256_int8_batch64_single_chain', 'src_sha256': bench.source_digest(), 'git': rev}))
 PY
 if [ -n "${QUICK:-}" ]; then SETS=("FETCH_SIZE" "WRITE_SIZE"); else SETS=("FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS" "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum"); fi
 for SET in "${SETS[@]}"; do
