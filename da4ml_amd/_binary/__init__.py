@@ -27,7 +27,7 @@ _i32p = np.ctypeslib.ndpointer(np.int32, flags='C_CONTIGUOUS')
 
 EXPORTS = (
     'da_last_error da_last_error_code da_version da_device_count da_set_device da_get_lsb_loc da_iceil_log2 da_cost_add da_int_arr_to_csd '
-    'da_csd_decompose da_kernel_decompose da_solve da_solve_batch da_solve_sharded da_rccl_unique_id da_rccl_shutdown da_solve_sharded_rccl da_comm_abort da_n_stages da_picked da_stage_info da_stage_copy '
+    'da_csd_decompose da_kernel_decompose da_solve da_solve_batch da_solve_sharded da_rccl_unique_id da_rccl_shutdown da_solve_sharded_rccl da_comm_abort da_shard_exchanged_elements da_n_stages da_picked da_stage_info da_stage_copy '
     'da_result_stats da_free da_timings da_engine_stats da_dais_run da_dais_last_error da_dais_run_on'
 ).split()
 
@@ -97,6 +97,8 @@ def lib():
     L.da_rccl_unique_id.argtypes = [C.c_char_p]
     L.da_rccl_shutdown.restype = C.c_int
     L.da_rccl_shutdown.argtypes = []
+    L.da_shard_exchanged_elements.restype = C.c_int64
+    L.da_shard_exchanged_elements.argtypes = []
     L.da_solve_sharded_rccl.restype = C.c_void_p
     L.da_solve_sharded_rccl.argtypes = [_f32p, C.c_int64, C.c_int64, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                         C.c_int, C.c_int, C.c_char_p, _i64p]
@@ -299,6 +301,11 @@ def solve_sharded_rccl(kernel, unique_id: bytes, method0: str = 'wmc', method1: 
     if not h:
         _raise(lib().da_last_error_code())
     return _collect(h), dict(zip(('sharded_chains', 'greedy_steps', 'allreduce_calls'), st.tolist()))
+
+
+def shard_exchanged_elements() -> int:
+    """int32 elements the last column-sharded solve of this process handed to all-reduce(sum) (x 4 = bytes per rank and direction)"""
+    return int(lib().da_shard_exchanged_elements())
 
 
 def comm_abort():

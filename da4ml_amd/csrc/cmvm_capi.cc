@@ -226,6 +226,8 @@ da_result *da_solve(const float *kernel, int64_t n_in, int64_t n_out, const char
 
 static std::atomic<int> g_comm_aborted{0};
 void da_comm_abort(void) { g_comm_aborted.store(1); }
+static std::atomic<long long> g_shard_elements{0};
+int64_t da_shard_exchanged_elements(void) { return (int64_t)g_shard_elements.load(); }
 
 static std::unique_ptr<da::ShardEngine> make_hip_shard(const da::ChainJob &job, int c0, int c1, double capacity_scale, void *ctx) {
     return static_cast<da::gpu::HipBackend *>(ctx)->make_shard_engine(job, c0, c1, capacity_scale);
@@ -329,6 +331,7 @@ static da_result *solve_sharded_impl(const float *kernel, int64_t n_in, int64_t 
             stats3[1] = be.sharded_steps;
             stats3[2] = be.comm().calls;
         }
+        g_shard_elements.store(be.comm().elements);
         return new da_result{std::move(res[0]), stats.empty() ? da::ChainStats{} : stats[0]};
     } catch (const std::exception &e) {
         fail(e);

@@ -34,7 +34,6 @@ enum ChainError : int {
     E_FLOAT_DOMAIN = 4,    // the latency model met a step it has no logarithm for (subnormal / non-positive)
     E_COUNT_OVERFLOW = 5,  // a pair count exceeded 16 bits
     E_REMOTE_ERROR = 6,    // column-sharded chain: another rank failed with something other than a capacity error, or the ranks fell out of step -- not worth a retry
-    E_PICK_TIMEOUT = 7,    // internal: the substitution block of a step gave up waiting for the pick its search block publishes (k_iter_select2)
 };
 
 struct RowInfo {  // quantised interval + latency of one row (reference Op.qint / Op.latency)

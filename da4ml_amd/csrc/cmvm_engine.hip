@@ -85,7 +85,11 @@ constexpr int WAVE = 64;
 constexpr int SEL_THREADS = 1024;  // k_iter_select block (16 waves)
 constexpr int UPD_THREADS = 256;   // k_iter_update block
 constexpr int UPD_WAVES = UPD_THREADS / WAVE;
-constexpr int MAX_GROUPS = 4096;   // 16 waves x 64 lanes x 4 register-resident bounds in k_iter_select
+#ifndef DA_MAX_GROUPS
+#define DA_MAX_GROUPS 2048  // group records the search sweeps every step (16 waves x 64 lanes x 2).  Measured (MI355X, round 6, C3 batch / one chain, us per step; slots of a
+                            // group read held in registers: DA_SEL_RK x 64): 4096 x 512 slots (RK 8) 34.4 / 23.0; 2048 x 1024 (RK 16) 33.1 / 22.2, (RK 8) 40.5 / 25.3; 1024 x 2048 (RK 16) 47.4 / 28.1
+#endif
+constexpr int MAX_GROUPS = DA_MAX_GROUPS;
 #ifndef DA_IDS_LDS
 #define DA_IDS_LDS 2048  // partner row ids of a step staged in LDS by k_iter_select (tests/emu builds with 16: its problems are small, both paths run)
 #endif
@@ -120,6 +124,23 @@ constexpr int MAX_GROUPS = 4096;   // 16 waves x 64 lanes x 4 register-resident 
 #define SEL_TIMER_DECL
 #define SEL_TIMER_MARK(i)
 #define SEL_TIMER_FLUSH
+#endif
+
+// -DDA_STEP_CLOCKS (diagnostic build): where a chain's step goes -- the two kernels' durations as the chain sees them (first block start to last
+// block end) and the two gaps between them (kernel boundary + the wait for a place on a CU), in ticks of the 100 MHz real-time counter, summed over
+// the steps into st_qdiag[0] (select), [1] (select -> update), [4] (update), [5] (update -> next select), [7] (steps counted)
+#ifdef DA_STEP_CLOCKS
+#define CLK_NOW() ((unsigned long long)__builtin_amdgcn_s_memrealtime())
+#define CLK_MARK(g, par, slot, inverted) atomicMax(&(g)->clk[par][slot], (inverted) ? ~CLK_NOW() : CLK_NOW())
+#ifndef DA_CLK_STEP_LO
+#define DA_CLK_STEP_LO 0  // the sums cover the steps [LO, HI) of every chain (a window of the chain)
+#endif
+#ifndef DA_CLK_STEP_HI
+#define DA_CLK_STEP_HI 0x7FFFFFFF
+#endif
+#define CLK_TIMED_STEP(t) ((t) >= DA_CLK_STEP_LO && (t) < DA_CLK_STEP_HI)
+#else
+#define CLK_MARK(g, par, slot, inverted)
 #endif
 
 // header of a pair block's payload line (16 bytes, followed by the K u16 counts)
@@ -308,11 +329,12 @@ struct ChainDev {
                                    // spec[t & 1].word, as it stands AFTER step t: appended by the update of step t (zeroed by the selection of step t)
     CandEntry l_list[2][TOUCH_CAP];// [t & 1]: the entries of the table of step t that touch exactly one row of the pick and reach spec[t & 1].word,
                                    // listed by the search block: the update of step t passes on those it does not re-evaluate
-    SpecPick pick;                 // a step that cannot use spec[]: the pick, found and published by the search block for the substitution block
-    unsigned int pick_flag;        // t + 1 once `pick` holds the pick of step t
     uint32_t *sp_cnt;              // [6][Kpad] exact counts of the six pairs among {A, B, new row}: select -> update
     unsigned long long st_fast;    // steps whose pick was known before the step began
     unsigned long long st_qphase[4];  // shader-clock cycles of the search block: bounds, arg-max (steps without a known pick), search, steps timed
+#ifdef DA_STEP_CLOCKS
+    unsigned long long clk[2][4];     // [step & 1]: ~(first select block start), last select block end, ~(first update block start), last update block end (s_memrealtime, 100 MHz)
+#endif
     unsigned long long st_qdiag[9];   // (phase-timer builds) [5] steps whose work list held > 32 groups, [6] the longest work list, [7] passes over the whole table (pick not known ahead), [8] work-list entries in all; group re-reads that found a stale bound below the floor / of clean groups with an excluded
                                       // best entry; [2],[3] scratch; [4] sum over the steps of the longest wave's re-read rounds
 };
@@ -1415,6 +1437,9 @@ static_assert(MAX_GROUPS % SEL2_THREADS == 0 && SEL2_THREADS % WAVE == 0 && SEL2
 #ifndef DA_AB_REPAIR_ROUNDS
 #define DA_AB_REPAIR_ROUNDS 8  // measured (MI355X, C3 batch / one chain, us per step): 0: 36.0 / 24.9, 1: 35.5 / 24.0, 2: 34.9 / 23.6, 4: 34.4 / 23.1, 8: 34.4 / 22.9
 #endif
+#ifndef DA_SEL_RK
+#define DA_SEL_RK 16  // (see DA_MAX_GROUPS)
+#endif
 constexpr int QL_CAP = DA_CAND_CAP * 4;  // entries touching the pick's rows the search may meet above its rising floor before it gives up (LDS)
 
 #ifdef DA_PHASE_TIMERS
@@ -1424,6 +1449,49 @@ constexpr int QL_CAP = DA_CAND_CAP * 4;  // entries touching the pick's rows the
 #define Q_TIMER_DECL
 #define Q_TIMER_MARK(i)
 #endif
+
+// The table's best entry -- highest rank, then highest tie word -- by ONE WORKGROUP and a plain pass over the dense rank array: no bounds, nothing
+// written.  For the substitution block of a step whose pick is not known ahead (the first step of a chain; an overflowed candidate list): 4 bytes per
+// slot twice (8 + 8 MB for a 256x256 chain, once per chain).  rank 0: nothing selectable.  red_*: one LDS word per wave.  Ends with a block barrier.
+__device__ __forceinline__ void table_argmax_block(ChainDev *g, uint32_t &rank, unsigned long long &tie, uint32_t *red_rank, unsigned long long *red_tie) {
+    const DA_GLOBAL uint32_t *hrank = (const DA_GLOBAL uint32_t *)g->hrank;
+    const DA_GLOBAL unsigned long long *hkey = (const DA_GLOBAL unsigned long long *)g->hkey;
+    const uint32_t C = g->C;
+    const DA_GLOBAL uint8_t *hidx = reinterpret_cast<const DA_GLOBAL uint8_t *>(hrank + (size_t)C);
+    const int tid = threadIdx.x, nthr = blockDim.x, lane = lane_id(), wid = wave_id(), nw = nthr / WAVE;
+    typedef unsigned int da_u4 __attribute__((ext_vector_type(4)));
+    const DA_GLOBAL da_u4 *hr4 = reinterpret_cast<const DA_GLOBAL da_u4 *>(hrank);  // (C is a multiple of 256, the array starts on a 256-byte boundary)
+    uint32_t best = 0;
+    for (uint32_t i = (uint32_t)tid; i < C / 4; i += (uint32_t)nthr) {
+        const da_u4 v = hr4[i];
+        best = max(max(best, v.x), max(max(v.y, v.z), v.w));
+    }
+    best = wave_max_u32(best);
+    if (lane == 0) red_rank[wid] = best;
+    __syncthreads();
+    best = wave_max_u32(lane < nw ? red_rank[lane] : 0u);
+    unsigned long long bt = 0;
+    if (best != 0)
+        for (uint32_t i = (uint32_t)tid; i < C / 4; i += (uint32_t)nthr) {
+            const da_u4 v = hr4[i];
+            const uint32_t r[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (r[q] == best) {
+                    const uint32_t sl = 4 * i + (uint32_t)q;
+                    const unsigned long long k = hkey[sl];
+                    const unsigned long long tw = tie_word((uint32_t)k, (uint32_t)(k >> 32), (int)hidx[sl]);
+                    bt = tw > bt ? tw : bt;
+                }
+        }
+    bt = wave_max_u64(bt);
+    if (lane == 0) red_tie[wid] = bt;
+    __syncthreads();
+    bt = wave_max_u64(lane < nw ? red_tie[lane] : 0ull);
+    rank = best;
+    tie = bt;
+    __syncthreads();
+}
 
 // The pick of a step from what the previous step left: the best entry it did not touch (spec) against the candidates its update
 // listed.  Every wave computes the same (one round trip when there are candidates, none otherwise).  false: no such entry, or a list
@@ -1454,6 +1522,7 @@ __device__ __forceinline__ bool resolve_pick(const DA_GLOBAL CandEntry *cl, unsi
 
 template <class Cell> __device__ __forceinline__ void search_body(ChainDev *g, int step) {
     constexpr int NW = SEL2_THREADS / WAVE, GPL = MAX_GROUPS / SEL2_THREADS;  // waves; group bounds per lane
+    constexpr int RKN = DA_SEL_RK;  // slots per lane of a group read that are held in registers (x 64 lanes: groups of up to 512 slots in one round trip)
     const int par = step & 1;
     int was_done = g->done, had_error = g->error, n_groups = g->n_groups;
     unsigned long long sp_word = g->spec[par ^ 1].word, sp_tie = g->spec[par ^ 1].tie;
@@ -1586,20 +1655,20 @@ template <class Cell> __device__ __forceinline__ void search_body(ChainDev *g, i
         auto read_group = [&](const uint32_t grp, const bool dirty, const unsigned long long /*bound*/, const unsigned long long fl) {
             const uint32_t base = grp * gs;
             // ---- round trip 1: the ranks of all slots (one dense array, coalesced; 8 slots per lane)
-            uint32_t rk[8], grank = 0;
+            uint32_t rk[RKN], grank = 0;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < RKN; ++u) {
                 const int o = lane + u * WAVE;
                 rk[u] = c.hrank[base + (o < gs ? o : 0)];
             }
             load_fence();
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < RKN; ++u) {
                 pin_vgpr(rk[u]);
                 if (lane + u * WAVE >= gs) rk[u] = 0;
                 grank = max(grank, rk[u]);
             }
-            for (int o = lane + 8 * WAVE; o < gs; o += WAVE) grank = max(grank, c.hrank[base + o]);
+            for (int o = lane + RKN * WAVE; o < gs; o += WAVE) grank = max(grank, c.hrank[base + o]);
             grank = wave_max_u32(grank);
             // only slots whose rank reaches the floor's can matter (the floor's own rank included: the tie word decides)
             // (a group that is not verified is left exact: at least its best slots are read)
@@ -1610,14 +1679,14 @@ template <class Cell> __device__ __forceinline__ void search_body(ChainDev *g, i
                 // flight together (nearly always a single turn: a handful of the 512 slots qualify)
                 uint32_t want = 0;
 #pragma unroll
-                for (int u = 0; u < 8; ++u) want |= rk[u] >= thr ? 1u << u : 0u;
+                for (int u = 0; u < RKN; ++u) want |= rk[u] >= thr ? 1u << u : 0u;
                 while (__any(want != 0)) {
                     if (want) {
                         const int u = ctz32(want);
                         want &= want - 1;
                         uint32_t r = rk[0];
 #pragma unroll
-                        for (int v = 1; v < 8; ++v) r = u == v ? rk[v] : r;
+                        for (int v = 1; v < RKN; ++v) r = u == v ? rk[v] : r;
                         const uint32_t sl = base + (uint32_t)(lane + u * WAVE);
                         const unsigned long long k = c.hkey[sl];
                         const unsigned long long tw = tie_word((uint32_t)k, (uint32_t)(k >> 32), (int)hidx[sl]);
@@ -1625,7 +1694,7 @@ template <class Cell> __device__ __forceinline__ void search_body(ChainDev *g, i
                         lw = max(lw, offer(r, tw, fl, pass != 0));
                     }
                 }
-                for (int o = lane + 8 * WAVE; o < gs; o += WAVE) {
+                for (int o = lane + RKN * WAVE; o < gs; o += WAVE) {
                     const uint32_t r2 = c.hrank[base + o];
                     if (r2 >= thr) {
                         const unsigned long long k2 = c.hkey[base + o];
@@ -1737,30 +1806,14 @@ template <class Cell> __device__ __forceinline__ void search_body(ChainDev *g, i
         const bool mine = best_rank != 0 && wnr == best_rank && wnt == best_tie;  // exactly one wave holds the winner (tie words are unique)
         if (pass == 0) {
             Q_TIMER_MARK(2)
-            // the pick of this step, for the substitution block that waits for it (device-scope stores, then the flag with release)
+            // (the substitution block of this launch finds the same pick by itself -- table_argmax_block: the two blocks never wait for each other)
             if (best_rank == 0) {
                 if (tid == 0) {
-                    __hip_atomic_store(&g->pick.word, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(&g->pick_flag, (unsigned int)step + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
                     g->spec[par].word = 0;
                     g->l_n[par] = 0;
                 }
                 if (lane == 0 && rescans) atomicAdd(&g->st_rescans, (unsigned long long)rescans);
                 return;  // the table holds nothing selectable: the chain ends
-            }
-            if (mine && lane == 0) {
-                unsigned long long *pw = reinterpret_cast<unsigned long long *>(&g->pick);
-                const unsigned long long v[8] = {bound_word(best_rank, best_tie),
-                                                 best_tie,
-                                                 ((unsigned long long)cand_refA.y << 32) | cand_refA.x,
-                                                 ((unsigned long long)cand_refB.y << 32) | cand_refB.x,
-                                                 ((unsigned long long)f2u(cand_ra.hi) << 32) | f2u(cand_ra.lo),
-                                                 ((unsigned long long)f2u(cand_ra.lat) << 32) | f2u(cand_ra.step),
-                                                 ((unsigned long long)f2u(cand_rb.hi) << 32) | f2u(cand_rb.lo),
-                                                 ((unsigned long long)f2u(cand_rb.lat) << 32) | f2u(cand_rb.step)};
-#pragma unroll
-                for (int q = 0; q < 8; ++q) __hip_atomic_store(&pw[q], v[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&g->pick_flag, (unsigned int)step + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
             }
             exA = (uint32_t)((best_tie >> 7) & 0xFFFFFFu);
             exB = (uint32_t)(best_tie >> 31);
@@ -1883,7 +1936,8 @@ template <class Cell> __device__ __forceinline__ int pick_body(ChainDev *g, unsi
     __shared__ int s_np, s_part[NW];
     __shared__ unsigned int s_matches;
     __shared__ RowInfo s_new;
-    __shared__ unsigned long long s_pick[8];  // the published pick (a step whose pick was not known ahead)
+    __shared__ unsigned long long s_am_tie[NW];  // table_argmax_block (a step whose pick was not known ahead)
+    __shared__ uint32_t s_am_rank[NW];
     constexpr int IDS_LDS = DA_IDS_LDS;
     __shared__ uint32_t s_ids[IDS_LDS];  // the first partner row ids of the step (the rest, if any, goes through pl_ids in HBM)
     __shared__ Log2Table s_log2;  // copy of c_log2 (the latency model's look-up then stays off the memory path)
@@ -1938,44 +1992,29 @@ template <class Cell> __device__ __forceinline__ int pick_body(ChainDev *g, unsi
         }
     }
     SEL_TIMER_MARK(1)
-    if (!fast && wid == 0) {
-        // (the search block of this chain is resident or will be: blocks of a launch are dispatched in order, it comes first, and a waiting
-        // block holds no resource the other needs.  The wait is bounded all the same -- seconds -- so that a fault ends in an error code.)
-        int timed_out = 0;
-        if (lane == 0) {
-            unsigned int spins = 0;
-            while (__hip_atomic_load(&g->pick_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != (unsigned int)step + 1u) {
-                if (++spins > (1u << 22)) {
-                    timed_out = 1;
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(2);
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-        if (lane < 8) s_pick[lane] = __hip_atomic_load(reinterpret_cast<unsigned long long *>(&g->pick) + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (timed_out) {  // lane 0: no pick -> the chain stops below, with the error
-            s_pick[0] = 0;
-            g->error = E_PICK_TIMEOUT;
+    unsigned long long pk_word = 1;
+    if (!fast) {
+        // (block-uniform, rare: the first step of a chain, an overflowed list) no pick known ahead: the arg-max of the table by this block itself, a
+        // plain pass over the rank array -- nothing is written, no bound is read, and nothing is awaited from the search block of this launch, which
+        // finds the same entry through the bounds for its own purpose (HIP promises nothing about the order in which workgroups are dispatched)
+        uint32_t r0;
+        table_argmax_block(g, r0, best_tie, s_am_rank, s_am_tie);
+        pk_word = r0 ? bound_word(r0, best_tie) : 0ull;
+        A = (uint32_t)((best_tie >> 7) & 0xFFFFFFu);
+        B = (uint32_t)(best_tie >> 31);
+        if (pk_word) {
+            refA = rowoff[A];
+            refB = rowoff[B];
+            ra = load_row(c.rows, A);
+            rb = load_row(c.rows, B);
         }
     }
     __syncthreads();
     SEL_TIMER_MARK(2)
-    unsigned long long pk_word = 1;
-    if (!fast) {
-        pk_word = s_pick[0];
-        best_tie = s_pick[1];
-        refA = da_u2{(uint32_t)s_pick[2], (uint32_t)(s_pick[2] >> 32)};
-        refB = da_u2{(uint32_t)s_pick[3], (uint32_t)(s_pick[3] >> 32)};
-        ra = RowInfo{u2f((uint32_t)s_pick[4]), u2f((uint32_t)(s_pick[4] >> 32)), u2f((uint32_t)s_pick[5]), u2f((uint32_t)(s_pick[5] >> 32))};
-        rb = RowInfo{u2f((uint32_t)s_pick[6]), u2f((uint32_t)(s_pick[6] >> 32)), u2f((uint32_t)s_pick[7]), u2f((uint32_t)(s_pick[7] >> 32))};
-        A = (uint32_t)((best_tie >> 7) & 0xFFFFFFu);
-        B = (uint32_t)(best_tie >> 31);
-    }
     const uint32_t Nw = (uint32_t)n_rows0;
     if (pk_word == 0 || (int)Nw >= rcap) {
         if (tid == 0) {
-            if (pk_word != 0) g->error = E_ROW_CAPACITY;  // (pk_word == 0 after a time-out: the error is set already)
+            if (pk_word != 0) g->error = E_ROW_CAPACITY;
             g->done = 1;
             g->n_partners = 0;
             atomicAdd(n_done, 1u);
@@ -2233,10 +2272,33 @@ template <class Cell> __device__ __forceinline__ int pick_body(ChainDev *g, unsi
 #endif
 template <class Cell> __global__ void __launch_bounds__(SEL2_THREADS) __attribute__((amdgpu_waves_per_eu(DA_SEL2_WAVES, DA_SEL2_WAVES))) k_iter_select2(ChainDev *chains, int n_chains, unsigned int *n_done, int step) {
     if ((int)blockIdx.x >= n_chains) return;
+#ifdef DA_STEP_CLOCKS
+    {
+        ChainDev *g = &chains[blockIdx.x];
+        if (threadIdx.x == 0 && !g->done) {
+            CLK_MARK(g, step & 1, 0, true);
+            if (blockIdx.y == 1 && step > 0) {  // the step before this one is complete: its four marks into the sums
+                unsigned long long *k = g->clk[(step - 1) & 1];
+                if (k[0] && k[1] && k[2] && k[3] && CLK_TIMED_STEP(step - 1)) {
+                    g->st_qdiag[0] += k[1] - ~k[0];
+                    g->st_qdiag[1] += ~k[2] - k[1];
+                    g->st_qdiag[4] += k[3] - ~k[2];
+                    g->st_qdiag[5] += CLK_NOW() - k[3];
+                    g->st_qdiag[7] += 1;
+                }
+                k[0] = k[1] = k[2] = k[3] = 0;
+            }
+        }
+    }
+#endif
     if (blockIdx.y == 0)
         search_body<Cell>(&chains[blockIdx.x], step);
     else
         (void)pick_body<Cell>(&chains[blockIdx.x], n_done, step);
+#ifdef DA_STEP_CLOCKS
+    __syncthreads();
+    if (threadIdx.x == 0) CLK_MARK(&chains[blockIdx.x], step & 1, 1, false);
+#endif
 }
 
 #ifndef DA_UPD_OCC
@@ -2613,7 +2675,17 @@ __device__ __forceinline__ void update_body(ChainDev *gq, bool in_range, int blo
 template <class Cell>
 __global__ void __launch_bounds__(UPD_THREADS, DA_UPD_OCC) __attribute__((amdgpu_num_sgpr(DA_UPD_SGPRS))) k_iter_update(ChainDev *chains, int n_chains) {
     // Grid (chains padded to a multiple of 8, blocks per chain): the chain index is the FAST grid dimension (see update_body)
+#ifdef DA_STEP_CLOCKS
+    ChainDev *gk = &chains[(int)blockIdx.x < n_chains ? blockIdx.x : 0];
+    const bool clk_on = (int)blockIdx.x < n_chains && !gk->done;
+    const int clk_par = (gk->iter - 1) & 1;
+    if (clk_on && threadIdx.x == 0) CLK_MARK(gk, clk_par, 2, true);
+#endif
     update_body<Cell, UPD_WAVES>(&chains[(int)blockIdx.x < n_chains ? blockIdx.x : 0], (int)blockIdx.x < n_chains, (int)blockIdx.y, (int)gridDim.y);  // clamped: the descriptor read is unconditional
+#ifdef DA_STEP_CLOCKS
+    __syncthreads();
+    if (clk_on && threadIdx.x == 0) CLK_MARK(gk, clk_par, 3, false);
+#endif
 }
 
 // ================================================================================= column-sharded chains (cmvm_shard.h)
@@ -2971,6 +3043,22 @@ struct DeviceBuffer {  // grow-only device allocation reused across calls
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// spin-wait step of the two launch threads' hand-shake: a pause for the first few thousand polls (the partner answers within microseconds while both are
+// queueing launches), then the core is given up between polls -- the waits that last (the main thread waiting for the device, the helper between
+// windows) must not hold a core at 100 % (ranks of one host share its cores)
+inline void spin_wait_step(unsigned &polls) {
+    if (++polls < 4096u) {
+#if defined(__x86_64__) || defined(__i386__)
+        __builtin_ia32_pause();
+#elif defined(__aarch64__)
+        asm volatile("yield");
+#endif
+    } else if (polls < 8192u)
+        std::this_thread::yield();
+    else
+        std::this_thread::sleep_for(std::chrono::microseconds(50));
+}
+
 // Events of one call, destroyed however the call ends (a HIP error or the termination guard of the greedy loop used to leak
 // the timing, window and sample events of the call -- up to 12 k of them).
 struct EventGuard {
@@ -3082,6 +3170,37 @@ struct Geometry {
     int n_bits, K, Kpad, rcap, lcap, gs_log2, n_groups, pk_cap, pb_log2;
     uint32_t C, rl_cap;
 };
+
+// Dynamic LDS of a k_iter_select2 block WITHOUT the optional claim area (pick_body's carve): B's list, six count vectors, five per-column arrays
+size_t sel2_fixed_lds(const ChainJob &job, const Geometry &g) {
+    const size_t no = (size_t)job.n_out, entb = g.wide ? 16 : 4;
+    return no * entb + 6 * (size_t)g.Kpad * 4 + (5 * no + 1) * 4;
+}
+// What the device leaves for it: the per-workgroup LDS limit less the kernel's STATIC __shared__ arrays (the search block's bound / work lists,
+// the substitution block's partner ids: ~75 KB -- asked from the runtime, not assumed), less a small reserve.  Static + dynamic beyond the limit
+// fails in hipFuncSetAttribute or at launch with a raw HIP error; the caller turns it into a clear message.
+size_t sel2_lds_budget(int device, bool wide) {
+    static std::mutex mu;
+    static size_t cached[2] = {0, 0};
+    std::lock_guard<std::mutex> lk(mu);
+    if (!cached[wide]) {
+        hipFuncAttributes fa;
+        const void *fn = wide ? reinterpret_cast<const void *>(&k_iter_select2<uint64_t>) : reinterpret_cast<const void *>(&k_iter_select2<uint32_t>);
+        HIP_CHECK(hipFuncGetAttributes(&fa, fn));
+        int limit = 0;
+        HIP_CHECK(hipDeviceGetAttribute(&limit, hipDeviceAttributeMaxSharedMemoryPerBlock, device));
+        if (limit < 64 * 1024) limit = 64 * 1024;
+        const size_t used = fa.sharedSizeBytes + 256;
+        cached[wide] = (size_t)limit > used ? (size_t)limit - used : 1;
+    }
+    return cached[wide];
+}
+// words of the optional LDS area in which the substitution block combines the row bitmaps of a young chain: dropped (0: every wave ORs its words
+// itself) when it does not fit beside the rest -- the kernel runs either way
+int claim_words_for(const ChainJob &job, const Geometry &g, size_t budget) {
+    const size_t words = ((size_t)g.rcap + 31) / 32, fixed = align_up(sel2_fixed_lds(job, g), 16);
+    return words * 4 <= 64 * 1024 && fixed + words * 4 + 16 <= budget ? (int)words : 0;
+}
 
 // carve one chain's arrays; with base == nullptr only the size is computed
 size_t carve_chain(unsigned char *base, const ChainJob &job, const Geometry &g, ChainDev &d) {
@@ -3290,7 +3409,7 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
         d.rl_cap = g.rl_cap;
         d.rl_used = (uint32_t)jobs[i].n_in * (uint32_t)jobs[i].n_out;
         d.n_rows = jobs[i].n_in;
-        d.claim_words = (g.rcap + 31) / 32 * 4 <= 64 * 1024 ? (g.rcap + 31) / 32 : 0;
+        d.claim_words = claim_words_for(jobs[i], g, sel2_lds_budget(im.device, g.wide));
         d.iter = 0;
         d.done = (jobs[i].method == M_DUMMY || jobs[i].method < 0) ? 1 : 0;
         d.cb_words = (g.rcap + 31) / 32;
@@ -3334,11 +3453,11 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
     long long max_pairs[2] = {0, 0};
     for (int i = 0; i < n; ++i) {
         int w = geo[i].wide;
-        size_t claim_bytes = ((size_t)geo[i].rcap + 31) / 32 * 4;
-        if (claim_bytes > 64 * 1024) claim_bytes = 0;
-        const size_t no = (size_t)jobs[i].n_out, cellb = geo[i].wide ? 8 : 4, entb = geo[i].wide ? 16 : 4;
-        size_t s = no * entb + 6 * (size_t)geo[i].Kpad * 4 + (5 * no + 1) * 4 + claim_bytes;
-        s = align_up(s, 16);
+        const size_t no = (size_t)jobs[i].n_out, cellb = geo[i].wide ? 8 : 4;
+        const size_t s = align_up(sel2_fixed_lds(jobs[i], geo[i]) + (size_t)desc[i].claim_words * 4, 16);
+        if (s > sel2_lds_budget(im.device, geo[i].wide))
+            throw std::runtime_error("selection kernel needs " + std::to_string(s) + " bytes of dynamic LDS, the device leaves it " + std::to_string(sel2_lds_budget(im.device, geo[i].wide)) +
+                                     " beside the kernel's static arrays (n_out too large)");
         sel_lds[w] = std::max(sel_lds[w], s);
         upd_lds[w] = std::max(upd_lds[w], align_up(2 * no * cellb + no * 6, 16) + align_up((size_t)UPD_WAVES * QN * 3 * (size_t)geo[i].Kpad * 4, 16));  // UpdLds: hand-off tables | counters
         pair_lds[w] = std::max(pair_lds[w], (size_t)4 * geo[i].Kpad * 4);
@@ -3365,7 +3484,6 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
         }
         HIP_CHECK(hipGetLastError());
     }
-    if (sel_lds[0] > 150 * 1024 || sel_lds[1] > 150 * 1024) throw std::runtime_error("selection kernel needs more than 150 KiB of LDS (n_out too large)");
     if (ranges[0].count)
         HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_iter_select2<uint32_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sel_lds[0]));
     if (ranges[1].count)
@@ -3473,7 +3591,8 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
                 HIP_CHECK(hipSetDevice(im.device));
                 while (true) {
                     long long s;
-                    while ((s = helper.seq.load(std::memory_order_acquire)) == seen && !helper.quit.load(std::memory_order_acquire)) __builtin_ia32_pause();
+                    unsigned polls = 0;
+                    while ((s = helper.seq.load(std::memory_order_acquire)) == seen && !helper.quit.load(std::memory_order_acquire)) spin_wait_step(polls);
                     if (s == seen) break;
                     seen = s;
                     if (!helper.err) window_launches(1, helper.first_step, helper.iters, helper.parity, nullptr);
@@ -3482,9 +3601,10 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
             } catch (...) {
                 helper.err = std::current_exception();
                 helper.ack.store(helper.seq.load(), std::memory_order_release);  // (whatever window was being served: the main thread rethrows)
+                unsigned polls = 0;
                 while (!helper.quit.load(std::memory_order_acquire)) {  // keep acknowledging until told to leave
                     helper.ack.store(helper.seq.load(), std::memory_order_release);
-                    __builtin_ia32_pause();
+                    spin_wait_step(polls);
                 }
             }
         });
@@ -3519,7 +3639,8 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
         launched_iters += this_window + 1;
         if (two_threads) {
             const long long want = helper.seq.load(std::memory_order_relaxed);
-            while (helper.ack.load(std::memory_order_acquire) != want) __builtin_ia32_pause();
+            unsigned polls = 0;
+            while (helper.ack.load(std::memory_order_acquire) != want) spin_wait_step(polls);
             if (helper.err) std::rethrow_exception(helper.err);
         }
         for (size_t gi = 0; gi < groups.size(); ++gi) HIP_CHECK(hipStreamWaitEvent(im.poll_stream, win_ev[p][gi], 0));

@@ -383,7 +383,20 @@ def solve_column_sharded(kernel, method0: str = 'wmc', method1: str = 'auto', ha
         # build and keep a new communicator each time.  Every rank takes the same branch: they all call in the same order.
         key = (world, dist.get_rank() if world > 1 else 0, str(device))
         raw = _rccl_ids.get(key)
-        if raw is None:
+        # Do all ranks still hold the group's id?  A rank whose previous solve raised has dropped it (below); the others may not have
+        # failed at all (an argument error, a KeyboardInterrupt, an out-of-memory on one rank).  One tiny all-reduce(max) per solve --
+        # not per greedy step -- makes the decision collective: if ANY rank needs an id, EVERY rank forgets its own (and the library's
+        # communicators of it) and takes the fresh one of the broadcast; no rank can broadcast while the others skip it.
+        need = 0 if raw is not None else 1
+        if world > 1:
+            need = int(max_over_ranks(need, device if dist.get_backend() == 'nccl' else None))
+        if need:
+            if raw is not None:  # (another rank lost its id: this rank's communicator of the old one goes too)
+                _rccl_ids.clear()
+                try:
+                    _binary.rccl_shutdown()
+                except Exception:
+                    pass
             raw = _binary.rccl_unique_id() if rank == 0 else bytes(128)
             if world > 1:
                 on_gpu = dist.get_backend() == 'nccl'
@@ -397,9 +410,9 @@ def solve_column_sharded(kernel, method0: str = 'wmc', method1: str = 'auto', ha
                                                      latencies=latencies, adder_size=adder_size, carry_size=carry_size, search_all_decompose_dc=search_all_decompose_dc,
                                                      rank=rank, world=world)  # fmt: skip
         except BaseException:
-            # a failed solve may leave the communicator of this id wedged: forget the id (and the library's communicators), so that the next
-            # call -- on every rank: they all failed or were aborted together -- broadcasts a fresh one instead of re-using it
-            _rccl_ids.pop(key, None)
+            # a failed solve may leave the communicator of this id wedged: forget every cached id and the library's communicators (rccl_shutdown
+            # destroys them all) on THIS rank; the agreement above makes the other ranks follow at the next call, whether they failed or not
+            _rccl_ids.clear()
             try:
                 _binary.rccl_shutdown()
             except Exception:

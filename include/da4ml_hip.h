@@ -107,6 +107,9 @@ da_result *da_solve_sharded_rccl(const float *kernel, int64_t n_in, int64_t n_ou
  * through the library): the running da_solve_sharded stops at the next exchange and fails with a runtime error instead of
  * continuing with a buffer that was not reduced. */
 void da_comm_abort(void);
+/* int32 elements handed to all-reduce(sum) by the last da_solve_sharded / da_solve_sharded_rccl of this process (x 4 = bytes per rank and
+ * exchange direction): the exchange volume of a column-sharded solve, for bench.py's c4 workload. */
+int64_t da_shard_exchanged_elements(void);
 
 /* ---- result access (da4ml.types.Pipeline / CombLogic / Op, bindings.cc:106-151) ---------------------------- */
 int da_n_stages(const da_result *r);

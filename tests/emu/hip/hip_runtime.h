@@ -271,3 +271,8 @@ inline hipError_t hipEventRecord(hipEvent_t, hipStream_t = nullptr) { return hip
 inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t, hipEvent_t) { *ms = 0.0f; return hipSuccess; }
 inline hipError_t hipFuncSetAttribute(const void *, hipFuncAttribute, int) { return hipSuccess; }
+struct hipFuncAttributes { size_t sharedSizeBytes = 0; int numRegs = 0; };
+// HIPEMU_STATIC_LDS (test hook): the static __shared__ bytes the emulated kernels report -- lets the CPU suite drive the product's LDS budget check
+inline hipError_t hipFuncGetAttributes(hipFuncAttributes *a, const void *) { *a = hipFuncAttributes{}; if (const char *e = getenv("HIPEMU_STATIC_LDS")) a->sharedSizeBytes = (size_t)atoll(e); return hipSuccess; }
+enum hipDeviceAttribute_t { hipDeviceAttributeMaxSharedMemoryPerBlock = 8 };
+inline hipError_t hipDeviceGetAttribute(int *v, hipDeviceAttribute_t, int) { *v = 160 * 1024; return hipSuccess; }

@@ -156,6 +156,18 @@ def fork_after_use():
         child_of_busy_fork=os.WEXITSTATUS(st2), fork_seconds=fork_seconds, solve_seconds=t_solve)
 
 
+def lds_budget():
+    """HIPEMU_STATIC_LDS makes the emulated kernels report static __shared__ bytes: the product's budget check (static + dynamic against the
+    device's per-workgroup limit) then drops the optional claim area first -- same results -- and refuses with a clear message beyond that"""
+    o = Oracle('port')
+    ks = [int_matrix(s, 10 + s, 12, -64, 64) for s in range(4)]
+    try:
+        got = hip.solve_many(ks, **SINGLE)
+        out(ok=True, bad=[i for i, k in enumerate(ks) if got[i] != o.solve(k, **SINGLE)], message='')
+    except RuntimeError as e:
+        out(ok=False, bad=[], message=str(e))
+
+
 def retry():
     """arena heuristics far too small (environment set by the test): capacity error on the device, rerun with larger arenas"""
     o = Oracle('port')
@@ -255,5 +267,5 @@ def dais():
 
 if __name__ == '__main__':
     what = sys.argv[1]
-    {'random': lambda: random_cases(int(sys.argv[2]), int(sys.argv[3])), 'oddsteps': lambda: odd_steps(int(sys.argv[2]), int(sys.argv[3])), 'layouts': layouts, 'batch': batch, 'retry': retry, 'big_table': big_table, 'fork': fork_after_use, 'record': lambda: record(sys.argv[2], sys.argv[3]),
+    {'random': lambda: random_cases(int(sys.argv[2]), int(sys.argv[3])), 'oddsteps': lambda: odd_steps(int(sys.argv[2]), int(sys.argv[3])), 'layouts': layouts, 'batch': batch, 'lds_budget': lds_budget, 'retry': retry, 'big_table': big_table, 'fork': fork_after_use, 'record': lambda: record(sys.argv[2], sys.argv[3]),
      'shard_single': shard_single, 'shard_retry': shard_retry, 'shard_rank': shard_rank, 'dais': dais, 'race_cases': race_cases}[what]()  # fmt: skip

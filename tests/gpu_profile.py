@@ -30,3 +30,8 @@ if tm['search_steps_timed']:
 if tm['search_steps_timed']:
     print('search work lists: %.2f groups per step, %d steps with more than 32, longest %d; passes over the whole table %d; steps with a known pick %d of %d' % (tm['search_list_entries'] / tm['search_steps_timed'], tm['search_long_lists'], tm['search_longest_list'], tm['search_full_passes'], tm['fast_steps'], its))
 print('sampled per-launch: select %.1f us, update %.1f us, chains/launch %.1f' % (1e3 * tm['select_ms_sampled'] / sm, 1e3 * tm['update_ms_sampled'] / sm, tm['sampled_chain_launches'] / sm))
+if os.environ.get('STEP_CLOCKS'):  # a -DDA_STEP_CLOCKS build: the four sums ride in the search diagnostics (ticks of the 100 MHz real-time counter)
+    q = max(tm['search_full_passes'], 1)
+    print('step clocks (us per chain-step, %d chain-steps): select %.2f | boundary + placement %.2f | update %.2f | boundary + placement %.2f | sum %.2f' % (
+        q, 0.01 * tm['search_stale_rereads'] / q, 0.01 * tm['search_touch_rereads'] / q, 0.01 * tm['search_rounds'] / q, 0.01 * tm['search_long_lists'] / q,
+        0.01 * (tm['search_stale_rereads'] + tm['search_touch_rereads'] + tm['search_rounds'] + tm['search_long_lists']) / q))

@@ -64,6 +64,17 @@ def test_wide_host_pool(emu):
     assert r['bad'] == [] and r['chains'] >= 13
 
 
+def test_lds_budget_of_the_selection_kernel(emu):
+    """static + dynamic LDS of k_iter_select2 against the device's 160 KB per workgroup: with static arrays that leave room for
+    everything the chain runs with its claim area; with less the area is dropped and the results stay the same; with no room for the fixed part
+    the call fails with a message that names the sizes, not with a raw HIP launch error"""
+    roomy = emu('lds_budget', env=dict(HIPEMU_STATIC_LDS='75000'))
+    tight = emu('lds_budget', env=dict(HIPEMU_STATIC_LDS=str(160 * 1024 - 256 - 1000)))  # fixed part of these 12-column chains: 976 bytes; with the claim words and the alignment reserve > 1000
+    none = emu('lds_budget', env=dict(HIPEMU_STATIC_LDS=str(160 * 1024 - 256 - 64)))
+    assert roomy == {'ok': True, 'bad': [], 'message': ''} and tight == {'ok': True, 'bad': [], 'message': ''}
+    assert not none['ok'] and 'bytes of dynamic LDS' in none['message'] and 'n_out too large' in none['message']
+
+
 def test_fork_after_use(emu):
     r = emu('fork', timeout=600)
     assert (r['child'], r['parent'], r['fork_during_solve_ok'], r['child_of_busy_fork']) == (0, True, True, 0), r

@@ -392,3 +392,76 @@ def test_ranks_get_disjoint_core_slices(monkeypatch):
     assert mg.pin_rank_to_core_slice(0, 1) is None and not seen  # a single rank keeps every core
     monkeypatch.setenv('DA4ML_PIN_RANKS', '0')
     assert mg.pin_rank_to_core_slice(0, 4) is None and not seen
+
+
+RCCL_ID_WORKER = r'''
+import os, sys, json
+sys.path.insert(0, os.environ["DA_ROOT"])
+import numpy as np
+import torch.distributed as dist
+from da4ml_amd import multi_gpu as mg
+from da4ml_amd import _binary
+rank, world, local, device = mg.init("gloo")
+# the library's RCCL entry points replaced by stand-ins (no GPU here): what is under test is the PROTOCOL around them
+made, shut, seen = [0], [0], []
+def fake_id():
+    made[0] += 1
+    return bytes([made[0]]) * 128
+def fake_shutdown():
+    shut[0] += 1
+    return 1
+calls = [0]
+def fake_solve(kernel, uid, rank=0, world=1, **kw):
+    calls[0] += 1
+    ids = [None] * world
+    dist.all_gather_object(ids, uid)            # every rank must have been handed the SAME id
+    assert len(set(ids)) == 1, ids
+    seen.append(uid[0])
+    return "pipe", {"allreduce_calls": 0}
+_binary.rccl_unique_id, _binary.rccl_shutdown, _binary.solve_sharded_rccl = fake_id, fake_shutdown, fake_solve
+_binary.device_count = lambda: 0
+k = np.zeros((4, 4), np.float32)
+mg.solve_column_sharded(k, transport="rccl")               # first solve: rank 0's id broadcast
+mg.solve_column_sharded(k, transport="rccl")               # second: cached, no broadcast
+first = list(seen)
+# third solve: fails on rank 1 ONLY, inside the solve (behind the agreement, as an argument error or an allocation failure of one rank would);
+# rank 0's solve ends normally (its stand-in skips the exchange this once): rank 1 forgets its id, rank 0 knows nothing of it
+gather = [True]
+def third(kernel, uid, rank=0, world=1, **kw):
+    if rank == 1:
+        raise ValueError("rank-local failure")
+    return "pipe", {"allreduce_calls": 0}
+_binary.solve_sharded_rccl = third
+try:
+    mg.solve_column_sharded(k, transport="rccl")
+    failed = False
+except ValueError:
+    failed = True
+assert failed == (rank == 1)
+_binary.solve_sharded_rccl = fake_solve
+mg.solve_column_sharded(k, transport="rccl")               # must not hang, must not mix ids: both ranks agree to take a fresh one
+print(json.dumps({"rank": rank, "first": first, "last": seen[-1], "ids_made": made[0], "shutdowns": shut[0]}), flush=True)
+mg.shutdown()
+'''
+
+
+def test_rccl_id_is_renewed_collectively_after_a_rank_local_failure():
+    """ADVICE r05: a solve that fails on ONE rank made that rank broadcast for a fresh RCCL id at its next call while the others re-used the
+    cached one and skipped the broadcast -- a collective mismatch.  Now one all-reduce(max) per solve decides together: any rank without an
+    id makes every rank drop its own and take part in the broadcast.  (Transport stubbed: gloo, world 2, no GPU.)"""
+    import json
+
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE='2', LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), DA_ROOT=str(ROOT), DA4ML_PIN_RANKS='0')
+        procs.append(subprocess.Popen([sys.executable, '-c', RCCL_ID_WORKER], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=180) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0, e[-3000:]
+    r = [json.loads(o.strip().splitlines()[-1]) for o, _ in outs]
+    assert r[0]['first'] == [1, 1] and r[1]['first'] == [1, 1]       # one id for the first two solves
+    assert r[0]['last'] == r[1]['last'] == 2                          # a fresh one, the same on both ranks, afterwards
+    assert r[0]['ids_made'] == 2 and r[0]['shutdowns'] >= 1 and r[1]['shutdowns'] >= 1

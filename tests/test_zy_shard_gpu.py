@@ -23,7 +23,7 @@ sys.path.insert(0, os.environ["DA_ROOT"]); sys.path.insert(0, os.path.join(os.en
 from da4ml_amd import _binary as hip
 from oracle.oracle import Oracle
 from cases import int_matrix, random_case
-O = Oracle("port")
+O = Oracle("ref" if os.path.exists(os.path.join(os.environ["DA_ROOT"], "oracle", "_ref", "libref.so")) else "port")  # the reference's own sources, live, where the build travelled
 cases = [(int_matrix(0, 16, 16, -128, 128), {}), (int_matrix(1, 48, 40, -128, 128), dict(method0="wmc", method1="wmc", decompose_dc=-1, search_all_decompose_dc=False)),
          (int_matrix(2, 9, 20, -8, 8), dict(adder_size=1, carry_size=-1)), (int_matrix(3, 33, 7, -64, 64), dict(hard_dc=1))]
 cases += [random_case(s)[:2] for s in (1003, 1006, 1012, 1021, 1030, 1033)]
@@ -44,7 +44,7 @@ from da4ml_amd import _binary as hip
 from oracle.oracle import Oracle
 from cases import int_matrix
 rank, world, local, device = mg.init("gloo")
-O = Oracle("port")
+O = Oracle("ref" if os.path.exists(os.path.join(os.environ["DA_ROOT"], "oracle", "_ref", "libref.so")) else "port")  # the reference's own sources, live, where the build travelled
 same, steps = [], 0
 for k, kw in [(int_matrix(0, 16, 16, -128, 128), {}), (int_matrix(5, 64, 64, -128, 128), dict(method0="wmc", method1="wmc", decompose_dc=-1, search_all_decompose_dc=False)),
               (int_matrix(2, 9, 21, -8, 8), dict(adder_size=1, carry_size=-1))]:
@@ -91,7 +91,7 @@ from da4ml_amd import _binary as hip
 from da4ml_amd import multi_gpu as mg
 from oracle.oracle import Oracle
 from cases import int_matrix, random_case
-O = Oracle("port")
+O = Oracle("ref" if os.path.exists(os.path.join(os.environ["DA_ROOT"], "oracle", "_ref", "libref.so")) else "port")  # the reference's own sources, live, where the build travelled
 uid = hip.rccl_unique_id()
 cases = [(int_matrix(0, 16, 16, -128, 128), {}), (int_matrix(1, 48, 40, -128, 128), dict(method0="wmc", method1="wmc", decompose_dc=-1, search_all_decompose_dc=False)),
          (int_matrix(2, 9, 20, -8, 8), dict(adder_size=1, carry_size=-1))]
@@ -123,15 +123,43 @@ print(json.dumps({"same": same, "calls": calls, "ids_before_shutdown": ids_befor
 
 def _run_bounded(cmd, env, seconds=int(os.environ.get('DA4ML_TEST_RCCL_SECONDS', '200'))):
     """The one-rank RCCL scripts take 30 - 50 s.  On two of five boxes of round 5 the same script, same library, did not return from RCCL's
-    communicator set-up when started from inside the test suite (and ran through in 45 s when started alone on a third box): bounded, tried
-    twice, and reported as a SKIP with that reason rather than as ten minutes of silence.  No multi-rank RCCL run has ever been possible
-    here (one-GPU boxes); the exchange protocol itself is covered by the gloo tests."""
+    communicator set-up when started from inside the test suite (and ran through in 45 s when started alone on a third box); round 6 could not
+    reproduce it (profiles/r06_rccl_probe.txt: every set-up in ~2 s under each suspected condition).  So the run is bounded, tried twice, and a time-out is reported as an
+    XFAIL -- not a skip -- that carries what a debugger-less box can tell about the stuck process: RCCL's own log (NCCL_DEBUG=INFO), the
+    Python frames (faulthandler) and every thread's kernel stack / wait channel from /proc (tools/rccl_init_probe.py), also written
+    to gpurun_out/rccl_hang/.  No multi-rank RCCL run has ever been possible here (one-GPU boxes); the exchange protocol itself is
+    covered by the gloo tests."""
+    import tempfile
+
+    sys.path.insert(0, str(ROOT / 'tools'))
+    from rccl_init_probe import proc_snapshot
+
+    notes = []
     for attempt in range(2):
-        try:
-            return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=seconds)
-        except subprocess.TimeoutExpired:
-            continue
-    pytest.skip(f'RCCL set-up did not return within {seconds} s (twice) on this box: the one-rank RCCL transport could not be exercised')
+        with tempfile.TemporaryDirectory() as tmp:
+            log = Path(tmp) / 'nccl.log'
+            e = dict(env, NCCL_DEBUG='INFO', NCCL_DEBUG_SUBSYS='INIT,ENV,NET,BOOTSTRAP', NCCL_DEBUG_FILE=str(log), PYTHONFAULTHANDLER='1')
+            p = subprocess.Popen(cmd, env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+            try:
+                so, se = p.communicate(timeout=seconds)
+                return subprocess.CompletedProcess(cmd, p.returncode, so, se)
+            except subprocess.TimeoutExpired:
+                snap = proc_snapshot(p.pid)
+                import signal
+
+                p.send_signal(signal.SIGABRT)  # faulthandler prints every thread's Python frames
+                try:
+                    so, se = p.communicate(timeout=20)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+                    so, se = p.communicate()
+                nccl = log.read_text()[-3000:] if log.exists() else '<no RCCL log>'
+                note = f'--- attempt {attempt}: no return within {seconds} s\n--- RCCL log (tail)\n{nccl}\n--- stderr (tail)\n{se[-3000:]}\n--- threads\n{snap[-6000:]}'
+                notes.append(note)
+                out_dir = ROOT / 'gpurun_out' / 'rccl_hang'
+                out_dir.mkdir(parents=True, exist_ok=True)
+                (out_dir / f'hang_{os.getpid()}_{attempt}.txt').write_text(note)
+    pytest.xfail(f'RCCL set-up did not return within {seconds} s (twice) on this box\n' + '\n'.join(notes)[-8000:])
 
 
 def test_rccl_transport_one_rank():

@@ -22,8 +22,52 @@ __global__ void chase(const unsigned long long *buf, unsigned long long n_lines,
     long long t1 = wall_clock64();
     if (lane == 0) { out[gw] = x; cycles[gw] = t1 - t0; }
 }
-int main() {
+// the same chase with a cheap index (32-bit multiply + mask instead of 64-bit multiplies and a modulo: the arithmetic of `chase` is part of its
+// figure) over SMALL footprints: is a dependent line load that hits the XCD's 4 MB L2 or the 256 MB Infinity Cache faster than one that goes to HBM?
+// (round 6: decides whether compacting the pair table of an old chain can pay)
+__global__ void chase_pow2(const unsigned long long *buf, unsigned int line_mask, int steps, unsigned long long *out, long long *cycles) {
+    const int lane = threadIdx.x & 63;
+    const unsigned int gw = blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64;
+    unsigned int x = gw * 0x9E3779B1u + 12345u;
+    long long t0 = wall_clock64();
+    for (int s = 0; s < steps; ++s) {
+        x = x * 0x85EBCA77u + 0x165667B1u;
+        const unsigned int line = (x >> 9) & line_mask;
+        const unsigned long long v = buf[(size_t)line * 16 + (lane & 15)];
+        x += (unsigned int)v;  // dependent
+    }
+    long long t1 = wall_clock64();
+    if (lane == 0) { out[gw] = x; cycles[gw] = t1 - t0; }
+}
+int main(int argc, char **argv) {
     const size_t GB = 1ull << 30;
+    if (argc > 1 && argv[1][0] == 's') {  // ./latency_probe small
+        const size_t MB = 1ull << 20;
+        unsigned long long *buf;
+        CK(hipMalloc(&buf, 1024 * MB));
+        CK(hipMemset(buf, 0, 1024 * MB));
+        unsigned long long *out; long long *cyc;
+        CK(hipMalloc(&out, 8 << 20)); CK(hipMalloc(&cyc, 8 << 20));
+        int rate = 0; CK(hipDeviceGetAttribute(&rate, hipDeviceAttributeWallClockRate, 0));
+        printf("wall clock %d kHz; dependent random 128-byte line loads, cheap index arithmetic, all 256 CUs chasing inside the SAME footprint\n", rate);
+        const int steps = 4000;
+        for (size_t mb : {1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024}) {
+            const unsigned int mask = (unsigned int)(mb * MB / 128 - 1);
+            for (int waves_per_cu : {1, 4, 16}) {
+                const int blocks = 256 * waves_per_cu / 4 < 1 ? 1 : 256 * waves_per_cu / 4;
+                for (int rep = 0; rep < 2; ++rep) {  // (the first pass warms the caches)
+                    hipLaunchKernelGGL(chase_pow2, dim3(blocks), dim3(256), 0, 0, buf, mask, steps, out, cyc);
+                    CK(hipDeviceSynchronize());
+                }
+                std::vector<long long> h(blocks * 4);
+                CK(hipMemcpy(h.data(), cyc, h.size() * 8, hipMemcpyDeviceToHost));
+                double s = 0; for (auto v : h) s += v;
+                const double ns = s / h.size() / steps * 1e6 / rate;
+                printf("footprint %5zu MB  waves/CU %2d : %7.1f ns per dependent random line load\n", mb, waves_per_cu, ns);
+            }
+        }
+        return 0;
+    }
     size_t max_bytes = 48 * GB;
     unsigned long long *buf;
     CK(hipMalloc(&buf, max_bytes));
