@@ -25,8 +25,11 @@ Extra objects on the JSON line:
   check.verify  outside the timed region: every result of the last step replayed (own numpy replay of the C arrays) and
                 compared with its matrix; digests of every seed that has a committed record (reference build preferred)
 
-Other workloads (`--workload`): the 8-matrix default search, the 64x64 batch, and `c5_model_batch` = the end-to-end
-compile of a synthetic layer stack through `solve_many_sharded` (BASELINE configs[4]) with a CPU process-pool baseline.
+Other workloads (`--workload`): the 8-matrix default search, the 64x64 batch, `c5_model_batch` = the end-to-end
+compile of a synthetic layer stack through `solve_many_sharded` (BASELINE configs[4]) with a CPU process-pool baseline, and
+BASELINE configs[3] -- ONE 256x256 solve over the N GPUs, strong scaling -- in its two layouts: `c4_256x256_int8_column_sharded`
+(one chain over the output columns, two RCCL all-reduces per greedy step) and `c4_256x256_int8_candidate_sharded` (the
+default search's ten candidates over the ranks).
 """
 
 import argparse
@@ -50,8 +53,14 @@ WORKLOADS = {
     'c3_256x256_int8_batch8_default_search': (256, 256, 8, dict()),
     'c2_64x64_int8_batch64_single_chain': (64, 64, 64, SINGLE_CHAIN),
     'c5_model_batch': None,  # see run_c5
+    # BASELINE configs[3]: ONE 256x256 chain sharded over the ranks' GPUs (see run_c4) -- by output columns with two all-reduce(sum) per greedy
+    # step (the layout the config names; latency-bound), or the ten decompose_dc candidates of one searching solve over the ranks
+    'c4_256x256_int8_column_sharded': (256, 256, 1, SINGLE_CHAIN),
+    'c4_256x256_int8_candidate_sharded': (256, 256, 1, dict()),
     # plumbing check of the multi-rank path (tests/test_bench_contract.py runs it at 8 ranks on the emulated device): not a benchmark
     't0_plumbing_12x10_batch3_single_chain': (12, 10, 3, SINGLE_CHAIN),
+    't0_plumbing_12x10_column_sharded': (12, 10, 1, SINGLE_CHAIN),
+    't0_plumbing_12x10_candidate_sharded': (12, 10, 1, dict()),
 }
 # BASELINE configs[4] stand-in (JEDI-linear's weights are not in the reference tree and there is no network): a documented
 # synthetic layer stack; every layer is applied to C5_ROWS row vectors with their own input intervals / latencies, which is
@@ -361,6 +370,88 @@ def run_c5(args):
     print(json.dumps(line), flush=True)
 
 
+
+# ------------------------------------------------------------------------------------------------ C4: one solve over N GPUs
+def run_c4(args):
+    """BASELINE configs[3]: ONE matrix (seed 0), one solve per step, sharded over the ranks -- strong scaling.
+    `*_column_sharded`: the greedy chain sharded over the output columns (mg.solve_column_sharded; the library's RCCL transport on GPUs:
+    ncclAllReduce stream-ordered with the kernels, two per greedy step; with one rank the sharded phases and the collectives run all the same).
+    `*_candidate_sharded`: the decompose_dc candidates of the default search over the ranks (mg.solve_candidates_sharded: one all-reduce(MIN) +
+    one broadcast per solve).  Every rank returns the same Pipeline; rank 0 compares it with its own unsharded solve and with the
+    reference build's record of the matrix, outside the timed region."""
+    import hashlib
+
+    import torch
+
+    from da4ml_amd import _binary as hip
+    from da4ml_amd import multi_gpu as mg
+
+    rank, world, local, device = mg.init()
+    assert world == args.gpus or world == 1, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    if hip.device_count() < 1:
+        raise SystemExit('bench.py needs a HIP device (no CPU fallback)')
+    hip.set_device(local % hip.device_count())
+    n_in, n_out, _, opts = WORKLOADS[args.workload]
+    k = make_batch(n_in, n_out, 1, 0)[0]
+    column = args.workload.endswith('column_sharded')
+    on_gpus = device.type == 'cuda'
+    if column and world == 1:  # the sharded phases and their collectives also with a single rank: what every rank pays before any xGMI latency
+        os.environ['DA4ML_SHARD_FORCE'] = '1'
+        os.environ['DA4ML_SHARD_FORCE_COMM'] = '1'
+    transport = 'rccl' if on_gpus else 'callback'  # (gloo ranks of the CPU tests: torch.distributed called back from the library)
+
+    def step():
+        if column:
+            return mg.solve_column_sharded(k, transport=transport, return_stats=True, **opts)
+        return mg.solve_candidates_sharded(k), {}
+
+    def sync():
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        mg.barrier()
+
+    for _ in range(args.warmup):  # (communicator set-up, arena growth)
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pipe, stats = step()
+    sync()
+    elapsed = mg.max_over_ranks(time.perf_counter() - t0, device if on_gpus else None)
+    exchanged = hip.shard_exchanged_elements() if column else 0
+    mg.shutdown()
+    if rank != 0:
+        return
+    check = {'kernel_reproduced': bool(np.array_equal(pipe.kernel, k)), 'cost': float(pipe.cost), 'adders': int(pipe.n_adders)}
+    if not args.no_verify:
+        os.environ.pop('DA4ML_SHARD_FORCE', None)
+        os.environ.pop('DA4ML_SHARD_FORCE_COMM', None)
+        check['equals_unsharded_solve_on_rank0'] = bool(pipe == hip.solve(k, **opts))
+        rec_path = ROOT / 'tests' / 'golden' / ('large_chain_golden.json' if opts else 'large_default_golden.json')
+        key = f'{n_in}x{n_out}_seed0_' + ('single_chain' if opts else 'default')
+        recs = json.loads(rec_path.read_text()) if rec_path.exists() else {}
+        gold = recs.get(key + '_ref') or recs.get(key)
+        if gold:
+            dump = json.loads(json.dumps(pipe, default=lambda o: o.to_dict()))
+            check['digest_matches_record'] = hashlib.sha256(json.dumps(dump, separators=(',', ':')).encode()).hexdigest() == gold['sha256']
+            check['record_from'] = gold.get('oracle', 'oracle/liboracle.so')
+    per = elapsed / args.steps
+    line = {'metric': f'CMVM solves/sec, {n_in}x{n_out} int8 matrix' + (', one chain column-sharded over the GPUs' if column else ', default search with its candidates over the GPUs'),
+            'value': args.steps / elapsed, 'unit': 'solves/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * per,
+            'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'u32', 'data': 'synthetic',
+            'config': {'workload': args.workload, 'matrix': f'{n_in}x{n_out} int8 (default_rng(0).integers(-128,128))', 'solve_options': opts,
+                       'parallelism': (f'{world} x column shard of one greedy chain, pair table replicated, two all-reduce(sum) per greedy step over '
+                                       + ('RCCL (library transport, stream-ordered)' if on_gpus else 'the process group (callback transport)')) if column
+                                      else f'{world} x candidate shard (candidate i on rank i mod {world}), one all-reduce(MIN) and one broadcast per solve'},
+            'check': check}  # fmt: skip
+    if column:
+        gs = max(int(stats.get('greedy_steps', 0)), 1)
+        line['engine'] = {'greedy_steps': int(stats.get('greedy_steps', 0)), 'us_per_greedy_step': 1e6 * per / gs, 'allreduce_calls_per_solve': int(stats.get('allreduce_calls', 0)),
+                          'exchanged_bytes_per_greedy_step_and_rank': 4.0 * exchanged / gs, 'transport': transport,
+                          'note': 'latency-bound by construction: two collectives and one host synchronisation per greedy step (DESIGN.md section 7); the layout that scales is the instance shard of the default workload'}
+    print(json.dumps(line), flush=True)
+
+
 # ------------------------------------------------------------------------------------------------ main
 def selftest_launcher():
     """CPU-runnable check of the rank launcher and the collectives bench.py uses (no GPU work): every rank joins the group
@@ -400,6 +491,8 @@ def main():
         return selftest_launcher()
     if args.workload == 'c5_model_batch':
         return run_c5(args)
+    if args.workload.endswith(('column_sharded', 'candidate_sharded')):
+        return run_c4(args)
 
     import torch
 

@@ -97,8 +97,9 @@ def lib():
     L.da_rccl_unique_id.argtypes = [C.c_char_p]
     L.da_rccl_shutdown.restype = C.c_int
     L.da_rccl_shutdown.argtypes = []
-    L.da_shard_exchanged_elements.restype = C.c_int64
-    L.da_shard_exchanged_elements.argtypes = []
+    if hasattr(L, 'da_shard_exchanged_elements'):  # (libraries of earlier revisions loaded through DA4ML_HIP_LIB for A/B timing lack it; __graft_entry__.build() and tests/test_abi.py check the product's exports)
+        L.da_shard_exchanged_elements.restype = C.c_int64
+        L.da_shard_exchanged_elements.argtypes = []
     L.da_solve_sharded_rccl.restype = C.c_void_p
     L.da_solve_sharded_rccl.argtypes = [_f32p, C.c_int64, C.c_int64, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                         C.c_int, C.c_int, C.c_char_p, _i64p]

@@ -523,7 +523,6 @@ __device__ int table_claim(const Ctx &c, unsigned long long key, uint32_t h) {
             int ok = 0;
             if (lane == l) {
                 ok = atomicCAS(gen(&c.hkey[s]), kk, key) == kk;
-                if (ok && kk == KEY_EMPTY) atomicAdd(&c.g->n_used, 1u);
             }
             ok = __shfl(ok, l);
             if (ok) return (int)((b0 + w * WAVE + l) & c.cmask);
@@ -576,8 +575,12 @@ __device__ __forceinline__ DA_GLOBAL uint8_t *hidx_ptr(const Ctx &c) { return re
 // Store a complete block.  cnt_of(k) gives the count of key k; returns false when the table is full.
 // Precondition: at least one count >= 2 (checked by the caller), key absent.  ra / rb: intervals of rows lo / hi.
 // `w_out` (optional): the bound word of the new block's best entry, 0 when none is selectable (wave-uniform).
+// `tally`: count the new block in the chain's n_live here, with a device atomic.  k_iter_update passes false and adds its creations and deletions
+// ONCE PER WORKGROUP: in the first thousands of steps of a chain hundreds of blocks are created and deleted per step, and one atomic each on the
+// same line of the chain descriptor serialises in the L2 at ~12 ns apiece -- behind which every later load of the issuing wave waits (vmcnt is
+// in-order): measured in round 6, k_iter_update of steps 0 - 2000 took 24.8 us for one chain where the late steps take 6.7.
 template <class CntFn>
-__device__ bool table_insert(const Ctx &c, uint32_t lo, uint32_t hi, const RowInfo &ra, const RowInfo &rb, CntFn cnt_of, unsigned long long *w_out = nullptr) {
+__device__ bool table_insert(const Ctx &c, uint32_t lo, uint32_t hi, const RowInfo &ra, const RowInfo &rb, CntFn cnt_of, unsigned long long *w_out = nullptr, bool tally = true) {
     int lane = lane_id();
     unsigned long long key = pack_pair(lo, hi);
     int slot = table_claim(c, key, hash_pair(lo, hi));
@@ -608,7 +611,7 @@ __device__ bool table_insert(const Ctx &c, uint32_t lo, uint32_t hi, const RowIn
             group_note(c, slot, 0ull, bound_word(rank, tie_word(lo, hi, (int)idx)));
             fold_entry(c, rank, tie_word(lo, hi, (int)idx));
         }
-        atomicAdd(&c.g->n_live, 1u);  // no return value: fire-and-forget (the peak is sampled by k_iter_select)
+        if (tally) atomicAdd(&c.g->n_live, 1u);  // no return value: fire-and-forget (the peak is sampled by the selection)
     }
     return true;
 }
@@ -618,12 +621,12 @@ __device__ bool table_insert(const Ctx &c, uint32_t lo, uint32_t hi, const RowIn
 __device__ __forceinline__ unsigned long long hdr_word(unsigned long long key, uint32_t rank, uint32_t idx) {
     return rank ? bound_word(rank, tie_word((uint32_t)key, (uint32_t)(key >> 32), (int)idx)) : 0ull;
 }
-__device__ __forceinline__ void block_commit(const Ctx &c, int slot, unsigned long long key, const BlkHdr &h, unsigned long long best, int alive) {
+__device__ __forceinline__ void block_commit(const Ctx &c, int slot, unsigned long long key, const BlkHdr &h, unsigned long long best, int alive, bool tally = true) {
     const unsigned long long w_old = hdr_word(key, h.rank, h.idx);
     if (!alive) {
         c.hrank[slot] = 0;
         c.hkey[slot] = c.tomb;
-        atomicSub(&c.g->n_live, 1u);
+        if (tally) atomicSub(&c.g->n_live, 1u);  // (see table_insert)
         if (h.rank) group_note(c, slot, w_old, 0ull);
         return;
     }
@@ -639,7 +642,7 @@ __device__ __forceinline__ void block_commit(const Ctx &c, int slot, unsigned lo
 // Re-evaluate a block after its counts changed (new_cnt(k, old) -> new count); deletes it when no count >= 2.
 // Returns the bound word of the block's best entry afterwards (0: deleted, or nothing selectable); wave-uniform.
 template <class CntFn>
-__device__ unsigned long long table_update(const Ctx &c, int slot, unsigned long long key, CntFn new_cnt) {
+__device__ unsigned long long table_update(const Ctx &c, int slot, unsigned long long key, CntFn new_cnt, bool tally = true, int *deleted = nullptr) {
     int lane = lane_id();
     const BlkHdr h = load_hdr(c, slot);
     DA_GLOBAL uint16_t *cnt = blk_cnt(c, slot);
@@ -656,7 +659,8 @@ __device__ unsigned long long table_update(const Ctx &c, int slot, unsigned long
     }
     best = wave_max_u64(best);
     alive = __any(alive);
-    if (lane == 0) block_commit(c, slot, key, h, best, alive);
+    if (lane == 0) block_commit(c, slot, key, h, best, alive, tally);
+    if (deleted) *deleted = !alive;
     return alive && (best >> 8) ? bound_word((uint32_t)(best >> 8), tie_word((uint32_t)key, (uint32_t)(key >> 32), (int)(best & 0xFF))) : 0ull;
 }
 
@@ -2401,7 +2405,7 @@ template <class Cell> __device__ __forceinline__ void copy_handoff(const UpdStep
 // partner, `rnew` the record of the new row.
 template <class Cell>
 __device__ __forceinline__ void update_partners(ChainDev *g, const UpdStep<Cell> &u, const UpdLds<Cell> &s, int first, int stride, int limit, unsigned long long ref_next,
-                                                const RowInfo &rnew, unsigned int &found, unsigned int &inserts) {
+                                                const RowInfo &rnew, unsigned int &found, unsigned int &inserts, unsigned int &deletes) {
     using F = RowFmt<Cell>;
     using Entry = typename F::Entry;
     constexpr int QCW = sizeof(Cell) == 4 ? 2 : 4;  // count words per lane: narrow layout Kpad / 2 <= 24 words, wide <= 60
@@ -2519,7 +2523,8 @@ __device__ __forceinline__ void update_partners(ChainDev *g, const UpdStep<Cell>
             }
             best = row_max_u64(best);  // all lanes take part (the DPP source lanes must be active); lane 15 of the row holds the result
             const bool any_alive = (((uint32_t)(__ballot(alive != 0) >> qsh) & 0xFFFFu) != 0);
-            if (has && l == QG - 1) block_commit(c, slot, key, BlkHdr{ov, dl, (uint32_t)hd.z, (uint32_t)hd.w}, best, any_alive);
+            if (has && l == QG - 1) block_commit(c, slot, key, BlkHdr{ov, dl, (uint32_t)hd.z, (uint32_t)hd.w}, best, any_alive, false);
+            deletes += (unsigned)__popcll(__ballot(has && l == QG - 1 && !any_alive));  // (wave-uniform: the blocks this pass deleted, tallied once per workgroup)
         };
         apply(sA, keyA, hdA, wA, dA);
         apply(sB, keyB, hdB, wB, dB);
@@ -2539,7 +2544,9 @@ __device__ __forceinline__ void update_partners(ChainDev *g, const UpdStep<Cell>
                     const uint32_t lo = min(A, rpr), hi = max(A, rpr);
                     const int slot = table_find_from(c, pack_pair(lo, hi), hash_pair(lo, hi), 1);
                     if (slot >= 0) {
-                        table_update(c, slot, pack_pair(lo, hi), [&](int k, uint32_t old) { return old - rdA[k]; });
+                        int gone = 0;
+                        table_update(c, slot, pack_pair(lo, hi), [&](int k, uint32_t old) { return old - rdA[k]; }, false, &gone);
+                        deletes += (unsigned)gone;
                         ++found;
                     }
                 }
@@ -2547,12 +2554,14 @@ __device__ __forceinline__ void update_partners(ChainDev *g, const UpdStep<Cell>
                     const uint32_t lo = min(B, rpr), hi = max(B, rpr);
                     const int slot = table_find_from(c, pack_pair(lo, hi), hash_pair(lo, hi), 1);
                     if (slot >= 0) {
-                        table_update(c, slot, pack_pair(lo, hi), [&](int k, uint32_t old) { return old - rdB[k]; });
+                        int gone = 0;
+                        table_update(c, slot, pack_pair(lo, hi), [&](int k, uint32_t old) { return old - rdB[k]; }, false, &gone);
+                        deletes += (unsigned)gone;
                         ++found;
                     }
                 }
                 if (rnewb) {
-                    table_insert(c, rpr, Nw, load_row(c.rows, rpr), rnew, [&](int k) { return rcN[k]; });
+                    table_insert(c, rpr, Nw, load_row(c.rows, rpr), rnew, [&](int k) { return rcN[k]; }, nullptr, false);
                     ++inserts;
                 }
             }
@@ -2653,23 +2662,25 @@ __device__ __forceinline__ void update_body(ChainDev *gq, bool in_range, int blo
     // hand-off of k_iter_select (they used to wait behind the hand-off barrier: two more dependent round trips)
     const unsigned long long ref0 = gw * QN + (lane >> 4) < u.n_partners ? u.plist[gw * QN + (lane >> 4)] : 0ull;
     const RowInfo rnew = load_row(u.c.rows, u.Nw);
-    __shared__ unsigned int s_stat[2];
-    if (tid < 2) s_stat[tid] = 0;
+    __shared__ unsigned int s_stat[3];
+    if (tid < 3) s_stat[tid] = 0;
     copy_handoff<Cell>(u, s, tid, NTHR);  // one pass, one barrier (the column map arrives ready-made)
     __syncthreads();
-    unsigned int found = 0, inserts = 0;
-    update_partners<Cell>(gq, u, s, gw * QN, total_waves * QN, u.n_partners, ref0, rnew, found, inserts);
+    unsigned int found = 0, inserts = 0, deletes = 0;
+    update_partners<Cell>(gq, u, s, gw * QN, total_waves * QN, u.n_partners, ref0, rnew, found, inserts, deletes);
     // statistics: summed per block in LDS, then ONE pair of device atomics per block.  (Four atomics per wave on one line
     // of the chain descriptor -- 640 per chain and launch, from all XCDs -- serialise at ~12 ns each and every launch had
     // to wait for them; the partner / cell counts are added by k_iter_select, which knows them without counting.)
-    if (lane == 0 && (found | inserts)) {
+    if (lane == 0 && (found | inserts | deletes)) {
         if (found) atomicAdd(&s_stat[0], found);
         if (inserts) atomicAdd(&s_stat[1], inserts);
+        if (deletes) atomicAdd(&s_stat[2], deletes);
     }
     __syncthreads();
     if (tid == 0) {
         if (s_stat[0]) atomicAdd(&gq->st_found, (unsigned long long)s_stat[0]);
         if (s_stat[1]) atomicAdd(&gq->st_inserts, (unsigned long long)s_stat[1]);
+        if (s_stat[1] != s_stat[2]) atomicAdd(&gq->n_live, s_stat[1] - s_stat[2]);  // blocks created less blocks deleted by this workgroup (modulo 2^32)
     }
 }
 template <class Cell>
@@ -2729,7 +2740,10 @@ template <class Cell> __global__ void __launch_bounds__(256) k_cs_init_table(Cha
 }
 
 // one block: union of the partner rows of all ranks (summed flag fields != 0), ascending row ids -> cs_uni, cs_nuni
-__global__ void __launch_bounds__(1024) k_cs_union(ChainDev *g) {
+// `report` (pinned host memory, mapped): {sequence number of the step, size of the union, the three summed status words} -- what the host needs
+// between the two exchanges of a step, written by the device itself: no device-to-host copies and no stream synchronisation per step
+// (each of the two small copies was a DMA operation of ~10 us; round 6).  The sequence number is stored last, behind a system-scope fence.
+__global__ void __launch_bounds__(1024) k_cs_union(ChainDev *g, volatile int *report, int seq, int flag_words) {
     __shared__ int s_part[16], s_base[17];
     const int tid = threadIdx.x, lane = lane_id(), wid = wave_id();
     const int n_rows = (int)g->Nw;  // rows that existed before this step's new row
@@ -2752,6 +2766,14 @@ __global__ void __launch_bounds__(1024) k_cs_union(ChainDev *g) {
         }
         s_base[16] = run;
         g->cs_nuni = run;
+        if (report) {
+            report[1] = run;
+            report[2] = g->cs_flags[flag_words];
+            report[3] = g->cs_flags[flag_words + 1];
+            report[4] = g->cs_flags[flag_words + 2];
+            __threadfence_system();
+            report[0] = seq;
+        }
     }
     __syncthreads();
     int at = s_base[wid] + inc - mine;
@@ -3948,6 +3970,8 @@ class HipShardEngine : public ShardEngine {
             }
         }
         push();
+        report_ = static_cast<volatile int *>(report_buf_.get(64));
+        for (int q = 0; q < 5; ++q) report_[q] = 0;
         d_done_ = static_cast<unsigned int *>(done_buf_.get(sizeof(unsigned int)));  // (a member buffer: released also when a later check of this constructor throws)
         HIP_CHECK(hipMemsetAsync(d_done_, 0, sizeof(unsigned int), st_));
         dim3 colgrid((n_loc_ + 3) / 4, 1);
@@ -4011,11 +4035,25 @@ class HipShardEngine : public ShardEngine {
         fcount = fw_ + SHARD_TRAILER;
     }
     int32_t *partial(int64_t &scount, int32_t status[SHARD_TRAILER]) override {
-        HIP_CHECK(hipMemcpyAsync(trailer_, d_.cs_flags + fw_, sizeof trailer_, hipMemcpyDeviceToHost, st_));  // the summed status, with the union's size
-        int nuni = 0;
-        hipLaunchKernelGGL(k_cs_union, dim3(1), dim3(1024), 0, st_, dd_);  // (on summed flags that are all zero when every rank has stopped: an empty union)
-        HIP_CHECK(hipMemcpyAsync(&nuni, &dd_->cs_nuni, sizeof(int), hipMemcpyDeviceToHost, st_));
-        sync();
+        // the summed status and the size of the union come from the device itself: k_cs_union writes them into pinned host memory, the
+        // host waits for the step's sequence number -- no copies, no stream synchronisation (the launch is checked; a device fault
+        // surfaces through the bounded wait's fall-back synchronisation)
+        const int seq = ++report_seq_;
+        hipLaunchKernelGGL(k_cs_union, dim3(1), dim3(1024), 0, st_, dd_, report_, seq, (int)fw_);  // (on summed flags that are all zero when every rank has stopped: an empty union)
+        HIP_CHECK(hipGetLastError());
+        {
+            unsigned polls = 0, tries = 0;
+            while (__atomic_load_n(&report_[0], __ATOMIC_ACQUIRE) != seq) {
+                if (++tries > (1u << 16)) {  // (seconds of polling, most of it asleep) let the runtime wait -- and report a fault, if that is what it is
+                    sync();
+                    if (__atomic_load_n(&report_[0], __ATOMIC_ACQUIRE) != seq) throw std::runtime_error("column-sharded chain: the device did not report the step's status");
+                    break;
+                }
+                spin_wait_step(polls);
+            }
+        }
+        const int nuni = report_[1];
+        for (int q = 0; q < SHARD_TRAILER; ++q) trailer_[q] = report_[2 + q];
         for (int q = 0; q < SHARD_TRAILER; ++q) status[q] = trailer_[q];
         scount = 0;
         if (status[0] != 0) {
@@ -4110,6 +4148,9 @@ class HipShardEngine : public ShardEngine {
     DeviceBuffer io_, desc_, arena_;
     DeviceBuffer done_buf_;
     unsigned int *d_done_ = nullptr;
+    PinnedBuffer report_buf_;          // {sequence number, union size, status[3]} written by k_cs_union (mapped pinned memory)
+    volatile int *report_ = nullptr;
+    int report_seq_ = 0;
     long long n_pairs_ = 0;
     int nuni_ = 0;
     size_t sel_lds_ = 0, part_lds_ = 0;

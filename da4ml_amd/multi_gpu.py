@@ -308,7 +308,7 @@ class _DeviceView:
         self.__cuda_array_interface__ = {'shape': (int(count),), 'typestr': '<i4', 'data': (int(ptr), False), 'version': 2}
 
 
-def make_allreduce_callback(device, abort=None):
+def make_allreduce_callback(device, abort=None, world=None):
     """C callback ``void(ctx, buf, count, on_device)`` = in-place all-reduce(sum) of int32 over the process group: the one
     collective a column-sharded chain uses (``csrc/cmvm_shard.h``).  RCCL (backend ``nccl``) works on device memory
     directly; with ``gloo`` (CPU tests, or several ranks sharing one GPU) device buffers are staged through the host.
@@ -327,6 +327,10 @@ def make_allreduce_callback(device, abort=None):
 
     def allreduce(ctx, buf, count, on_device):
         try:
+            if world == 1 and not dist.is_initialized():
+                return  # a single rank without a process group (the forced exchanges of a one-rank measurement): the sum over one rank
+            if on_device and not torch.cuda.is_available() and os.environ.get('HIPEMU_DEVICES'):
+                on_device = 0  # the emulated device of the CPU tests (tests/emu): its "device" memory is host memory
             if on_device:
                 t = torch.as_tensor(_DeviceView(buf, count), device=device)
                 if nccl:
@@ -432,7 +436,7 @@ def solve_column_sharded(kernel, method0: str = 'wmc', method1: str = 'auto', ha
         from . import _binary
 
         abort = _binary.comm_abort
-    cb, errors = make_allreduce_callback(device, abort)
+    cb, errors = make_allreduce_callback(device, abort, world)
     try:
         pipe, stats = sharded_solver(kernel, method0=method0, method1=method1, hard_dc=hard_dc, decompose_dc=decompose_dc, qintervals=qintervals,
                                      latencies=latencies, adder_size=adder_size, carry_size=carry_size, search_all_decompose_dc=search_all_decompose_dc,

@@ -175,6 +175,7 @@ inline unsigned __builtin_amdgcn_s_getreg(int) { return 0u; }  // HW_REG_XCC_ID:
 #define __builtin_amdgcn_fence(order, scope) ((void)0)         // blocks run one after the other: every store is visible
 inline void __syncthreads() { hipemu::block_barrier(); }
 inline void __threadfence() {}
+inline void __threadfence_system() {}
 inline void __threadfence_block() {}
 
 // ------------------------------------------------------------------------------------------------ scalar device functions

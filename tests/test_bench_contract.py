@@ -147,6 +147,29 @@ def test_bench_runs_end_to_end_at_eight_ranks_on_the_emulated_device():
     assert line['engine']['picks_known_a_step_ahead'] > 0.5
 
 
+@pytest.mark.parametrize('workload,world', [('t0_plumbing_12x10_column_sharded', 8), ('t0_plumbing_12x10_column_sharded', 1), ('t0_plumbing_12x10_candidate_sharded', 8)])
+def test_bench_c4_layouts_on_the_emulated_device(workload, world):
+    """BASELINE configs[3] as bench workloads: ONE solve per step over the ranks, strong scaling -- the column-sharded chain
+    (every rank its slice of the columns, two all-reduces per greedy step; with one rank the sharded phases and collectives forced) and the
+    candidate-sharded default search -- at the config's own 8 ranks, kernels on the emulated device, exchanges over gloo.  Rank 0 checks the
+    result against its own unsharded solve.  (What this cannot show: RCCL with more than one rank.)"""
+    import os
+
+    emu = ROOT / 'tests' / 'emu' / 'libda4ml_emu.so'
+    if not emu.exists():
+        pytest.skip('tests/emu/libda4ml_emu.so is not built')
+    env = dict(os.environ, DA4ML_HIP_LIB=str(emu), HIPEMU_DEVICES='8', DA4ML_HIP_UPD_BLOCKS='8')
+    r = subprocess.run([sys.executable, str(ROOT / 'bench.py'), '--gpus', str(world), '--steps', '1', '--warmup', '1', '--workload', workload], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+    assert line['n_gpus'] == world and line['scaling'] == 'strong' and line['unit'] == 'solves/s' and line['config']['workload'] == workload
+    assert abs(line['value'] - line['steps'] / (line['ms_per_step'] * 1e-3 * line['steps'])) < 1e-6 * line['value']  # one solve per step, whole job
+    assert line['check']['kernel_reproduced'] is True and line['check']['equals_unsharded_solve_on_rank0'] is True
+    if workload.endswith('column_sharded'):
+        e = line['engine']
+        assert e['greedy_steps'] > 0 and e['allreduce_calls_per_solve'] >= 2 * e['greedy_steps'] and e['exchanged_bytes_per_greedy_step_and_rank'] > 0
+
+
 def test_bench_refuses_more_ranks_than_gpus():
     from da4ml_amd import _binary
 
