@@ -8,7 +8,7 @@
 //   k_init_pairs     all-pairs enumeration / FreqMap::initialize   state_opr.cc:117-143, types.hh:73-100
 //   k_iter_select2   idx_mc / idx_mc_dc / idx_wmc / idx_wmc_dc + update_expr   indexers.cc:6-90, state_opr.cc:227-283
 //                    (two workgroups per chain: the search finds the next pick one step AHEAD, beside the substitution of the current one;
-//                    k_iter_select: the one-block form of rounds 1-4, kept for the column-sharded chain)
+//                    ordinary and column-sharded chains alike -- the one-block k_iter_select of rounds 1-5 is gone)
 //   k_iter_update    update_stats (purge + regenerate) as an exact incremental update   state_opr.cc:285-345
 //   k_extract        digit gather of to_solution             cmvm_core.cc:103-113
 //   k_col_dist       stage-1 CSD Hamming distances           mat_decompose.cc:75-93
@@ -82,7 +82,6 @@ constexpr uint64_t KEY_EMPTY = ~0ull;
 constexpr uint64_t KEY_TOMB = ~0ull - 1;
 constexpr uint64_t KEY_TOMB_LO = KEY_TOMB - 3;  // keys >= KEY_TOMB_LO and != KEY_EMPTY are tombstones
 constexpr int WAVE = 64;
-constexpr int SEL_THREADS = 1024;  // k_iter_select block (16 waves)
 constexpr int UPD_THREADS = 256;   // k_iter_update block
 constexpr int UPD_WAVES = UPD_THREADS / WAVE;
 #ifndef DA_MAX_GROUPS
@@ -91,10 +90,10 @@ constexpr int UPD_WAVES = UPD_THREADS / WAVE;
 #endif
 constexpr int MAX_GROUPS = DA_MAX_GROUPS;
 #ifndef DA_IDS_LDS
-#define DA_IDS_LDS 2048  // partner row ids of a step staged in LDS by k_iter_select (tests/emu builds with 16: its problems are small, both paths run)
+#define DA_IDS_LDS 2048  // partner row ids of a step staged in LDS by the substitution block (tests/emu builds with 16: its problems are small, both paths run)
 #endif
 
-// Per-phase shader-clock timers of k_iter_select / k_iter_update (tests/gpu_profile.py).  They cost SGPRs, VALU time and --
+// Per-phase shader-clock timers of k_iter_select2 / k_iter_update (tests/gpu_profile.py).  They cost SGPRs, VALU time and --
 // every s_memtime is followed by a wait for all outstanding LDS and scalar operations -- latency on the dependent chain of
 // the select kernel (eight of them per launch), so they are compiled in only with -DDA_PHASE_TIMERS (make PHASE_TIMERS=1).
 #ifdef DA_PHASE_TIMERS
@@ -286,8 +285,9 @@ struct ChainDev {
     void *mA, *mB;
     unsigned long long *plist;
     int m, n_partners;
-    int claim_words;   // words of the LDS claim bitmap in k_iter_select (0: use the global stamp array)
+    int claim_words;   // words of the optional LDS area in which the substitution block combines the row bitmaps of a young chain (0: none)
     uint32_t A, B, Nw;
+    int pk_shift, pk_sub;  // the pick's key (shift, sub): the consumed B-role digits are the A-role ones moved by `shift`, signs flipped when `sub` (k_iter_update)
     // progress
     int n_rows, iter, done, error, unknown_hit;
     unsigned int n_live, n_used, live_peak;
@@ -347,7 +347,7 @@ __device__ __forceinline__ int wave_id() { return threadIdx.x / WAVE; }
 
 // Wave-wide reductions on the DPP path (row shifts inside the 16-lane rows, then the two row broadcasts of gfx9): six
 // VALU operations per 32-bit word and no LDS round trip.  (The __shfl_xor butterflies they replace go through
-// ds_bpermute -- about 900 cycles per 64-bit reduction, which dominated the arg-max loop of k_iter_select.)
+// ds_bpermute -- about 900 cycles per 64-bit reduction, which dominated the arg-max loop of the selection.)
 template <int CTRL, int ROW_MASK> __device__ __forceinline__ uint32_t dpp_u32(uint32_t identity, uint32_t v) {
     return (uint32_t)__builtin_amdgcn_update_dpp((int)identity, (int)v, CTRL, ROW_MASK, 0xF, false);
 }
@@ -442,7 +442,7 @@ struct Ctx {
     CandEntry *cl;             // entry they are all the next selection has to compare
 };
 
-// launch_id: 2 * iteration for k_iter_select, 2 * iteration + 1 for k_iter_update (only the low two bits are used)
+// launch_id: 2 * iteration for k_iter_select2, 2 * iteration + 1 for k_iter_update (only the low two bits are used)
 __device__ __forceinline__ Ctx make_ctx_raw(ChainDev *g, int launch_id) {
     Ctx c;
     c.tomb = KEY_TOMB - (unsigned long long)(launch_id & 3);
@@ -835,582 +835,6 @@ template <class Cell> __global__ void __launch_bounds__(256) k_init_pairs(ChainD
     table_insert(c, lo, hi, load_row(c.rows, lo), load_row(c.rows, hi), [&](int k) { return cnt[k]; });
 }
 
-// ------------------------------------------------------------------------------------------------ k_iter_select (column-sharded chains)
-// The one-block selection of rounds 1-4, kept for the column-sharded chain (cmvm_shard.h; ordinary chains use k_iter_select2 below): the chain
-// holds a slice of the columns and a replica of the pair table.  One block per chain: (1) arg-max of the pair table via lazily tightened group
-// upper bounds, (2) substitution of the chosen pair in the lists of rows A and B (the new row's list is their match set), (3) exact recount of
-// the pairs among the modified rows {A, B, new} -- only PARTIAL here: they go to the head of the exchange slab --, (4) one flag per row that
-// shares a substituted column (read from the column lists) instead of a partner list.  Returns 1 when the chain is (or just became) finished.
-template <class Cell, bool SHARDED = true> __device__ __forceinline__ int select_body(ChainDev *g, unsigned int *n_done) {
-    static_assert(SHARDED, "the one-block selection serves the column-sharded chain only (cmvm_shard.h); ordinary chains: k_iter_select2");
-    using O = CellOps<Cell>;
-    using F = RowFmt<Cell>;
-    using Entry = typename F::Entry;
-    // ---- ONE scalar round trip: every descriptor field the block needs, pinned before the first branch (pin_sgpr; left
-    // alone the compiler sinks each load behind the branch that first needs it -- ten dependent round trips in this kernel)
-    int was_done = g->done, had_error = g->error, iter = g->iter, n_groups = g->n_groups, lcap = g->lcap, claim_words = g->claim_words;
-    int n_rows0 = g->n_rows, rcap = g->rcap, cbw = g->cb_words, adder_size = g->adder_size, carry_size = g->carry_size;
-    uint32_t offN = g->rl_used, rl_cap = g->rl_cap, n_live0 = g->n_live, live_peak0 = g->live_peak;
-    const uint32_t *step_mant = g->step_mant;
-    const float *step_tab = g->step_tab;
-    int n_step_mant = g->n_step_mant;
-    Ctx c = make_ctx_raw(g, 2 * iter);
-    DA_GLOBAL int *collen = (DA_GLOBAL int *)g->collen;
-    DA_GLOBAL unsigned long long *gtie_arr = (DA_GLOBAL unsigned long long *)g->gtie;
-    DA_GLOBAL da_u2 *rowoff = (DA_GLOBAL da_u2 *)g->rowoff;
-    DA_GLOBAL Entry *rl = (DA_GLOBAL Entry *)g->rlist;
-    DA_GLOBAL Cell *mA = (DA_GLOBAL Cell *)g->mA, *mB = (DA_GLOBAL Cell *)g->mB;
-    DA_GLOBAL int *mcol = (DA_GLOBAL int *)g->mcol;
-    DA_GLOBAL unsigned long long *collist = (DA_GLOBAL unsigned long long *)g->collist;
-    DA_GLOBAL uint16_t *cmap = (DA_GLOBAL uint16_t *)g->cmap;
-    DA_GLOBAL uint32_t *colbits = (DA_GLOBAL uint32_t *)g->colbits;
-    DA_GLOBAL uint32_t *pl_ids = (DA_GLOBAL uint32_t *)g->pl_ids;
-    DA_GLOBAL unsigned long long *plist = (DA_GLOBAL unsigned long long *)g->plist;
-    DA_GLOBAL da_i4 *picks = (DA_GLOBAL da_i4 *)g->picks;
-    DA_GLOBAL int32_t *cs_slab = (DA_GLOBAL int32_t *)g->cs_slab, *cs_flags = (DA_GLOBAL int32_t *)g->cs_flags;
-    pin_sgpr(was_done, had_error, iter, n_groups, lcap, claim_words, n_rows0, rcap, cbw, adder_size, carry_size, offN, rl_cap, n_live0, live_peak0, step_mant, step_tab, n_step_mant);
-    pin_sgpr(c.n_out, c.n_bits, c.K, c.Kpad, c.method, c.gs_log2, c.pb_log2, c.cmask, c.windows, c.hkey, c.hrank, c.hblk, c.ub, c.glow, c.gdirty, c.rows);
-    pin_sgpr(collen, gtie_arr, rowoff, rl, mA, mB, mcol, collist, cmap, colbits, pl_ids, plist, picks);
-    if constexpr (SHARDED) pin_sgpr(cs_slab, cs_flags);
-    ctx_finish(c);
-    const int n_out = c.n_out, Kpad = c.Kpad, nb = c.n_bits;
-    // column-sharded chain: a rank whose chain stops (finished, or an error) still hands out the flag buffer of the step -- zero
-    // flags and the status trailer {1, capacity error?, other error?} (cmvm_shard.h) -- written here, on the device: the host does
-    // not read the descriptor back between the steps
-    auto shard_stop = [&](int err) {
-        if constexpr (SHARDED) {
-            const int fw = (n_rows0 + 3) / 4;  // rows before this step
-            for (int w = threadIdx.x; w < fw; w += SEL_THREADS) cs_flags[w] = 0;
-            if (threadIdx.x == 0) {
-                const bool cap = err == E_ROW_CAPACITY || err == E_TABLE_CAPACITY || err == E_LIST_CAPACITY;
-                cs_flags[fw] = 1;
-                cs_flags[fw + 1] = cap ? 1 : 0;
-                cs_flags[fw + 2] = err != E_OK && !cap ? 1 : 0;
-            }
-        }
-    };
-    if (was_done) {
-        shard_stop(had_error);
-        return 1;
-    }
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // dynamic LDS carve: B's list | special-pair counters | per-matched-column scratch | column -> position in B | claim bitmap
-    Entry *s_bent = reinterpret_cast<Entry *>(smem);                                  // [n_out] entries of row B (updated in place)
-    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_bent + n_out);                  // [6][Kpad]
-    int *s_len = reinterpret_cast<int *>(s_cnt + 6 * Kpad);                           // [n_out + 1] list lengths -> offsets
-    int *s_col = s_len + n_out + 1;                                                   // [n_out] matched columns
-    int *s_bpos = s_col + n_out;                                                      // [n_out] 1 + position of a column in B's list, 0 = absent
-    int *s_clen = s_bpos + n_out;                                                     // [n_out] list length of every column (fetched while the arg-max runs)
-    int *s_cm = s_clen + n_out;                                                       // [n_out] 1 + index among the matched columns, 0 = not matched
-    uint32_t *s_bits = reinterpret_cast<uint32_t *>(s_cm + n_out);                   // [claim_words] rows already claimed (if it fits)
-    constexpr int NW = SEL_THREADS / WAVE;
-    __shared__ unsigned long long s_red_tie[NW], s_floor0, s_floor;
-    __shared__ uint32_t s_red_rank[NW];
-    __shared__ int s_np, s_part[NW];
-    __shared__ unsigned int s_matches;
-    __shared__ RowInfo s_new, s_ra, s_rb;
-    __shared__ da_u2 s_refA, s_refB;
-    __shared__ Log2Table s_log2;  // copy of c_log2 (fetched with the bounds; the latency model's look-up then stays off the memory path)
-
-    const int tid = threadIdx.x, lane = lane_id(), wid = wave_id();
-    const int gs = 1 << c.gs_log2;
-
-    SEL_TIMER_DECL
-    SEL_TIMER_MARK(0)
-    if (had_error != E_OK) {  // a capacity error poisons the chain: stop it (the host retries with a larger arena)
-        if (tid == 0) {
-            g->done = 1;
-            g->n_partners = 0;
-            atomicAdd(n_done, 1u);
-        }
-        shard_stop(had_error);
-        return 1;
-    }
-
-    // ---------------- (1) selection.  A group is CLEAN when no block in it changed its best (rank, key) since the
-    // group was last verified; then its bound word and stored tie word are exact.  The best clean bound is a floor of
-    // the answer.  Wave w owns the groups [w * GPW, (w+1) * GPW); every lane keeps the bounds and states of its (up to
-    // four) groups in registers, loaded coalesced from global memory, and the wave re-reads its highest dirty group
-    // while that group's (possibly stale) bound can still beat or tie the rising floor.
-    if (tid == 0) {
-        s_np = 0;
-        s_matches = 0;
-        s_floor0 = 0;
-    }
-    // ---- ONE vector round trip: the bounds and dirty flags of this lane's (up to four) groups and the list length of this
-    // thread's column leave together.  The loads are UNCONDITIONAL (index clamped to group / column 0) and every use comes
-    // after the last of them: behind an `in ? load : 0` the compiler waits for each load inside its own branch -- four
-    // serialised round trips for the bounds alone (ISA reading, round 2).
-    const int GPW = (n_groups + NW - 1) / NW;  // groups per wave, <= 4 * WAVE
-    unsigned long long ubr[4], gtr[4];
-    int dr[4];  // 0 clean on entry, 1 dirty, 2 verified in this call, 3 absent
-    {
-        // the list lengths of all columns: needed for the matched columns only, after the substitution -- fetched now, off
-        // the critical path, so that no dependent load is left there
-        const int clen0 = collen[tid < n_out ? tid : 0];
-        const bool want_log2 = (adder_size >= 0 || carry_size >= 0) && tid < (int)(sizeof(Log2Table) / 4);
-        const uint32_t l2w = want_log2 ? reinterpret_cast<const uint32_t *>(&c_log2)[tid] : 0u;
-        bool in[4];
-        uint32_t dv[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int q = wid * GPW + lane + u * WAVE;
-            in[u] = lane + u * WAVE < GPW && q < n_groups;
-            const int qc = in[u] ? q : 0;
-            ubr[u] = c.ub[qc];
-            dv[u] = c.gdirty[qc];
-            gtr[u] = gtie_arr[qc];  // the stored tie word (exact while the group is clean): with the bounds, not a round trip later
-            const unsigned long long gl = c.glow[qc];
-            if (ubr[u] != 0 && gl >= ubr[u]) dv[u] |= 2u;  // an entry that had reached the bound was lowered (group_note): not clean
-        }
-        if (tid < n_out) {
-            s_clen[tid] = clen0;
-            s_cm[tid] = 0;
-            s_bpos[tid] = 0;
-        }
-        if (want_log2) reinterpret_cast<uint32_t *>(&s_log2)[tid] = l2w;
-        for (int j = tid + SEL_THREADS; j < n_out; j += SEL_THREADS) {
-            s_clen[j] = collen[j];
-            s_cm[j] = 0;
-            s_bpos[j] = 0;
-        }
-        unsigned long long cl = 0;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            ubr[u] = in[u] ? ubr[u] : 0ull;
-            dr[u] = in[u] ? (dv[u] ? 1 : 0) : 3;
-            if (dr[u] == 0) cl = max(cl, ubr[u]);
-        }
-        __syncthreads();  // s_floor0 initialised
-        cl = wave_max_u64(cl);
-        if (lane == 0 && cl) atomicMax(&s_floor0, cl);
-    }
-    __syncthreads();
-    SEL_TIMER_MARK(1)
-    uint32_t best_rank, cand_rank;
-    unsigned long long best_tie, cand_tie;
-    RowInfo cand_ra, cand_rb;
-    da_u2 cand_refA, cand_refB;
-    {
-        const unsigned long long floor0 = s_floor0;
-        if (tid == 0) s_floor = floor0;
-        __syncthreads();
-        uint32_t wrank = 0;
-        unsigned long long wtie = 0;
-        unsigned int rescans = 0;
-        // groups that were clean on entry and tie the floor: their stored tie word (fetched with the bounds) decides
-        unsigned long long clean_tie = 0;
-        bool clean_any = false;
-        if (floor0) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (dr[u] == 0 && ubr[u] == floor0) {
-                    clean_tie = gtr[u] > clean_tie ? gtr[u] : clean_tie;
-                    clean_any = true;
-                }
-        }
-        while (true) {
-            // ONE group per wave and round: the wave's highest dirty group is re-read while its (possibly stale) bound still reaches the
-            // rising floor.  (Two groups per round keep two sets of loads in flight, but every wave that re-reads anything then issues the
-            // instruction stream of both -- ~1500 instructions per round, most of them predicated off.)
-            const unsigned long long fl = __hip_atomic_load(&s_floor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            unsigned long long top = 0;
-            int top_u = 0;
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (dr[u] == 1 && ubr[u] > top) {
-                    top = ubr[u];
-                    top_u = u;
-                }
-            const unsigned long long wtop = wave_max_u64(top);
-            if (wtop == 0 || wtop < fl) break;
-            const int owner = __ffsll((long long)__ballot(top == wtop)) - 1;
-            const int own_u = __builtin_amdgcn_readlane(top_u, owner);
-            const uint32_t grp = (uint32_t)(wid * GPW + owner + own_u * WAVE), base = grp * gs;
-            uint32_t rk[8], grank = 0;
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int o = lane + u * WAVE;
-                rk[u] = o < gs ? c.hrank[base + o] : 0u;
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) grank = max(grank, rk[u]);
-            for (int o = lane + 8 * WAVE; o < gs; o += WAVE) grank = max(grank, c.hrank[base + o]);
-            grank = wave_max_u32(grank);
-            unsigned long long kk[8], gt = 0;
-            uint32_t bi[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int o = lane + u * WAVE;
-                kk[u] = 0;
-                bi[u] = 0;
-                if (grank && o < gs && rk[u] == grank) {
-                    kk[u] = c.hkey[base + o];
-                    bi[u] = load_best_idx(c, base + o);
-                }
-            }
-            load_fence();
-#pragma unroll
-            for (int u = 0; u < 8; ++u) pin_vgpr(kk[u], bi[u]);
-            if (grank) {
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int o = lane + u * WAVE;
-                    if (o < gs && rk[u] == grank) {
-                        const unsigned long long tw = tie_word((uint32_t)kk[u], (uint32_t)(kk[u] >> 32), (int)bi[u]);
-                        gt = tw > gt ? tw : gt;
-                    }
-                }
-                for (int o = lane + 8 * WAVE; o < gs; o += WAVE)
-                    if (c.hrank[base + o] == grank) {
-                        const unsigned long long k2 = c.hkey[base + o];
-                        const unsigned long long tw = tie_word((uint32_t)k2, (uint32_t)(k2 >> 32), (int)load_best_idx(c, base + o));
-                        gt = tw > gt ? tw : gt;
-                    }
-            }
-            gt = wave_max_u64(gt);
-            const unsigned long long exact = grank ? bound_word(grank, gt) : 0ull;
-            if (lane == owner) {
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    if (u == own_u) {
-                        ubr[u] = exact;
-                        dr[u] = 2;
-                    }
-                c.ub[grp] = exact;
-                gtie_arr[grp] = gt;
-                c.gdirty[grp] = 0;
-                c.glow[grp] = 0;
-                if (exact) atomicMax(&s_floor, exact);
-            }
-            if (grank > wrank || (grank == wrank && gt > wtie)) {
-                wrank = grank;
-                wtie = gt;
-            }
-            ++rescans;
-            lds_fence();
-        }
-        if (floor0) {
-            const unsigned long long ct = wave_max_u64(clean_tie);
-            if (__any(clean_any)) {
-                const uint32_t r0 = (uint32_t)(floor0 >> 32);
-                if (r0 > wrank || (r0 == wrank && ct > wtie)) {
-                    wrank = r0;
-                    wtie = ct;
-                }
-            }
-        }
-        // Every wave fetches the list references and records of ITS candidate pair now (four broadcast loads, in flight
-        // across the reduction): the winner's are then already here -- one dependent round trip less than fetching them once
-        // the block knows the winner.
-        const uint32_t cA = wrank ? (uint32_t)((wtie >> 7) & 0xFFFFFFu) : 0u, cB = wrank ? (uint32_t)(wtie >> 31) : 0u;
-        cand_ra = load_row(c.rows, cA);
-        cand_rb = load_row(c.rows, cB);
-        cand_refA = rowoff[cA];
-        cand_refB = rowoff[cB];
-        cand_rank = wrank;
-        cand_tie = wtie;
-        if (lane == 0) {
-            s_red_rank[wid] = wrank;
-            s_red_tie[wid] = wtie;
-            if (rescans) atomicAdd(&g->st_rescans, (unsigned long long)rescans);
-        }
-        __syncthreads();
-        {  // the waves' results, one per lane: highest rank, then highest tie word among its holders.  Every wave reduces
-           // them itself (a dozen DPP steps): no broadcast through LDS, no second barrier.
-            const uint32_t r = lane < NW ? s_red_rank[lane] : 0u;
-            const unsigned long long t = lane < NW ? s_red_tie[lane] : 0ull;
-            best_rank = wave_max_u32(r);
-            best_tie = wave_max_u64(r == best_rank ? t : 0ull);
-        }
-    }
-    SEL_TIMER_MARK(2)
-    const uint32_t Nw = (uint32_t)n_rows0;
-    if (best_rank == 0 || (int)Nw >= rcap) {
-        if (tid == 0) {
-            if (best_rank != 0) g->error = E_ROW_CAPACITY;
-            g->done = 1;
-            g->n_partners = 0;
-            atomicAdd(n_done, 1u);
-        }
-        shard_stop(best_rank != 0 ? E_ROW_CAPACITY : E_OK);
-        return 1;
-    }
-    const uint32_t A = (uint32_t)((best_tie >> 7) & 0xFFFFFFu), B = (uint32_t)(best_tie >> 31);
-    const int idx = (int)(best_tie & 0x7F);
-    int shift, sub;
-    key_decode(idx, nb, shift, sub);
-    const bool same = A == B;
-
-    // ---------------- (2) new row record + substitution.  The list references and the records of rows A and B arrive from the
-    // wave that held the winner (fetched before the reduction, see above; thread 0 builds the new row from the records, the
-    // special-pair waves need them for new blocks); ONE round trip follows: this thread's entry of A and of B.  Thread 0
-    // builds the new row while those are in flight (it used to fetch the records after the references had arrived, then look
-    // up the latency model's table, then the live-block counters: five dependent round trips in wave 0 with fifteen waves
-    // waiting at the barrier).
-    if (cand_rank == best_rank && cand_tie == best_tie && lane == 0) {  // exactly one wave holds the winner (tie words are unique)
-        s_ra = cand_ra;
-        s_rb = cand_rb;
-        s_refA = cand_refA;
-        s_refB = cand_refB;
-    }
-    __syncthreads();
-    const RowInfo ra = s_ra, rb = s_rb;
-    const da_u2 refA = s_refA, refB = s_refB;
-    const int lenA = (int)refA.y, lenB = (int)refB.y;
-    if (offN + (uint32_t)lenA > rl_cap) {  // the new row has at most lenA entries (cannot happen with the exact bound; guarded)
-        if (tid == 0) {
-            g->error = E_LIST_CAPACITY;
-            g->done = 1;
-            g->n_partners = 0;
-            atomicAdd(n_done, 1u);
-        }
-        shard_stop(E_LIST_CAPACITY);
-        return 1;
-    }
-    DA_GLOBAL Entry *rlA = rl + refA.x, *rlB = rl + refB.x, *rlN = rl + offN;
-    // this thread's entry of A (first chunk) and of B: pass 1 below then starts without a dependent load
-    // (unconditional loads, index clamped to entry 0 of the arena: behind a branch the wait counters become ambiguous and
-    // the second load is only issued after the first has returned)
-    Entry eA0 = rl[tid < lenA ? refA.x + (uint32_t)tid : 0u], eB0 = rl[tid < lenB ? refB.x + (uint32_t)tid : 0u];
-    load_fence();
-    RowInfo rn = RowInfo{0.0f, 0.0f, 0.0f, 0.0f};
-    int derr = 0;
-    if (tid == 0) {  // arithmetic only, while the entries are in flight; the global stores follow once they have been consumed
-        qint_add_pair(ra, rb, shift, sub, rn.lo, rn.hi, rn.step);
-        float dlat = adder_dlat(ra, rb, shift, sub, adder_size, carry_size, s_log2, StepLog2{n_step_mant, step_mant, step_tab}, derr);
-        rn.lat = (ra.lat < rb.lat ? rb.lat : ra.lat) + dlat;
-        s_new = rn;
-    }
-    for (int k = tid; k < 6 * Kpad; k += SEL_THREADS) s_cnt[k] = 0;
-    if (tid >= lenA) eA0 = F::none();
-    if (same || tid >= lenB) eB0 = F::none();
-    pin_vgpr(eA0, eB0);  // both consumed (waited for) here, in front of thread 0's stores below
-    if (!same) {  // B's list into LDS, addressable by column (s_bpos was zeroed at the start, several barriers ago)
-        if (tid < lenB) {
-            s_bent[tid] = eB0;
-            s_bpos[F::col(eB0)] = tid + 1;
-        }
-        for (int t = tid + SEL_THREADS; t < lenB; t += SEL_THREADS) {
-            const Entry e = rlB[t];
-            s_bent[t] = e;
-            s_bpos[F::col(e)] = t + 1;
-        }
-    }
-    if (tid == 0) {  // (a wait for a loaded value also waits for every store issued before it: these come after the last one)
-        if (derr) g->error = E_FLOAT_DOMAIN;
-        store_row((DA_GLOBAL RowInfo *)c.rows, Nw, rn);
-        picks[iter] = da_i4{(int)A, (int)B, sub, shift};
-        if (n_live0 > live_peak0) g->live_peak = n_live0;
-    }
-    __syncthreads();
-    SEL_TIMER_MARK(3)
-    uint32_t *cAA = s_cnt, *cAB = s_cnt + Kpad, *cBB = s_cnt + 2 * Kpad, *cAN = s_cnt + 3 * Kpad, *cBN = s_cnt + 4 * Kpad,
-             *cNN = s_cnt + 5 * Kpad;
-    unsigned int my_matches = 0;
-    int m = 0;  // matched columns so far (block-uniform)
-    // pass 1: one thread per entry of A (ascending columns); the matched columns are compacted in column order, which
-    // is the order of the new row's list
-    for (int t0 = 0; t0 < lenA; t0 += SEL_THREADS) {
-        const int t = t0 + tid;
-        Cell a = 0, b = 0, ma = 0, mb = 0, na = 0, nbv = 0;
-        uint32_t colA = 0;
-        int pos = 0;
-        if (t < lenA) {
-            const Entry e = t0 == 0 ? eA0 : rlA[t];
-            colA = F::col(e);
-            a = F::cell(e);
-            if (same)
-                b = a;
-            else {
-                pos = s_bpos[colA];
-                b = pos ? F::cell(s_bent[pos - 1]) : (Cell)0;
-            }
-            if (a && b) substitute_column<Cell>(a, b, same, shift, sub, ma, mb);
-            na = same ? (Cell)(a & ~ma & ~mb) : (Cell)(a & ~ma);
-            nbv = b & ~mb;
-        }
-        const bool hit = ma != 0;
-        const unsigned long long bal = __ballot(hit);
-        if (lane == 0) s_part[wid] = __popcll(bal);
-        __syncthreads();
-        int wbase = 0, chunk = 0;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) {
-            const int v = s_part[w];
-            wbase += w < wid ? v : 0;
-            chunk += v;
-        }
-        if (hit) {
-            const int at = m + wbase + __popcll(bal & ((1ull << lane) - 1));
-            rlA[t] = F::pack(colA, na);
-            if (!same) s_bent[pos - 1] = F::pack(colA, nbv);
-            rlN[at] = F::pack(colA, ma);
-            mcol[at] = (int)colA;
-            mA[at] = ma;
-            mB[at] = mb;
-            s_cm[colA] = at + 1;
-            {  // row bitmaps of this column: the new row enters, a row whose cell just lost its last digit leaves
-                DA_GLOBAL uint32_t *cb = colbits + (size_t)colA * cbw;
-                atomicOr(gen(&cb[Nw >> 5]), 1u << (Nw & 31));
-                if (na == 0) atomicAnd(gen(&cb[A >> 5]), ~(1u << (A & 31)));
-                if (!same && nbv == 0) atomicAnd(gen(&cb[B >> 5]), ~(1u << (B & 31)));
-            }
-            s_len[at] = s_clen[colA];  // the pre-append length: the new row itself is not a partner
-            s_col[at] = (int)colA;
-            my_matches += popc32(O::plus(ma) | O::minus(ma));
-        }
-        // ---------------- (3) exact recount of the pairs among {A, B, new} (their old blocks are replaced); the
-        // self pairs of B are counted in pass 2 (B may have columns A does not have)
-        if (na) for_pairs_self<Cell>(na, nb, [&](int k) { atomicAdd(&cAA[k], 1u); });
-        if (!same) {
-            if (na && nbv) for_pairs_cross<Cell>(na, nbv, nb, [&](int k) { atomicAdd(&cAB[k], 1u); });
-            if (nbv && ma) for_pairs_cross<Cell>(nbv, ma, nb, [&](int k) { atomicAdd(&cBN[k], 1u); });
-        }
-        if (na && ma) for_pairs_cross<Cell>(na, ma, nb, [&](int k) { atomicAdd(&cAN[k], 1u); });
-        if (ma) for_pairs_self<Cell>(ma, nb, [&](int k) { atomicAdd(&cNN[k], 1u); });
-        m += chunk;
-        __syncthreads();  // s_part is reused by the next chunk; s_bent updates visible to pass 2
-    }
-    if (my_matches) atomicAdd(&s_matches, my_matches);  // LDS; added to the chain's statistics by thread 0 at the end
-    // pass 2: B's list back to memory, self pairs of what is left of B
-    if (!same)
-        for (int t = tid; t < lenB; t += SEL_THREADS) {
-            const Entry e = s_bent[t];
-            rlB[t] = e;
-            const Cell nbv = F::cell(e);
-            if (nbv) for_pairs_self<Cell>(nbv, nb, [&](int k) { atomicAdd(&cBB[k], 1u); });
-        }
-    // the map column -> matched index for the update blocks (one coalesced copy; pass 1 has completed: its last barrier)
-    for (int j = tid; j < n_out; j += SEL_THREADS) cmap[j] = (uint16_t)s_cm[j];
-    // the new row joins the lists of its columns
-    {
-        const unsigned long long refN = ref_pack(Nw, (uint32_t)m, offN);
-        for (int k = tid; k < m; k += SEL_THREADS) {
-            const int j = s_col[k], len = s_len[k];
-            if (len < lcap) {
-                collist[(size_t)j * lcap + len] = refN;
-                collen[j] = len + 1;
-            } else
-                g->error = E_LIST_CAPACITY;
-        }
-    }
-    __syncthreads();
-    SEL_TIMER_MARK(4)
-    int total = 0;
-    if constexpr (SHARDED) {  // only the column-sharded chain still walks the column lists
-    // exclusive prefix sum of the list lengths of the matched columns (m <= n_out)
-    for (int k = tid; k < claim_words; k += SEL_THREADS) s_bits[k] = 0;
-    if (m <= WAVE) {  // the common case: one wave, shuffle scan
-        if (wid == 0) {
-            int v = lane < m ? s_len[lane] : 0, inc = v;
-            for (int o = 1; o < WAVE; o <<= 1) {
-                int t = __shfl_up(inc, o);
-                if (lane >= o) inc += t;
-            }
-            if (lane < m) s_len[lane] = inc - v;
-            if (lane == WAVE - 1) s_len[m] = inc;
-        }
-        __syncthreads();
-    } else {  // chunked block scan
-        int per = (m + SEL_THREADS - 1) / SEL_THREADS;
-        int lo = min(tid * per, m), hi = min(lo + per, m), sum = 0;
-        for (int q = lo; q < hi; ++q) sum += s_len[q];
-        int inc = sum;
-        for (int o = 1; o < WAVE; o <<= 1) {
-            int t = __shfl_up(inc, o);
-            if (lane >= o) inc += t;
-        }
-        if (lane == WAVE - 1) s_part[wid] = inc;
-        __syncthreads();
-        int wbase = 0;
-        for (int w = 0; w < wid; ++w) wbase += s_part[w];
-        int run = wbase + inc - sum;
-        __syncthreads();
-        for (int q = lo; q < hi; ++q) {
-            int l = s_len[q];
-            s_len[q] = run;
-            run += l;
-        }
-        if (tid == SEL_THREADS - 1) s_len[m] = wbase + inc;
-        __syncthreads();
-    }
-    total = s_len[m];
-    }
-    SEL_TIMER_MARK(5)
-    // ---------------- (4) partner rows -- the rows that have digits in a substituted column -- into the partner list, by the
-    // first NW-6 waves; the last six waves store the six special pairs meanwhile.  A column-sharded chain leaves one flag per
-    // row instead (read from its column lists).
-    constexpr int CLAIM_WAVES = NW - 6, CLAIM_THREADS = CLAIM_WAVES * WAVE;
-    if (wid < CLAIM_WAVES) {
-        if constexpr (SHARDED) {
-            for (int f = tid; f < total; f += CLAIM_THREADS) {
-                int lo = 0, hi = m;
-                while (hi - lo > 1) {
-                    int mid = (lo + hi) >> 1;
-                    if (s_len[mid] <= f)
-                        lo = mid;
-                    else
-                        hi = mid;
-                }
-                const uint32_t row = ref_row(collist[(size_t)s_col[lo] * lcap + (f - s_len[lo])]);
-                if (row != A && row != B) atomicOr(&s_bits[row >> 5], 1u << (row & 31));
-            }
-        }
-    } else {
-        const int sp = wid - CLAIM_WAVES;  // (A,A) (A,B) (B,B) (A,N) (B,N) (N,N): the pairs with B do not exist when the pick is a row with itself
-        const uint32_t *cnt = s_cnt + sp * Kpad;
-        const bool active = !(same && (sp == 1 || sp == 2 || sp == 4));
-        if constexpr (SHARDED) {  // partial counts of the six special pairs: head of the exchange slab, [6][K]
-            DA_GLOBAL int32_t *spec = cs_slab + (size_t)sp * c.K;
-            for (int k = lane; k < c.K; k += WAVE) spec[k] = active ? (int32_t)cnt[k] : 0;
-        }
-    }
-    SEL_TIMER_MARK(6)
-    __syncthreads();
-    SEL_TIMER_MARK(7)
-    if constexpr (SHARDED) {  // claim bitmap -> 8-bit flag fields, four rows per word (summed over the ranks without carry)
-        DA_GLOBAL int32_t *flags = cs_flags;
-        for (int w = tid; w < (int)((Nw + 3) / 4); w += SEL_THREADS) {
-            const uint32_t b = (s_bits[w >> 3] >> ((w & 7) * 4)) & 0xFu;
-            flags[w] = (int32_t)((b & 1u) | ((b & 2u) << 7) | ((b & 4u) << 14) | ((b & 8u) << 21));
-        }
-        if (tid < SHARD_TRAILER) flags[(int)((Nw + 3) / 4) + tid] = 0;  // status trailer of a rank that took the step (cmvm_shard.h)
-    }
-    if (tid == 0) {
-        SEL_TIMER_FLUSH
-        rowoff[Nw] = da_u2{offN, (uint32_t)m};
-        g->rl_used = offN + (uint32_t)m;
-        g->m = m;
-        g->n_partners = s_np;
-        // statistics: atomics without a return value (a plain += is load -> add -> store: one more round trip at the very end)
-        atomicAdd(&g->st_matches, (unsigned long long)s_matches);
-        atomicAdd(&g->st_partners, (unsigned long long)s_np);
-        atomicAdd(&g->st_cells, (unsigned long long)s_np * (unsigned)m);
-        {
-            // algorithmic bytes of this selection step: bound / dirty / tie word of every group, the list
-            // lengths of all columns, records and list references of A and B, both row lists read and written back, the row
-            // bitmaps of the m substituted columns, per partner its id + list reference + partner-list entry, the hand-off
-            // (matched columns, consumed digits, new row's list, column map, column-list and bitmap updates), six special blocks
-            const unsigned long long eb = sizeof(Entry), cb = sizeof(Cell);
-            const unsigned long long nwords = (Nw + 31) >> 5;
-            atomicAdd(&g->st_sel_bytes, 17ull * (unsigned)n_groups + 4ull * (unsigned)n_out + 48ull + 2ull * eb * (unsigned)(lenA + (same ? 0 : lenB)) +
-                                            4ull * (unsigned)m * nwords + 20ull * (unsigned)s_np + (unsigned)m * (4ull + 2ull * cb + eb + 8ull + 12ull) + 2ull * (unsigned)n_out +
-                                            6ull * (16ull + 4ull * (unsigned)c.K));
-        }
-        g->A = A;
-        g->B = B;
-        g->Nw = Nw;
-        g->n_rows = (int)Nw + 1;
-        g->iter = iter + 1;
-    }
-    return 0;
-}
-template <class Cell, bool SHARDED = true> __global__ void __launch_bounds__(SEL_THREADS) k_iter_select(ChainDev *chains, unsigned int *n_done) {
-    (void)select_body<Cell, SHARDED>(&chains[blockIdx.x], n_done);
-}
-
-
 // ================================================================================= k_iter_select2: the next pick, one step ahead
 // A greedy step changes only table entries that touch the two rows of its pick (A, B) or the row it creates (N).  So the
 // best entry R_t of the table of step t that touches neither A_t nor B_t is still in the table of step t + 1, unchanged, and
@@ -1423,8 +847,9 @@ template <class Cell, bool SHARDED = true> __global__ void __launch_bounds__(SEL
 //     {A, B, N}) that reaches R_t to c_list[t & 1], changed or not (fold_entry), and passes on the entries of l_list whose block
 //     it does not visit (the other row is not a partner row: the entry is unchanged);
 //   * the SUBSTITUTION block (pick_body, blockIdx.y == 1) of step t + 1 takes the largest of R_t and c_list[t & 1] as its pick:
-//     no bounds, no arg-max in front of the substitution.  Only when there is no R_t or a list overflowed does it wait for the
-//     search block, which then runs the arg-max first (as k_iter_select did), publishes the pick, and searches afterwards.
+//     no bounds, no arg-max in front of the substitution.  Only when there is no R_t or a list overflowed (the first step of a chain) does it
+//     find the pick itself -- a plain arg-max over the dense rank array (table_argmax_block) --, as does the search block for its own purpose
+//     (through the bounds): the two blocks never wait for each other.
 // Exactness: an entry of the table of step t + 1 either touches none of A_t, B_t, N_t -- then it is at most R_t --, or its block
 // was written / re-evaluated by the update -- then its best entry is in c_list if it reaches R_t --, or it touches A_t or B_t
 // and its block was not visited -- then it is unchanged since the search saw it, and in l_list -> c_list if it reaches R_t.
@@ -1597,7 +1022,7 @@ template <class Cell> __device__ __forceinline__ void search_body(ChainDev *g, i
             return 0ull;
         };
         // ---- ONE vector round trip: bound, dirty flag and stored tie word of this lane's (up to GPL) groups; unconditional loads, index clamped
-        // (see select_body).  A clean group's bound and tie word are exact: its best entry is a candidate right away, or -- if it touches an
+        // (behind an `in ? load : 0` the compiler waits for each load inside its own branch).  A clean group's bound and tie word are exact: its best entry is a candidate right away, or -- if it touches an
         // excluded row -- the group has to be read.  (The second pass of a launch reads what the first one tightened: fenced below.)
         // Groups that may have to be read -- dirty, or clean with an excluded best entry -- keep their bound in LDS (q_ub[u][tid], 0 = nothing to
         // read); a lane holds only its highest one in registers (top, top_u) and one bit per group: dirty.
@@ -1885,11 +1310,13 @@ template <class Cell> __device__ __forceinline__ void search_body(ChainDev *g, i
 #endif
 }
 
-// pick_body: the substitution block of a step (see above).  Phases (2)-(4) of select_body -- substitution of the pick in the
+// pick_body: the substitution block of a step (see above): substitution of the pick in the
 // lists of rows A and B, exact recount of the six pairs among {A, B, new} (their counts go to sp_cnt: the blocks are written by
-// k_iter_update), partner rows -- behind a pick that is either read from the descriptor (known one step ahead) or awaited
-// from the search block.  Returns 1 when the chain is (or just became) finished.
-template <class Cell> __device__ __forceinline__ int pick_body(ChainDev *g, unsigned int *n_done, int step) {
+// k_iter_update), partner rows -- behind a pick that is either read from the descriptor (known one step ahead) or found by the block itself
+// (table_argmax_block).  SHARDED (cmvm_shard.h): the chain holds a slice of the columns and a replica of the pair table -- the six count vectors are
+// PARTIAL and go to the head of the exchange slab, and the block leaves one flag per row that shares a substituted column instead of a partner list.
+// Returns 1 when the chain is (or just became) finished.
+template <class Cell, bool SHARDED = false> __device__ __forceinline__ int pick_body(ChainDev *g, unsigned int *n_done, int step) {
     using O = CellOps<Cell>;
     using F = RowFmt<Cell>;
     using Entry = typename F::Entry;
@@ -1920,12 +1347,32 @@ template <class Cell> __device__ __forceinline__ int pick_body(ChainDev *g, unsi
     DA_GLOBAL unsigned long long *plist = (DA_GLOBAL unsigned long long *)g->plist;
     DA_GLOBAL da_i4 *picks = (DA_GLOBAL da_i4 *)g->picks;
     DA_GLOBAL uint32_t *sp_cnt = (DA_GLOBAL uint32_t *)g->sp_cnt;
+    DA_GLOBAL int32_t *cs_slab = (DA_GLOBAL int32_t *)g->cs_slab, *cs_flags = (DA_GLOBAL int32_t *)g->cs_flags;  // (column-sharded chains only)
     pin_sgpr(was_done, had_error, lcap, claim_words, n_rows0, rcap, cbw, adder_size, carry_size, offN, rl_cap, n_live0, live_peak0, step_mant, step_tab, n_step_mant);
     pin_sgpr(sp_word, sp_tie, cn_prev, cl_prev, sp_ax, sp_ay, sp_bx, sp_by, sp_ra0, sp_ra1, sp_ra2, sp_ra3, sp_rb0, sp_rb1, sp_rb2, sp_rb3);
     pin_sgpr(c.n_out, c.n_bits, c.K, c.Kpad, c.rows);
     pin_sgpr(collen, rowoff, rl, mA, mB, mcol, collist, cmap, colbits, pl_ids, plist, picks, sp_cnt);
+    if constexpr (SHARDED) pin_sgpr(cs_slab, cs_flags);
     const int n_out = c.n_out, Kpad = c.Kpad, nb = c.n_bits;
-    if (was_done) return 1;
+    // column-sharded chain (cmvm_shard.h): a rank whose chain stops (finished, or an error) still hands out the flag buffer of the step -- zero
+    // flags and the status trailer {1, capacity error?, other error?} -- written here, on the device: the host does not read the descriptor
+    // back between the steps
+    auto shard_stop = [&](int err) {
+        if constexpr (SHARDED) {
+            const int fw = (n_rows0 + 3) / 4;  // rows before this step
+            for (int w = threadIdx.x; w < fw; w += SEL2_THREADS) cs_flags[w] = 0;
+            if (threadIdx.x == 0) {
+                const bool cap = err == E_ROW_CAPACITY || err == E_TABLE_CAPACITY || err == E_LIST_CAPACITY;
+                cs_flags[fw] = 1;
+                cs_flags[fw + 1] = cap ? 1 : 0;
+                cs_flags[fw + 2] = err != E_OK && !cap ? 1 : 0;
+            }
+        }
+    };
+    if (was_done) {
+        shard_stop(had_error);
+        return 1;
+    }
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // dynamic LDS carve: B's list | special-pair counters | per-matched-column scratch | column -> position in B
     Entry *s_bent = reinterpret_cast<Entry *>(smem);                                  // [n_out] entries of row B (updated in place)
@@ -1956,6 +1403,7 @@ template <class Cell> __device__ __forceinline__ int pick_body(ChainDev *g, unsi
             g->n_partners = 0;
             atomicAdd(n_done, 1u);
         }
+        shard_stop(had_error);
         return 1;
     }
     // ---------------- (1) the pick: the best of what the previous step left (its untouched entry against the entries its update listed), or --
@@ -2023,6 +1471,7 @@ template <class Cell> __device__ __forceinline__ int pick_body(ChainDev *g, unsi
             g->n_partners = 0;
             atomicAdd(n_done, 1u);
         }
+        shard_stop(pk_word != 0 ? E_ROW_CAPACITY : E_OK);
         return 1;
     }
     const int idx = (int)(best_tie & 0x7F);
@@ -2039,6 +1488,7 @@ template <class Cell> __device__ __forceinline__ int pick_body(ChainDev *g, unsi
             g->n_partners = 0;
             atomicAdd(n_done, 1u);
         }
+        shard_stop(E_LIST_CAPACITY);
         return 1;
     }
     DA_GLOBAL Entry *rlA = rl + refA.x, *rlB = rl + refB.x, *rlN = rl + offN;
@@ -2169,7 +1619,13 @@ template <class Cell> __device__ __forceinline__ int pick_body(ChainDev *g, unsi
     SEL_TIMER_MARK(4)
     SEL_TIMER_MARK(5)
     // the exact counts of the six pairs among {A, B, new}: to the special-pair block of k_iter_update (all counters are final: the barrier above)
-    for (int k = tid; k < 6 * Kpad; k += SEL2_THREADS) sp_cnt[k] = s_cnt[k];
+    if constexpr (SHARDED) {  // PARTIAL counts (this rank's columns): the head of the exchange slab, [6][K]; pairs with B do not exist when the pick is a row with itself
+        for (int k = tid; k < 6 * c.K; k += SEL2_THREADS) {
+            const int sp = k / c.K;
+            cs_slab[k] = (same && (sp == 1 || sp == 2 || sp == 4)) ? 0 : (int32_t)s_cnt[sp * Kpad + (k - sp * c.K)];
+        }
+    } else
+        for (int k = tid; k < 6 * Kpad; k += SEL2_THREADS) sp_cnt[k] = s_cnt[k];
     // ---------------- (4) partner rows -- the rows that have digits in a substituted column -- into the partner list:
     // OR of those columns' row bitmaps (A, B and the new row masked out: their bits are being changed by this very kernel).  Word w
     // of the OR covers rows 32 w ..; the set bits are counted (DPP prefix sum), one LDS atomic per wave reserves the places, the
@@ -2204,6 +1660,17 @@ template <class Cell> __device__ __forceinline__ int pick_body(ChainDev *g, unsi
                 if ((int)(B >> 5) == w) bits &= ~(1u << (B & 31));
                 if ((int)(Nw >> 5) == w) bits &= ~(1u << (Nw & 31));
             }
+            if constexpr (SHARDED) {  // one 8-bit flag field per row (four rows per word: summed over the ranks without carry) instead of a partner list
+                const int fw = (int)((Nw + 3) / 4);
+                if (w < nwords) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const uint32_t b = (bits >> (4 * q)) & 0xFu;
+                        if (8 * w + q < fw) cs_flags[8 * w + q] = (int32_t)((b & 1u) | ((b & 2u) << 7) | ((b & 4u) << 14) | ((b & 8u) << 21));
+                    }
+                }
+                continue;
+            }
             const int cnt = popc32(bits), inc = (int)wave_scan_add_u32((uint32_t)cnt);  // inclusive prefix inside the wave (DPP)
             const int wave_total = __builtin_amdgcn_readlane(inc, WAVE - 1);
             if (wave_total == 0) continue;
@@ -2223,6 +1690,9 @@ template <class Cell> __device__ __forceinline__ int pick_body(ChainDev *g, unsi
     }
     SEL_TIMER_MARK(6)
     __syncthreads();
+    if constexpr (SHARDED) {
+        if (tid < SHARD_TRAILER) cs_flags[(int)((Nw + 3) / 4) + tid] = 0;  // status trailer of a rank that took the step (cmvm_shard.h)
+    }
     {  // partner ids -> partner list entries (row id, list length, list offset)
         const int np = s_np;
         const DA_GLOBAL uint32_t *ids = pl_ids;
@@ -2262,6 +1732,8 @@ template <class Cell> __device__ __forceinline__ int pick_body(ChainDev *g, unsi
         g->A = A;
         g->B = B;
         g->Nw = Nw;
+        g->pk_shift = shift;
+        g->pk_sub = sub;
         g->n_rows = (int)Nw + 1;
         g->iter = iter + 1;
     }
@@ -2274,7 +1746,7 @@ template <class Cell> __device__ __forceinline__ int pick_body(ChainDev *g, unsi
 #ifndef DA_SEL2_WAVES
 #define DA_SEL2_WAVES 4  // wavefronts per SIMD the register budget of k_iter_select2 is capped for (measured 4 .. 8: the spills of 5 and more cost more than the smaller footprint gains)
 #endif
-template <class Cell> __global__ void __launch_bounds__(SEL2_THREADS) __attribute__((amdgpu_waves_per_eu(DA_SEL2_WAVES, DA_SEL2_WAVES))) k_iter_select2(ChainDev *chains, int n_chains, unsigned int *n_done, int step) {
+template <class Cell, bool SHARDED = false> __global__ void __launch_bounds__(SEL2_THREADS) __attribute__((amdgpu_waves_per_eu(DA_SEL2_WAVES, DA_SEL2_WAVES))) k_iter_select2(ChainDev *chains, int n_chains, unsigned int *n_done, int step) {
     if ((int)blockIdx.x >= n_chains) return;
 #ifdef DA_STEP_CLOCKS
     {
@@ -2298,7 +1770,7 @@ template <class Cell> __global__ void __launch_bounds__(SEL2_THREADS) __attribut
     if (blockIdx.y == 0)
         search_body<Cell>(&chains[blockIdx.x], step);
     else
-        (void)pick_body<Cell>(&chains[blockIdx.x], n_done, step);
+        (void)pick_body<Cell, SHARDED>(&chains[blockIdx.x], n_done, step);
 #ifdef DA_STEP_CLOCKS
     __syncthreads();
     if (threadIdx.x == 0) CLK_MARK(&chains[blockIdx.x], step & 1, 1, false);
@@ -2340,6 +1812,7 @@ template <class Cell> struct UpdStep {
     Ctx c;
     int done, n_partners, m, n_in;
     uint32_t A, B, Nw;
+    int shift, sub;  // of the pick's key
     const DA_GLOBAL int *mcol;
     const DA_GLOBAL Cell *mA, *mB;
     const DA_GLOBAL uint16_t *cmap;
@@ -2353,6 +1826,7 @@ template <class Cell> __device__ __forceinline__ UpdStep<Cell> load_upd_step(Cha
     int iter = gq->iter;
     u.done = gq->done, u.n_partners = gq->n_partners, u.m = gq->m, u.n_in = gq->n_in;
     u.A = gq->A, u.B = gq->B, u.Nw = gq->Nw;
+    u.shift = gq->pk_shift, u.sub = gq->pk_sub;
     u.c = make_ctx_raw(gq, 2 * iter - 1);
     // the step being applied is iter - 1 (the selection has counted it): its search left the best entry the step does not touch in
     // spec[(iter - 1) & 1]; the best entry of every block this launch writes that reaches it goes to c_list[(iter - 1) & 1] (fold_entry)
@@ -2364,7 +1838,7 @@ template <class Cell> __device__ __forceinline__ UpdStep<Cell> load_upd_step(Cha
     u.cmap = (const DA_GLOBAL uint16_t *)gq->cmap;
     u.rl = (const DA_GLOBAL Entry *)gq->rlist;
     u.plist = (const DA_GLOBAL unsigned long long *)gq->plist;
-    pin_sgpr(u.done, u.n_partners, iter, u.m, u.n_in, u.A, u.B, u.Nw, u.mcol, u.mA, u.mB, u.cmap, u.rl, u.plist);
+    pin_sgpr(u.done, u.n_partners, iter, u.m, u.n_in, u.A, u.B, u.Nw, u.shift, u.sub, u.mcol, u.mA, u.cmap, u.rl, u.plist);
     pin_sgpr(u.c.n_out, u.c.n_bits, u.c.K, u.c.Kpad, u.c.method, u.c.gs_log2, u.c.pb_log2, u.c.cmask, u.c.windows, u.c.hkey, u.c.hrank, u.c.hblk, u.c.ub, u.c.glow, u.c.gdirty, u.c.rows);
     pin_sgpr(u.c.rword, u.c.cn, u.c.cl);
     u.c.tomb = KEY_TOMB - (unsigned long long)((2 * iter - 1) & 3);
@@ -2396,7 +1870,6 @@ template <class Cell> __device__ __forceinline__ void copy_handoff(const UpdStep
     for (int j = t; j < u.m; j += nthr) {
         s.col[j] = u.mcol[j];
         s.mA[j] = u.mA[j];
-        s.mB[j] = u.mB[j];
     }
 }
 
@@ -2411,10 +1884,10 @@ __device__ __forceinline__ void update_partners(ChainDev *g, const UpdStep<Cell>
     constexpr int QCW = sizeof(Cell) == 4 ? 2 : 4;  // count words per lane: narrow layout Kpad / 2 <= 24 words, wide <= 60
     const Ctx &c = u.c;
     const uint32_t A = u.A, B = u.B, Nw = u.Nw;
-    const int m = u.m, n_in = u.n_in;
+    const int m = u.m, n_in = u.n_in, pk_shift = u.shift, pk_sub = u.sub;
     const DA_GLOBAL Entry *rl = u.rl;
     const DA_GLOBAL unsigned long long *plist = u.plist;
-    Cell *s_mA = s.mA, *s_mB = s.mB;
+    Cell *s_mA = s.mA;
     int *s_col = s.col;
     uint16_t *s_cmap = s.cmap;
     uint32_t *s_cnt = s.cnt;
@@ -2481,13 +1954,36 @@ __device__ __forceinline__ void update_partners(ChainDev *g, const UpdStep<Cell>
             const Cell x = F::cell(en);
             const int at = x ? (int)s_cmap[F::col(en)] : 0;
             if (!at) return;  // empty cell, or a column that was not substituted
-            const Cell ma = s_mA[at - 1], mb = s_mB[at - 1];
-            if (sA != SLOT_NONE) {
-                for_pairs_part<Cell>(ma, x, A < pr, nb, [&](int k) { atomicAdd(&dA[k], 1u); });
-                if (same) for_pairs_part<Cell>(mb, x, A < pr, nb, [&](int k) { atomicAdd(&dA[k], 1u); });
+            const Cell ma = s_mA[at - 1];
+            // The digit pairs (partner digit, consumed A-role digit) are walked ONCE for all the blocks they count in (round 6; three walks,
+            // one per block, were most of this phase's instructions):
+            //   * gained with the new row, whose cell in this column IS ma (the partner is the row with the smaller id): key (q - p, signs);
+            //   * lost with A: the same key when the partner is also below A, the mirrored one (shift negated) otherwise;
+            //   * lost with the B-role digit that went with the A-role one: it sits `shift` positions further, its sign flipped when the pick
+            //     subtracts (substitute_column, cmvm_core.h: mb = ma moved by shift, also when A and B are one row) -- in B's block, or in A's
+            //     when the pick is a row with itself.
+            {
+                using O = CellOps<Cell>;
+                const uint32_t xm = O::minus(x), hm = O::minus(ma), ha = O::plus(ma) | hm;
+                const bool hasA = sA != SLOT_NONE, hasB = same ? hasA : sB != SLOT_NONE;
+                const bool mirA = A < pr, mirB = same ? mirA : B < pr;
+                uint32_t *dBx = same ? dA : dB;
+                uint32_t la = O::plus(x) | xm;
+                while (la) {
+                    const int p_ = ctz32(la);
+                    la &= la - 1;
+                    const int sl = (int)((xm >> p_) & 1u);
+                    uint32_t h = ha;
+                    while (h) {
+                        const int q_ = ctz32(h);
+                        h &= h - 1;
+                        const int sg = sl ^ (int)((hm >> q_) & 1u), d = q_ - p_, db = d + pk_shift;
+                        atomicAdd(&cN[key_index(d, sg, nb)], 1u);
+                        if (hasA) atomicAdd(&dA[key_index(mirA ? -d : d, sg, nb)], 1u);
+                        if (hasB) atomicAdd(&dBx[key_index(mirB ? -db : db, sg ^ pk_sub, nb)], 1u);
+                    }
+                }
             }
-            if (!same && sB != SLOT_NONE) for_pairs_part<Cell>(mb, x, B < pr, nb, [&](int k) { atomicAdd(&dB[k], 1u); });
-            for_pairs_cross<Cell>(x, ma, nb, [&](int k) { atomicAdd(&cN[k], 1u); });
         };
 #pragma unroll
         for (int u = 0; u < CH; ++u)
@@ -2837,11 +2333,30 @@ template <class Cell> __global__ void __launch_bounds__(256) k_cs_partial(ChainD
 // grid (ceil((n_union + 6) / 4)): the summed slab into the table.  Waves 0-5: the six pairs among {A, B, new} (their
 // blocks are replaced); wave 6 + u: row u of the union (blocks with A and B reduced, block with the new row created).
 template <class Cell> __global__ void __launch_bounds__(256) k_cs_apply(ChainDev *g) {
-    const Ctx c = make_ctx(g, 2 * g->iter - 1);
+    Ctx c = make_ctx(g, 2 * g->iter - 1);
+    // as k_iter_update (load_upd_step): the step being applied is iter - 1; the best entry of every block this launch writes or re-evaluates that
+    // reaches the entry the step leaves untouched (spec) is listed for the next pick (fold_entry)
+    c.rword = g->spec[(g->iter - 1) & 1].word;
+    c.cn = &g->c_n[(g->iter - 1) & 1];
+    c.cl = &g->c_list[(g->iter - 1) & 1][0];
     const int K = c.K;
     const int w = (int)blockIdx.x * 4 + wave_id();
     const uint32_t A = g->A, B = g->B, Nw = g->Nw;
     const bool same = A == B;
+    if (w == 5 && c.rword) {
+        // the entries the search listed (they touch exactly one of A / B and reach the untouched entry): a block whose other row is in the union of
+        // partner rows is re-evaluated by that row's wave, which passes its best entry on itself; the others are unchanged -- passed on here
+        // (special_pairs does the same for ordinary chains).  In the union <=> the row's summed flag field is not zero.
+        const int nl = (int)g->l_n[(g->iter - 1) & 1];
+        const CandEntry *ll = &g->l_list[(g->iter - 1) & 1][0];
+        if (lane_id() == 0)
+            for (int e = 0; e < nl; ++e) {
+                const unsigned long long tw = ll[e].tie;
+                const uint32_t i0 = (uint32_t)((tw >> 7) & 0xFFFFFFu), i1 = (uint32_t)(tw >> 31);
+                const uint32_t r = (i0 == A || i0 == B) ? i1 : i0;
+                if (((g->cs_flags[r >> 2] >> (8 * (r & 3))) & 0xFF) == 0) fold_entry(c, (uint32_t)ll[e].rank, tw);
+            }
+    }
     if (w < 6) {
         uint32_t lo = A, hi = A;
         bool active = true, existed = false;
@@ -3924,7 +3439,6 @@ class HipShardEngine : public ShardEngine {
         if (g.gs_log2 > 14) throw std::runtime_error("pair table larger than 64M slots is not supported");
         if (g.C < 256) g.C = 256;
         g.n_groups = (int)(g.C >> g.gs_log2);
-        if (((size_t)g.rcap + 31) / 32 * 4 > 64 * 1024) throw std::runtime_error("column-sharded chain: more rows than the LDS claim bitmap holds");
         n_pairs_ = (long long)job.n_in * (job.n_in + 1) / 2;
         // arena: the chain's arrays (local column count) + the exchange buffers
         ChainJob local = job;
@@ -3953,7 +3467,7 @@ class HipShardEngine : public ShardEngine {
         d_.rl_cap = g.rl_cap;
         d_.rl_used = (uint32_t)job.n_in * (uint32_t)n_loc_;
         d_.n_rows = job.n_in;
-        d_.claim_words = (g.rcap + 31) / 32;
+        d_.claim_words = claim_words_for(local_job(), g, sel2_lds_budget(device_, g.wide));
         HIP_CHECK(hipMemsetAsync(d_.stamp, 0, sizeof(uint32_t) * (size_t)g.rcap, st_));
         HIP_CHECK(hipMemsetAsync(d_.hkey, 0xFF, sizeof(unsigned long long) * (size_t)g.C, st_));
         HIP_CHECK(hipMemsetAsync(d_.hrank, 0, sizeof(uint32_t) * (size_t)g.C, st_));
@@ -3980,12 +3494,12 @@ class HipShardEngine : public ShardEngine {
         else
             hipLaunchKernelGGL(k_init_cells<uint64_t>, colgrid, dim3(256), 0, st_, dd_);
         HIP_CHECK(hipGetLastError());
-        sel_lds_ = align_up((size_t)n_loc_ * (g.wide ? 16 : 4) + 6 * (size_t)g.Kpad * 4 + (5 * (size_t)n_loc_ + 1) * 4 + (size_t)d_.claim_words * 4, 16);
-        if (sel_lds_ > 150 * 1024) throw std::runtime_error("selection kernel needs more than 150 KiB of LDS");
+        sel_lds_ = align_up(sel2_fixed_lds(local_job(), g) + (size_t)d_.claim_words * 4, 16);
+        if (sel_lds_ > sel2_lds_budget(device_, g.wide)) throw std::runtime_error("selection kernel needs more dynamic LDS than the device leaves beside its static arrays (n_out too large)");
         if (!g.wide)
-            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_iter_select<uint32_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sel_lds_));
+            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_iter_select2<uint32_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sel_lds_));
         else
-            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_iter_select<uint64_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sel_lds_));
+            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_iter_select2<uint64_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sel_lds_));
         part_lds_ = align_up(2 * (size_t)n_loc_ * (g.wide ? 8 : 4) + 4 * 3 * (size_t)g.Kpad * 4 + (size_t)n_loc_ * 2, 16);
         HIP_CHECK(hipStreamSynchronize(st_));
     }
@@ -4019,10 +3533,12 @@ class HipShardEngine : public ShardEngine {
     void select(int32_t *&flags, int64_t &fcount) override {
         fw_ = flag_words(job_.n_in + (int)steps_);  // rows before this step
         if (!stopped_) {
+            // the two-block selection of the ordinary chains (search beside substitution, the pick known one step ahead): the table is a replica,
+            // so every rank takes the same pick; the substitution block leaves flags and partial special-pair counts instead of a partner list
             if (!geo_.wide)
-                hipLaunchKernelGGL((k_iter_select<uint32_t, true>), dim3(1), dim3(SEL_THREADS), sel_lds_, st_, dd_, d_done_);
+                hipLaunchKernelGGL((k_iter_select2<uint32_t, true>), dim3(1, 2), dim3(SEL2_THREADS), sel_lds_, st_, dd_, 1, d_done_, (int)steps_);
             else
-                hipLaunchKernelGGL((k_iter_select<uint64_t, true>), dim3(1), dim3(SEL_THREADS), sel_lds_, st_, dd_, d_done_);
+                hipLaunchKernelGGL((k_iter_select2<uint64_t, true>), dim3(1, 2), dim3(SEL2_THREADS), sel_lds_, st_, dd_, 1, d_done_, (int)steps_);
             HIP_CHECK(hipGetLastError());
         } else {  // (not reached by ShardedBackend, which leaves the loop with the step that stopped; kept well-defined)
             const int32_t tr[SHARD_TRAILER] = {1, 0, 0};
@@ -4123,6 +3639,11 @@ class HipShardEngine : public ShardEngine {
     }
 
   private:
+    ChainJob local_job() const {  // the chain as this rank holds it: n_loc_ columns
+        ChainJob j = job_;
+        j.n_out = n_loc_;
+        return j;
+    }
     void sync() {
         HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipStreamSynchronize(st_));
