@@ -1807,6 +1807,14 @@ __device__ __forceinline__ unsigned long long row_max_u64(unsigned long long v) 
     return v;
 }
 
+constexpr int DPP_QUAD_XOR1 = 0xB1, DPP_QUAD_XOR2 = 0x4E, DPP_ROW_HALF_MIRROR = 0x141;  // quad_perm:[1,0,3,2], quad_perm:[2,3,0,1], lane i <-> 7 - i of its eight
+__device__ __forceinline__ unsigned long long half_row_max_u64(unsigned long long v) {  // max over each group of EIGHT lanes, in all of them (three butterfly steps)
+    v = dpp_max_u64<DPP_QUAD_XOR1, 0xF>(v);
+    v = dpp_max_u64<DPP_QUAD_XOR2, 0xF>(v);
+    v = dpp_max_u64<DPP_ROW_HALF_MIRROR, 0xF>(v);
+    return v;
+}
+
 // ---- one update step of a chain, as the wave-uniform values its workers need (scalar registers)
 template <class Cell> struct UpdStep {
     Ctx c;
@@ -1881,7 +1889,7 @@ __device__ __forceinline__ void update_partners(ChainDev *g, const UpdStep<Cell>
                                                 const RowInfo &rnew, unsigned int &found, unsigned int &inserts, unsigned int &deletes) {
     using F = RowFmt<Cell>;
     using Entry = typename F::Entry;
-    constexpr int QCW = sizeof(Cell) == 4 ? 2 : 4;  // count words per lane: narrow layout Kpad / 2 <= 24 words, wide <= 60
+    constexpr int HW = sizeof(Cell) == 4 ? 4 : 8;  // count words per lane (a block's words over EIGHT lanes): narrow layout Kpad / 2 <= 24 words, wide <= 60
     const Ctx &c = u.c;
     const uint32_t A = u.A, B = u.B, Nw = u.Nw;
     const int m = u.m, n_in = u.n_in, pk_shift = u.shift, pk_sub = u.sub;
@@ -1937,16 +1945,19 @@ __device__ __forceinline__ void update_partners(ChainDev *g, const UpdStep<Cell>
             }
         }
         UPD_TIMER_MARK(1)  // reference + list + table probes
-        // ---- round trip 3: the payload lines of the blocks that exist: header (same 16 bytes for the group) + count words
+        // ---- round trip 3: the payload lines of the blocks that exist.  The two blocks of a partner -- (A, r) and (B, r) -- are handled SIDE BY SIDE:
+        // lanes 0-7 of the group take A's block, lanes 8-15 B's, so that one pass of the instruction stream below re-evaluates both (round 6:
+        // one pass per block was twice the instructions; batch 31.1 -> 30.7 us per step); a lane holds the header of its block (16 bytes) and every eighth count word
+        const int half = l >> 3, hl = l & 7;
+        const int sX = half ? sB : sA;
+        const unsigned long long keyX = half ? keyB : keyA;
         const da_i4 z4 = da_i4{0, 0, 0, 0};
-        const da_i4 hdA = sA >= 0 ? *reinterpret_cast<const DA_GLOBAL da_i4 *>(blk_ptr(c, sA)) : z4;
-        const da_i4 hdB = sB >= 0 ? *reinterpret_cast<const DA_GLOBAL da_i4 *>(blk_ptr(c, sB)) : z4;
-        uint32_t wA[QCW], wB[QCW];
+        const da_i4 hdX = sX >= 0 ? *reinterpret_cast<const DA_GLOBAL da_i4 *>(blk_ptr(c, sX)) : z4;
+        uint32_t wX[HW];
 #pragma unroll
-        for (int u = 0; u < QCW; ++u) {
-            const int j = l + u * QG;
-            wA[u] = (sA >= 0 && j < KW) ? reinterpret_cast<const DA_GLOBAL uint32_t *>(blk_ptr(c, sA) + 16)[j] : 0u;
-            wB[u] = (sB >= 0 && j < KW) ? reinterpret_cast<const DA_GLOBAL uint32_t *>(blk_ptr(c, sB) + 16)[j] : 0u;
+        for (int u = 0; u < HW; ++u) {
+            const int j = hl + u * 8;
+            wX[u] = (sX >= 0 && j < KW) ? reinterpret_cast<const DA_GLOBAL uint32_t *>(blk_ptr(c, sX) + 16)[j] : 0u;
         }
         lds_fence();  // counters are zero
         // ---- digit pairs lost with A's / B's consumed digits and gained with the new row: a lane per list entry
@@ -1995,20 +2006,21 @@ __device__ __forceinline__ void update_partners(ChainDev *g, const UpdStep<Cell>
         for (int k = l; k < K; k += QG) fnew |= cN[k] >= 2u;
         const bool gnew = valid && (((uint32_t)(__ballot(fnew != 0) >> qsh) & 0xFFFFu) != 0);
         UPD_TIMER_MARK(2)  // pair enumeration
-        // ---- re-evaluate the blocks: two counts per lane and word, reduction inside the DPP row, lane 15 publishes
-        auto apply = [&](int slot, unsigned long long key, const da_i4 &hd, const uint32_t (&w)[QCW], const uint32_t *d) {
-            const bool has = slot >= 0;
-            const int ov = hd.x;
-            const float dl = __int_as_float(hd.y);
+        // ---- re-evaluate both blocks at once: two counts per lane and word, reduction inside the eight lanes of a block, their last lane publishes
+        {
+            const bool has = sX >= 0;
+            const int ov = hdX.x;
+            const float dl = __int_as_float(hdX.y);
+            const uint32_t *d = half ? dB : dA;
             unsigned long long best = 0;
             int alive = 0;
 #pragma unroll
-            for (int u = 0; u < QCW; ++u) {
-                const int j = l + u * QG;
+            for (int u = 0; u < HW; ++u) {
+                const int j = hl + u * 8;
                 if (has && j < KW) {
-                    const uint32_t o0 = w[u] & 0xFFFFu, o1 = w[u] >> 16;
+                    const uint32_t o0 = wX[u] & 0xFFFFu, o1 = wX[u] >> 16;
                     const uint32_t n0 = o0 - d[2 * j], n1 = o1 - d[2 * j + 1];
-                    if (n0 != o0 || n1 != o1) reinterpret_cast<DA_GLOBAL uint32_t *>(blk_ptr(c, slot) + 16)[j] = (n0 & 0xFFFFu) | (n1 << 16);
+                    if (n0 != o0 || n1 != o1) reinterpret_cast<DA_GLOBAL uint32_t *>(blk_ptr(c, sX) + 16)[j] = (n0 & 0xFFFFu) | (n1 << 16);
                     alive |= (n0 >= 2u) | (n1 >= 2u);
                     const uint32_t r0 = entry_rank(n0, ov, dl, c.method), r1 = entry_rank(n1, ov, dl, c.method);
                     const unsigned long long c0 = r0 ? (((unsigned long long)r0 << 8) | (unsigned)(2 * j)) : 0ull;
@@ -2017,13 +2029,11 @@ __device__ __forceinline__ void update_partners(ChainDev *g, const UpdStep<Cell>
                     best = c1 > best ? c1 : best;
                 }
             }
-            best = row_max_u64(best);  // all lanes take part (the DPP source lanes must be active); lane 15 of the row holds the result
-            const bool any_alive = (((uint32_t)(__ballot(alive != 0) >> qsh) & 0xFFFFu) != 0);
-            if (has && l == QG - 1) block_commit(c, slot, key, BlkHdr{ov, dl, (uint32_t)hd.z, (uint32_t)hd.w}, best, any_alive, false);
-            deletes += (unsigned)__popcll(__ballot(has && l == QG - 1 && !any_alive));  // (wave-uniform: the blocks this pass deleted, tallied once per workgroup)
-        };
-        apply(sA, keyA, hdA, wA, dA);
-        apply(sB, keyB, hdB, wB, dB);
+            best = half_row_max_u64(best);  // all lanes take part (the DPP source lanes must be active); every lane of a block's eight holds its result
+            const bool any_alive = (((uint32_t)(__ballot(alive != 0) >> (qsh + 8 * half)) & 0xFFu) != 0);
+            if (has && hl == 7) block_commit(c, sX, keyX, BlkHdr{ov, dl, (uint32_t)hdX.z, (uint32_t)hdX.w}, best, any_alive, false);
+            deletes += (unsigned)__popcll(__ballot(has && hl == 7 && !any_alive));  // (wave-uniform: the blocks this pass deleted, tallied once per workgroup)
+        }
         UPD_TIMER_MARK(3)  // block updates
         // ---- rare: blocks beyond their first bucket, block creation -- the whole wave, one group at a time
         const unsigned long long rare = __ballot(valid && (sA == SLOT_SLOW || sB == SLOT_SLOW || gnew));

@@ -153,6 +153,12 @@ __attribute__((noinline)) inline int __builtin_amdgcn_update_dpp(int old, int sr
     } else if (ctrl >= 0x101 && ctrl <= 0x10F) {  // row_shl:n
         const int n = ctrl & 0xF;
         from = in_row + n < 16 ? l + n : -1;
+    } else if (ctrl >= 0 && ctrl <= 0xFF) {  // quad_perm:[a,b,c,d] -- within every group of four lanes
+        from = (l & ~3) + ((ctrl >> (2 * (l & 3))) & 3);
+    } else if (ctrl == 0x140) {  // row_mirror
+        from = (l & ~15) + (15 - in_row);
+    } else if (ctrl == 0x141) {  // row_half_mirror -- within every group of eight lanes
+        from = (l & ~7) + (7 - (l & 7));
     } else if (ctrl == 0x142) {  // row_bcast:15 -- lane 15 of the previous row
         from = row >= 1 ? row * 16 - 1 : -1;
     } else if (ctrl == 0x143) {  // row_bcast:31 -- lane 31 for rows 2 and 3
