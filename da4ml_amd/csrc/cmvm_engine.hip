@@ -1797,7 +1797,14 @@ constexpr int SLOT_NONE = -1, SLOT_SLOW = -2;  // no such block / to be searched
 // block are 16 words = one word (two counts) per lane, and the reductions stay inside the DPP row.  Everything that was
 // wave-uniform per partner (slots, keys, hashes) is now a per-lane value, identical across the lanes of a group.
 // Rare cases (key not in its first bucket, block creation) fall back to the wave-wide table functions, one group at a time.
-constexpr int QG = 16, QN = WAVE / QG;  // lanes per partner, partners per wavefront
+#ifndef DA_UPD_QG
+#define DA_UPD_QG 16  // lanes per partner row (16: four partners per wavefront; 8: eight -- every wave instruction then serves twice as many partners, but a row list
+                      // takes twice the chunks and a bucket two slots per lane: measured (MI355X, round 6, C3 batch / one chain) 32.5 / 24.2 us per step against 30.6 / 20.3)
+#endif
+constexpr int QG = DA_UPD_QG, QN = WAVE / QG;  // lanes per partner, partners per wavefront
+constexpr int QG_LOG2 = QG == 16 ? 4 : 3, SPL = (int)BUCKET / QG, HL = QG / 2;  // key slots of a bucket per lane; lanes per block in the re-evaluation
+constexpr uint32_t QMASK = (1u << QG) - 1u, HMASK = (1u << HL) - 1u;
+static_assert(QG == 16 || QG == 8, "a partner row is handled by one DPP row or half a row");
 
 __device__ __forceinline__ unsigned long long row_max_u64(unsigned long long v) {  // max over each 16-lane row, valid in lane 15 of the row
     v = dpp_max_u64<DPP_ROW_SHR1, 0xF>(v);
@@ -1808,10 +1815,10 @@ __device__ __forceinline__ unsigned long long row_max_u64(unsigned long long v) 
 }
 
 constexpr int DPP_QUAD_XOR1 = 0xB1, DPP_QUAD_XOR2 = 0x4E, DPP_ROW_HALF_MIRROR = 0x141;  // quad_perm:[1,0,3,2], quad_perm:[2,3,0,1], lane i <-> 7 - i of its eight
-__device__ __forceinline__ unsigned long long half_row_max_u64(unsigned long long v) {  // max over each group of EIGHT lanes, in all of them (three butterfly steps)
+template <int LANES> __device__ __forceinline__ unsigned long long part_row_max_u64(unsigned long long v) {  // max over each group of EIGHT / FOUR lanes, in all of them (butterfly steps)
     v = dpp_max_u64<DPP_QUAD_XOR1, 0xF>(v);
     v = dpp_max_u64<DPP_QUAD_XOR2, 0xF>(v);
-    v = dpp_max_u64<DPP_ROW_HALF_MIRROR, 0xF>(v);
+    if constexpr (LANES == 8) v = dpp_max_u64<DPP_ROW_HALF_MIRROR, 0xF>(v);
     return v;
 }
 
@@ -1889,7 +1896,7 @@ __device__ __forceinline__ void update_partners(ChainDev *g, const UpdStep<Cell>
                                                 const RowInfo &rnew, unsigned int &found, unsigned int &inserts, unsigned int &deletes) {
     using F = RowFmt<Cell>;
     using Entry = typename F::Entry;
-    constexpr int HW = sizeof(Cell) == 4 ? 4 : 8;  // count words per lane (a block's words over EIGHT lanes): narrow layout Kpad / 2 <= 24 words, wide <= 60
+    constexpr int HW = ((sizeof(Cell) == 4 ? 24 : 60) + HL - 1) / HL;  // count words per lane (a block's words over its HL lanes): narrow layout Kpad / 2 <= 24 words, wide <= 60
     const Ctx &c = u.c;
     const uint32_t A = u.A, B = u.B, Nw = u.Nw;
     const int m = u.m, n_in = u.n_in, pk_shift = u.shift, pk_sub = u.sub;
@@ -1901,7 +1908,7 @@ __device__ __forceinline__ void update_partners(ChainDev *g, const UpdStep<Cell>
     uint32_t *s_cnt = s.cnt;
     const int nb = c.n_bits, Kpad = c.Kpad, K = c.K;
     const int lane = lane_id();
-    const int q = lane >> 4, l = lane & (QG - 1), qsh = q * QG;
+    const int q = lane >> QG_LOG2, l = lane & (QG - 1), qsh = q * QG;
     const bool same = A == B;
     uint32_t *dA = s_cnt + (size_t)q * 3 * Kpad, *dB = dA + Kpad, *cN = dB + Kpad;  // this group's counters
     const int KW = Kpad / 2;  // 32-bit words of counts per block (two u16 counts each)
@@ -1925,8 +1932,12 @@ __device__ __forceinline__ void update_partners(ChainDev *g, const UpdStep<Cell>
         const uint32_t lA = min(A, pr), hA = max(A, pr), lB = min(B, pr), hB = max(B, pr);
         const unsigned long long keyA = pack_pair(lA, hA), keyB = pack_pair(lB, hB);
         const uint32_t baseA = (hash_pair(lA, hA) & ~(BUCKET - 1)) & c.cmask, baseB = (hash_pair(lB, hB) & ~(BUCKET - 1)) & c.cmask;
-        const unsigned long long kA = valid ? c.hkey[baseA + l] : KEY_TOMB;
-        const unsigned long long kB = (valid && !same) ? c.hkey[baseB + l] : KEY_TOMB;
+        unsigned long long kA[SPL], kB[SPL];  // (16 slots of a bucket over the group's lanes: one or two -- adjacent -- per lane)
+#pragma unroll
+        for (int t = 0; t < SPL; ++t) {
+            kA[t] = valid ? c.hkey[baseA + l * SPL + t] : KEY_TOMB;
+            kB[t] = (valid && !same) ? c.hkey[baseB + l * SPL + t] : KEY_TOMB;
+        }
         Entry e[CH];
 #pragma unroll
         for (int u = 0; u < CH; ++u) {
@@ -1937,18 +1948,35 @@ __device__ __forceinline__ void update_partners(ChainDev *g, const UpdStep<Cell>
         // ---- resolve the probes (per group: 16 bits of the wave ballots)
         int sA = SLOT_NONE, sB = SLOT_NONE;
         {
-            const uint32_t hitA = (uint32_t)(__ballot(kA == keyA) >> qsh) & 0xFFFFu, empA = (uint32_t)(__ballot(kA == KEY_EMPTY) >> qsh) & 0xFFFFu;
-            const uint32_t hitB = (uint32_t)(__ballot(kB == keyB) >> qsh) & 0xFFFFu, empB = (uint32_t)(__ballot(kB == KEY_EMPTY) >> qsh) & 0xFFFFu;
+            // which of a lane's slots holds the key (a key sits in one slot at most), and whether the bucket has an EMPTY slot
+            bool emp_a = false, emp_b = false;
+            int at_a = -1, at_b = -1;
+#pragma unroll
+            for (int t = 0; t < SPL; ++t) {
+                at_a = kA[t] == keyA ? t : at_a;
+                at_b = kB[t] == keyB ? t : at_b;
+                emp_a |= kA[t] == KEY_EMPTY;
+                emp_b |= kB[t] == KEY_EMPTY;
+            }
+            const uint32_t hitA = (uint32_t)(__ballot(at_a >= 0) >> qsh) & QMASK, empA = (uint32_t)(__ballot(emp_a) >> qsh) & QMASK;
+            const uint32_t hitB = (uint32_t)(__ballot(at_b >= 0) >> qsh) & QMASK, empB = (uint32_t)(__ballot(emp_b) >> qsh) & QMASK;
+            // (SPL == 2: the slot inside the hit lane's pair comes from that lane; all lanes take part in the exchange)
+            int ta = 0, tb = 0;
+            if constexpr (SPL > 1) {
+                ta = __shfl(at_a, hitA ? qsh + ctz32(hitA) : lane);
+                tb = __shfl(at_b, hitB ? qsh + ctz32(hitB) : lane);
+            }
             if (valid) {
-                sA = hitA ? (int)(baseA + (uint32_t)ctz32(hitA)) : (empA ? SLOT_NONE : SLOT_SLOW);
-                if (!same) sB = hitB ? (int)(baseB + (uint32_t)ctz32(hitB)) : (empB ? SLOT_NONE : SLOT_SLOW);
+                sA = hitA ? (int)(baseA + (uint32_t)(ctz32(hitA) * SPL + ta)) : (empA ? SLOT_NONE : SLOT_SLOW);
+                if (!same) sB = hitB ? (int)(baseB + (uint32_t)(ctz32(hitB) * SPL + tb)) : (empB ? SLOT_NONE : SLOT_SLOW);
             }
         }
         UPD_TIMER_MARK(1)  // reference + list + table probes
         // ---- round trip 3: the payload lines of the blocks that exist.  The two blocks of a partner -- (A, r) and (B, r) -- are handled SIDE BY SIDE:
-        // lanes 0-7 of the group take A's block, lanes 8-15 B's, so that one pass of the instruction stream below re-evaluates both (round 6:
-        // one pass per block was twice the instructions; batch 31.1 -> 30.7 us per step); a lane holds the header of its block (16 bytes) and every eighth count word
-        const int half = l >> 3, hl = l & 7;
+        // the lower half of the group's lanes takes A's block, the upper half B's, so that one pass of the instruction stream below re-evaluates both
+        // (round 6: one pass per block was twice the instructions; batch 31.1 -> 30.7 us per step); a lane holds the header of its block (16 bytes)
+        // and every HL-th count word
+        const int half = l / HL, hl = l % HL;
         const int sX = half ? sB : sA;
         const unsigned long long keyX = half ? keyB : keyA;
         const da_i4 z4 = da_i4{0, 0, 0, 0};
@@ -1956,7 +1984,7 @@ __device__ __forceinline__ void update_partners(ChainDev *g, const UpdStep<Cell>
         uint32_t wX[HW];
 #pragma unroll
         for (int u = 0; u < HW; ++u) {
-            const int j = hl + u * 8;
+            const int j = hl + u * HL;
             wX[u] = (sX >= 0 && j < KW) ? reinterpret_cast<const DA_GLOBAL uint32_t *>(blk_ptr(c, sX) + 16)[j] : 0u;
         }
         lds_fence();  // counters are zero
@@ -2004,7 +2032,7 @@ __device__ __forceinline__ void update_partners(ChainDev *g, const UpdStep<Cell>
         lds_fence();
         int fnew = 0;  // a block (partner, new row) is created when one of its counts reached 2
         for (int k = l; k < K; k += QG) fnew |= cN[k] >= 2u;
-        const bool gnew = valid && (((uint32_t)(__ballot(fnew != 0) >> qsh) & 0xFFFFu) != 0);
+        const bool gnew = valid && (((uint32_t)(__ballot(fnew != 0) >> qsh) & QMASK) != 0);
         UPD_TIMER_MARK(2)  // pair enumeration
         // ---- re-evaluate both blocks at once: two counts per lane and word, reduction inside the eight lanes of a block, their last lane publishes
         {
@@ -2016,7 +2044,7 @@ __device__ __forceinline__ void update_partners(ChainDev *g, const UpdStep<Cell>
             int alive = 0;
 #pragma unroll
             for (int u = 0; u < HW; ++u) {
-                const int j = hl + u * 8;
+                const int j = hl + u * HL;
                 if (has && j < KW) {
                     const uint32_t o0 = wX[u] & 0xFFFFu, o1 = wX[u] >> 16;
                     const uint32_t n0 = o0 - d[2 * j], n1 = o1 - d[2 * j + 1];
@@ -2029,10 +2057,10 @@ __device__ __forceinline__ void update_partners(ChainDev *g, const UpdStep<Cell>
                     best = c1 > best ? c1 : best;
                 }
             }
-            best = half_row_max_u64(best);  // all lanes take part (the DPP source lanes must be active); every lane of a block's eight holds its result
-            const bool any_alive = (((uint32_t)(__ballot(alive != 0) >> (qsh + 8 * half)) & 0xFFu) != 0);
-            if (has && hl == 7) block_commit(c, sX, keyX, BlkHdr{ov, dl, (uint32_t)hdX.z, (uint32_t)hdX.w}, best, any_alive, false);
-            deletes += (unsigned)__popcll(__ballot(has && hl == 7 && !any_alive));  // (wave-uniform: the blocks this pass deleted, tallied once per workgroup)
+            best = part_row_max_u64<HL>(best);  // all lanes take part (the DPP source lanes must be active); every lane of a block's HL holds its result
+            const bool any_alive = (((uint32_t)(__ballot(alive != 0) >> (qsh + HL * half)) & HMASK) != 0);
+            if (has && hl == HL - 1) block_commit(c, sX, keyX, BlkHdr{ov, dl, (uint32_t)hdX.z, (uint32_t)hdX.w}, best, any_alive, false);
+            deletes += (unsigned)__popcll(__ballot(has && hl == HL - 1 && !any_alive));  // (wave-uniform: the blocks this pass deleted, tallied once per workgroup)
         }
         UPD_TIMER_MARK(3)  // block updates
         // ---- rare: blocks beyond their first bucket, block creation -- the whole wave, one group at a time
@@ -2166,7 +2194,7 @@ __device__ __forceinline__ void update_body(ChainDev *gq, bool in_range, int blo
     const int total_waves = grid_y * NWV, gw = block_y * NWV + wid;
     // ---- ONE vector round trip: the group's first partner reference and the new row's record leave together with the
     // hand-off of k_iter_select (they used to wait behind the hand-off barrier: two more dependent round trips)
-    const unsigned long long ref0 = gw * QN + (lane >> 4) < u.n_partners ? u.plist[gw * QN + (lane >> 4)] : 0ull;
+    const unsigned long long ref0 = gw * QN + (lane >> QG_LOG2) < u.n_partners ? u.plist[gw * QN + (lane >> QG_LOG2)] : 0ull;
     const RowInfo rnew = load_row(u.c.rows, u.Nw);
     __shared__ unsigned int s_stat[3];
     if (tid < 3) s_stat[tid] = 0;
