@@ -448,7 +448,13 @@ def run_c4(args):
         gs = max(int(stats.get('greedy_steps', 0)), 1)
         line['engine'] = {'greedy_steps': int(stats.get('greedy_steps', 0)), 'us_per_greedy_step': 1e6 * per / gs, 'allreduce_calls_per_solve': int(stats.get('allreduce_calls', 0)),
                           'exchanged_bytes_per_greedy_step_and_rank': 4.0 * exchanged / gs, 'transport': transport,
-                          'note': 'latency-bound by construction: two collectives and one host synchronisation per greedy step (DESIGN.md section 7); the layout that scales is the instance shard of the default workload'}
+                          'note': 'latency-bound by construction: two collectives per greedy step with the union size read by the host in between (DESIGN.md section 7); the layout that scales is the instance shard of the default workload'}
+    try:  # RCCL writes a version banner through the C library's buffered stdout at communicator set-up: out first, so that the JSON line is the LAST line
+        import ctypes
+
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
     print(json.dumps(line), flush=True)
 
 

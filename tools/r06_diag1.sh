@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 6, first GPU call: sanity (GPU suite without the two RCCL scripts), where a chain's step goes (-DDA_STEP_CLOCKS builds), the group-count A/B,
 # dependent-load latency at cache-sized footprints, and the RCCL set-up probe.  Everything bounded.
-cd "$GRAFT_REPO_ROOT"; O=gpurun_out/r06_first; mkdir -p $O
+cd "$GRAFT_REPO_ROOT"; O=gpurun_out/r06_diag1; mkdir -p $O
 nproc > $O/host.txt; /opt/rocm/bin/rocm-smi --showproductname 2>/dev/null | head -12 >> $O/host.txt
 timeout 500 python -m pytest tests -m gpu -x -q -k "not rccl_transport_one_rank and not torch_nccl_paths_one_rank" > $O/gpu_suite.txt 2>&1; tail -2 $O/gpu_suite.txt
 for spec in clk:64 clk:32 clk:8 clk:1 clk2048:64 clk2048:1; do

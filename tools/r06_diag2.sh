@@ -2,7 +2,7 @@
 # Round 6, second GPU call: the engine without the in-launch wait (pick found by the substitution block itself), 2048 group records: GPU suite,
 # step clocks under several geometries, A/B timing against the round-5 library, the two one-rank RCCL scripts five times from inside a pytest
 # process that holds the GPU (the condition under which round 5 saw the set-up hang).
-cd "$GRAFT_REPO_ROOT"; O=gpurun_out/r06_second; mkdir -p $O
+cd "$GRAFT_REPO_ROOT"; O=gpurun_out/r06_diag2; mkdir -p $O
 timeout 600 python -m pytest tests -m gpu -x -q -k "not rccl_transport_one_rank and not torch_nccl_paths_one_rank" > $O/gpu_suite.txt 2>&1; tail -2 $O/gpu_suite.txt
 clk() { echo "== $1 batch $2 $3" >> $O/step_clocks.txt; env $3 STEP_CLOCKS=1 DA4ML_HIP_LIB=ab_libs/lib_$1.so timeout 120 python tests/gpu_profile.py 256 $2 2>&1 | grep "step clocks\|us/iter" >> $O/step_clocks.txt; }
 clk clk 64; clk clk 1; clk clk512 64; clk clk512 1

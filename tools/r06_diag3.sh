@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 6, third GPU call: where the batch's step time goes ALONG the chain (step clocks over four windows, batch 64 and one chain), the instruction
 # cache (PMC pass + the alternating-launch probe), hipExtAnyOrderLaunch on gfx950.
-cd "$GRAFT_REPO_ROOT"; O=gpurun_out/r06_third; mkdir -p $O
+cd "$GRAFT_REPO_ROOT"; O=gpurun_out/r06_diag3; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for w in A B C D; do for b in 64 1; do
   echo "== window $w batch $b" >> $O/step_clock_windows.txt

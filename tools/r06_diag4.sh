@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 6, sixth GPU call: k_iter_update at 6 / 8 wavefronts per SIMD (spilling) in the slot-saturated early windows of the chain; two processes per GPU
-cd "$GRAFT_REPO_ROOT"; O=gpurun_out/r06_sixth; mkdir -p $O
+cd "$GRAFT_REPO_ROOT"; O=gpurun_out/r06_diag4; mkdir -p $O
 for l in clkA clkA_o6 clkA_o8 clkB clkB_o6 clkB_o8; do
   echo "== $l batch 64" >> $O/occ_windows.txt
   STEP_CLOCKS=1 DA4ML_HIP_LIB=ab_libs/lib_$l.so timeout 120 python tests/gpu_profile.py 256 64 2>&1 | grep "step clocks\|us/iter" >> $O/occ_windows.txt

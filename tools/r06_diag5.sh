@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 6, seventh GPU call: what the end of a kernel costs as a function of what it wrote (gap probe, second part); kernel-level gaps of the loop
 # from the profiler's own timestamps (one chain and the batch)
-cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"; O=gpurun_out/r06_seventh; mkdir -p $O
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"; O=gpurun_out/r06_diag5; mkdir -p $O
 timeout 300 tools/micro/gap_probe > $O/gap_probe.txt 2>&1; tail -6 $O/gap_probe.txt
 export DA4ML_HIP_LIB=ab_libs/lib_cur.so
 for B in 1 64; do
