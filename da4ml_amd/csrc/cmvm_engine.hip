@@ -2063,8 +2063,83 @@ __device__ __forceinline__ void update_partners(ChainDev *g, const UpdStep<Cell>
             deletes += (unsigned)__popcll(__ballot(has && hl == HL - 1 && !any_alive));  // (wave-uniform: the blocks this pass deleted, tallied once per workgroup)
         }
         UPD_TIMER_MARK(3)  // block updates
-        // ---- rare: blocks beyond their first bucket, block creation -- the whole wave, one group at a time
-        const unsigned long long rare = __ballot(valid && (sA == SLOT_SLOW || sB == SLOT_SLOW || gnew));
+        // ---- block creation, ALL creating groups of the wavefront at once (a group = one new block (partner, new row)): the first bucket of the key
+        // is probed by the group's lanes, its first free slot claimed by compare-and-swap (lost to another claimant: the next free one), the counts
+        // come from the group's LDS counters two per lane, the best key by a reduction inside the DPP row.  One instruction stream for up to QN
+        // creations instead of one wave-wide table_insert after the other: the launch lasts as long as its slowest wave, and in the first thousands
+        // of steps that is a wave with four creations in a pass (round 6: batch 30.4 -> 29.5 us per step; steps 0 - 2000: update 35.1 -> 28.7 us).
+        // A group whose first bucket has no free slot takes the wave-wide path below.
+        bool gslow = false;  // this group's creation is left to table_insert
+        if (__ballot(gnew)) {
+            const unsigned long long keyN = pack_pair(pr, Nw);  // (the partner is older than the new row)
+            const uint32_t baseN = (hash_pair(pr, Nw) & ~(BUCKET - 1)) & c.cmask;
+            unsigned long long kN[SPL];
+#pragma unroll
+            for (int t = 0; t < SPL; ++t) kN[t] = gnew ? c.hkey[baseN + l * SPL + t] : 0ull;
+            const RowInfo rp = load_row(c.rows, gnew ? pr : 0u);
+            int pick_t = -1;  // a free slot of this lane: EMPTY, or a tombstone of an earlier launch
+#pragma unroll
+            for (int t = SPL - 1; t >= 0; --t)
+                if (gnew && (kN[t] == KEY_EMPTY || (kN[t] >= KEY_TOMB_LO && kN[t] != c.tomb))) pick_t = t;
+            uint32_t av = (uint32_t)(__ballot(pick_t >= 0) >> qsh) & QMASK;
+            int nslot = -1;
+            bool trying = gnew;
+            while (__ballot(trying)) {
+                const int cand = av ? ctz32(av) : -1;
+                int ok = 0;
+                if (trying && l == cand) {
+                    const unsigned long long was = pick_t == 0 ? kN[0] : kN[SPL - 1];
+                    ok = atomicCAS(gen(&c.hkey[baseN + l * SPL + pick_t]), was, keyN) == was;
+                }
+                const bool won = (((uint32_t)(__ballot(ok != 0) >> qsh)) & QMASK) != 0;
+                int tsel = 0;
+                if constexpr (SPL > 1) tsel = __shfl(pick_t, cand >= 0 ? qsh + cand : lane);
+                if (trying) {
+                    if (cand < 0) {
+                        trying = false;
+                        gslow = true;
+                    } else if (won) {
+                        nslot = (int)(baseN + (uint32_t)(cand * SPL + tsel));
+                        trying = false;
+                    } else
+                        av &= av - 1;
+                }
+            }
+            const bool made = nslot >= 0;
+            const int ovn = n_overlap(rp, rnew);
+            const float dln = fabsf(rp.lat - rnew.lat);
+            unsigned long long bestn = 0;
+            constexpr int CWN = ((sizeof(Cell) == 4 ? 24 : 60) + QG - 1) / QG;  // count words per lane
+#pragma unroll
+            for (int u = 0; u < CWN; ++u) {
+                const int j = l + u * QG;
+                if (made && j < KW) {
+                    const uint32_t n0 = cN[2 * j], n1 = cN[2 * j + 1];  // (zero beyond K: nothing ever counts there)
+                    if ((n0 | n1) > 65535u) c.g->error = E_COUNT_OVERFLOW;
+                    reinterpret_cast<DA_GLOBAL uint32_t *>(blk_ptr(c, nslot) + 16)[j] = (n0 & 0xFFFFu) | (n1 << 16);
+                    const uint32_t r0 = entry_rank(n0, ovn, dln, c.method), r1 = entry_rank(n1, ovn, dln, c.method);
+                    const unsigned long long c0 = r0 ? (((unsigned long long)r0 << 8) | (unsigned)(2 * j)) : 0ull;
+                    const unsigned long long c1 = r1 ? (((unsigned long long)r1 << 8) | (unsigned)(2 * j + 1)) : 0ull;
+                    bestn = c0 > bestn ? c0 : bestn;
+                    bestn = c1 > bestn ? c1 : bestn;
+                }
+            }
+            bestn = part_row_max_u64<8>(bestn);  // (eight lanes, then the two halves of the group)
+            if constexpr (QG == 16) bestn = dpp_max_u64<0x140, 0xF>(bestn);  // row_mirror: lane i <-> 15 - i
+            if (made && l == QG - 1) {
+                const uint32_t rank = (uint32_t)(bestn >> 8), bidx = (uint32_t)(bestn & 0xFF);
+                store_hdr(c, nslot, ovn, dln, rank, bidx);
+                c.hrank[nslot] = rank;
+                hidx_ptr(c)[nslot] = (uint8_t)bidx;
+                if (rank) {
+                    group_note(c, nslot, 0ull, bound_word(rank, tie_word(pr, Nw, (int)bidx)));
+                    fold_entry(c, rank, tie_word(pr, Nw, (int)bidx));
+                }
+            }
+            inserts += (unsigned)__popcll(__ballot(made && l == 0));
+        }
+        // ---- rare: blocks beyond their first bucket (look-up, or creation in a full bucket) -- the whole wave, one group at a time
+        const unsigned long long rare = __ballot(valid && (sA == SLOT_SLOW || sB == SLOT_SLOW || gslow));
         found += (unsigned)__popcll(__ballot(l == 0 && sA >= 0)) + (unsigned)__popcll(__ballot(l == 0 && sB >= 0));
         if (rare) {
 #pragma unroll 1
@@ -2072,7 +2147,7 @@ __device__ __forceinline__ void update_partners(ChainDev *g, const UpdStep<Cell>
                 if (!((rare >> (qq * QG)) & 1ull)) continue;
                 const uint32_t rpr = (uint32_t)__builtin_amdgcn_readlane((int)pr, qq * QG);
                 const int rsA = __builtin_amdgcn_readlane(sA, qq * QG), rsB = __builtin_amdgcn_readlane(sB, qq * QG);
-                const int rnewb = __builtin_amdgcn_readlane((int)gnew, qq * QG);
+                const int rnewb = __builtin_amdgcn_readlane((int)gslow, qq * QG);
                 const uint32_t *rdA = s_cnt + (size_t)qq * 3 * Kpad, *rdB = rdA + Kpad, *rcN = rdB + Kpad;
                 if (rsA == SLOT_SLOW) {
                     const uint32_t lo = min(A, rpr), hi = max(A, rpr);
