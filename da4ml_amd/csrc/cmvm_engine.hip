@@ -116,9 +116,46 @@ constexpr int MAX_GROUPS = DA_MAX_GROUPS;
 #define SEL_TIMER_MARK(i) tp[i] = clock64();
 #define SEL_TIMER_FLUSH \
     if (DA_TIMED_STEP(iter)) for (int q = 0; q < 7; ++q) g->st_phase[q] += (unsigned long long)(tp[q + 1] - tp[q]);
+#define UPD_TIMER_PASS_END UPD_TIMER_MARK(4)
+#elif defined(DA_UPD_TAIL)
+// -DDA_UPD_TAIL (diagnostic build, tools/gpu_tail.py): how long the passes of k_iter_update's wavefronts last, by kind -- st_phase[7] cycles of all
+// passes, [8] passes, [9] cycles / [10] number of the passes with a rare case (a key beyond its first bucket, a creation in a full bucket), [11] passes
+// with a block creation and no rare case, st_qdiag[0] their cycles, [1] / [4] passes longer than 20 k / 40 k cycles, [5] lanes of groups with a rare case
+#ifndef DA_TIMER_STEP_LO
+#define DA_TIMER_STEP_LO 0
+#endif
+#ifndef DA_TIMER_STEP_HI
+#define DA_TIMER_STEP_HI 0x7FFFFFFF
+#endif
+#define DA_TIMED_STEP(t) ((t) >= DA_TIMER_STEP_LO && (t) < DA_TIMER_STEP_HI)
+#define UPD_TIMER_DECL long long up[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, u0 = clock64(), u1;
+#define UPD_TIMER_MARK(i)
+#define UPD_TIMER_PASS_END                                                        \
+    {                                                                             \
+        u1 = clock64();                                                           \
+        const long long dt = u1 - u0;                                             \
+        const bool cr = __ballot(gnew) != 0;                                      \
+        up[0] += dt, up[1] += 1;                                                  \
+        if (rare) up[2] += dt, up[3] += 1, up[8] += __popcll(rare);               \
+        if (!rare && cr) up[4] += 1, up[5] += dt;                                 \
+        up[6] += dt > 20000, up[7] += dt > 40000;                                 \
+        u0 = clock64();                                                           \
+    }
+#define UPD_TIMER_FLUSH                                                           \
+    if (lane == 0 && DA_TIMED_STEP(g->iter - 1)) {                                \
+        for (int q = 0; q < 5; ++q) atomicAdd(&g->st_phase[7 + q], (unsigned long long)up[q]); \
+        atomicAdd(&g->st_qdiag[0], (unsigned long long)up[5]);                    \
+        atomicAdd(&g->st_qdiag[1], (unsigned long long)up[6]);                    \
+        atomicAdd(&g->st_qdiag[4], (unsigned long long)up[7]);                    \
+        atomicAdd(&g->st_qdiag[5], (unsigned long long)up[8]);                    \
+    }
+#define SEL_TIMER_DECL
+#define SEL_TIMER_MARK(i)
+#define SEL_TIMER_FLUSH
 #else
 #define UPD_TIMER_DECL
 #define UPD_TIMER_MARK(i)
+#define UPD_TIMER_PASS_END
 #define UPD_TIMER_FLUSH
 #define SEL_TIMER_DECL
 #define SEL_TIMER_MARK(i)
@@ -1862,14 +1899,14 @@ template <class Cell> __device__ __forceinline__ UpdStep<Cell> load_upd_step(Cha
 }
 // LDS of an update worker: the hand-off of the selection (consumed digits of A and B [n_out each], the substituted columns
 // [n_out], column -> 1 + index of the substituted column [n_out]) -- shared by the waves that copied it together -- and ONE
-// wave's per-partner counters [QN][3][Kpad]
+// wave's per-partner counters [QN][3][Kpad] + a spare vector [Kpad] (counts of blocks that do not exist)
 template <class Cell> struct UpdLds {
     Cell *mA, *mB;
     int *col;
     uint16_t *cmap;
     uint32_t *cnt;
     static __device__ __forceinline__ size_t table_bytes(int n_out) { return (size_t)n_out * (2 * sizeof(Cell) + 4 + 2); }
-    static __device__ __forceinline__ size_t wave_bytes(int Kpad) { return (size_t)QN * 3 * Kpad * 4; }
+    static __device__ __forceinline__ size_t wave_bytes(int Kpad) { return (size_t)(QN * 3 + 1) * Kpad * 4; }  // (+ one spare vector)
     __device__ __forceinline__ void carve(unsigned char *tables, unsigned char *counters, int n_out) {
         mA = reinterpret_cast<Cell *>(tables);
         mB = mA + n_out;
@@ -1988,39 +2025,48 @@ __device__ __forceinline__ void update_partners(ChainDev *g, const UpdStep<Cell>
             wX[u] = (sX >= 0 && j < KW) ? reinterpret_cast<const DA_GLOBAL uint32_t *>(blk_ptr(c, sX) + 16)[j] : 0u;
         }
         lds_fence();  // counters are zero
-        // ---- digit pairs lost with A's / B's consumed digits and gained with the new row: a lane per list entry
+        // ---- digit pairs lost with A's / B's consumed digits and gained with the new row: a lane per list entry.
+        // The digit pairs (partner digit, consumed A-role digit) are walked ONCE for all the blocks they count in (round 6; three walks,
+        // one per block, were most of this phase's instructions):
+        //   * gained with the new row, whose cell in this column IS ma (the partner is the row with the smaller id): key (q - p, signs);
+        //   * lost with A: the same key when the partner is also below A, the mirrored one (shift negated) otherwise;
+        //   * lost with the B-role digit that went with the A-role one: it sits `shift` positions further, its sign flipped when the pick
+        //     subtracts (substitute_column, cmvm_core.h: mb = ma moved by shift, also when A and B are one row) -- in B's block, or in A's
+        //     when the pick is a row with itself.
+        // The body of the walk is straight-line (21 instructions per digit pair, 35 with a branch per block): what depends on the partner
+        // only -- which blocks exist, which are mirrored, where the B-role key sits -- is folded into three counter addresses and two signs in
+        // front of it (a block that does not exist counts into a spare vector of the wavefront that nobody reads), the consumed digits (one
+        // per column, hardly ever more) are the OUTER loop.  Batch 29.6 -> 29.25 us per step, one chain 19.8 -> 19.65 (MI355X).
+        const bool hasA = sA != SLOT_NONE, hasB = same ? hasA : sB != SLOT_NONE;
+        const bool mirA = A < pr, mirB = same ? mirA : B < pr;
+        const int Wk4 = 4 * (2 * nb - 1), sgnA4 = mirA ? -4 : 4, sgnB4 = mirB ? -4 : 4, tau = pk_sub ? -1 : 1;  // (byte offsets into the counters)
+        unsigned char *const spare = reinterpret_cast<unsigned char *>(s_cnt + (size_t)QN * 3 * Kpad);
+        unsigned char *const pN = reinterpret_cast<unsigned char *>(cN + (nb - 1));
+        unsigned char *const pA = (hasA ? reinterpret_cast<unsigned char *>(dA) : spare) + 4 * (nb - 1);
+        unsigned char *const pB = (hasB ? reinterpret_cast<unsigned char *>(same ? dA : dB) : spare) + 4 * (nb - 1) + (pk_sub ? Wk4 : 0) + sgnB4 * pk_shift;
+        auto bump = [](unsigned char *at) { atomicAdd(reinterpret_cast<uint32_t *>(at), 1u); };
         auto pairs_of = [&](const Entry en) {
+            using O = CellOps<Cell>;
             const Cell x = F::cell(en);
             const int at = x ? (int)s_cmap[F::col(en)] : 0;
             if (!at) return;  // empty cell, or a column that was not substituted
             const Cell ma = s_mA[at - 1];
-            // The digit pairs (partner digit, consumed A-role digit) are walked ONCE for all the blocks they count in (round 6; three walks,
-            // one per block, were most of this phase's instructions):
-            //   * gained with the new row, whose cell in this column IS ma (the partner is the row with the smaller id): key (q - p, signs);
-            //   * lost with A: the same key when the partner is also below A, the mirrored one (shift negated) otherwise;
-            //   * lost with the B-role digit that went with the A-role one: it sits `shift` positions further, its sign flipped when the pick
-            //     subtracts (substitute_column, cmvm_core.h: mb = ma moved by shift, also when A and B are one row) -- in B's block, or in A's
-            //     when the pick is a row with itself.
-            {
-                using O = CellOps<Cell>;
-                const uint32_t xm = O::minus(x), hm = O::minus(ma), ha = O::plus(ma) | hm;
-                const bool hasA = sA != SLOT_NONE, hasB = same ? hasA : sB != SLOT_NONE;
-                const bool mirA = A < pr, mirB = same ? mirA : B < pr;
-                uint32_t *dBx = same ? dA : dB;
-                uint32_t la = O::plus(x) | xm;
+            const uint32_t xm = O::minus(x), hm = O::minus(ma), la0 = O::plus(x) | xm;
+            uint32_t h = O::plus(ma) | hm;
+            while (h) {
+                const int q_ = ctz32(h);
+                h &= h - 1;
+                const uint32_t xq = (hm >> q_) & 1u ? ~xm : xm;  // bit p: the signs of the two digits differ
+                uint32_t la = la0;
                 while (la) {
                     const int p_ = ctz32(la);
                     la &= la - 1;
-                    const int sl = (int)((xm >> p_) & 1u);
-                    uint32_t h = ha;
-                    while (h) {
-                        const int q_ = ctz32(h);
-                        h &= h - 1;
-                        const int sg = sl ^ (int)((hm >> q_) & 1u), d = q_ - p_, db = d + pk_shift;
-                        atomicAdd(&cN[key_index(d, sg, nb)], 1u);
-                        if (hasA) atomicAdd(&dA[key_index(mirA ? -d : d, sg, nb)], 1u);
-                        if (hasB) atomicAdd(&dBx[key_index(mirB ? -db : db, sg ^ pk_sub, nb)], 1u);
-                    }
+                    int sgm = -(int)((xq >> p_) & 1u);
+                    pin_vgpr(sgm);  // (kept as a mask: the compiler otherwise turns the AND below into compare + move + select)
+                    const int d = q_ - p_, off = sgm & Wk4;  // key (d, sg) -> index sg (2 nb - 1) + d + nb - 1
+                    bump(pN + off + 4 * d);
+                    bump(pA + off + __mul24(d, sgnA4));
+                    bump(pB + __mul24(off, tau) + __mul24(d, sgnB4));
                 }
             }
         };
@@ -2175,7 +2221,7 @@ __device__ __forceinline__ void update_partners(ChainDev *g, const UpdStep<Cell>
                 }
             }
         }
-        UPD_TIMER_MARK(4)  // slow path + block creation
+        UPD_TIMER_PASS_END  // slow path + block creation
         lds_fence();  // the next pass overwrites the counters
     }
     UPD_TIMER_FLUSH
@@ -3109,7 +3155,7 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
             throw std::runtime_error("selection kernel needs " + std::to_string(s) + " bytes of dynamic LDS, the device leaves it " + std::to_string(sel2_lds_budget(im.device, geo[i].wide)) +
                                      " beside the kernel's static arrays (n_out too large)");
         sel_lds[w] = std::max(sel_lds[w], s);
-        upd_lds[w] = std::max(upd_lds[w], align_up(2 * no * cellb + no * 6, 16) + align_up((size_t)UPD_WAVES * QN * 3 * (size_t)geo[i].Kpad * 4, 16));  // UpdLds: hand-off tables | counters
+        upd_lds[w] = std::max(upd_lds[w], align_up(2 * no * cellb + no * 6, 16) + align_up((size_t)UPD_WAVES * (QN * 3 + 1) * (size_t)geo[i].Kpad * 4, 16));  // UpdLds: hand-off tables | counters
         pair_lds[w] = std::max(pair_lds[w], (size_t)4 * geo[i].Kpad * 4);
         max_pairs[w] = std::max(max_pairs[w], (long long)jobs[i].n_in * (jobs[i].n_in + 1) / 2);
     }

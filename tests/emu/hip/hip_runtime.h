@@ -188,6 +188,7 @@ inline void __threadfence_block() {}
 inline int __popc(unsigned x) { return __builtin_popcount(x); }
 inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 inline int __ffs(int x) { return __builtin_ffs(x); }
+inline int __mul24(int a, int b) { return a * b; }
 inline int __ffsll(long long x) { return __builtin_ffsll(x); }
 inline int __clz(int x) { return x ? __builtin_clz((unsigned)x) : 32; }
 inline int __clzll(long long x) { return x ? __builtin_clzll((unsigned long long)x) : 64; }
