@@ -1014,6 +1014,13 @@ std::vector<PipeResult> solve_batch_unique(Backend &be, const std::vector<Proble
                     c.phase = Candidate::DONE;
             }
         }
+        lap("results taken over");
+        // the round's device outputs (digits, picks, column lists: megabytes per chain) are released on the pool, not one after the other at the closing brace
+        parallel_for(outs.size(), [&](size_t k) {
+            outs[k] = ChainOut();
+            std::vector<int64_t>().swap(first_op[k]);
+        });
+        lap("round buffers released");
     }
 
     lap("candidate bookkeeping");
