@@ -72,6 +72,36 @@ int main(int argc, char **argv) {
         printf("\n  streams 0-3 together (the engine's choice): %.2f us -> %.2f in flight\n", t4, first4.size() * us / t4);
         return 0;
     }
+    if (argc > 1 && !strcmp(argv[1], "masked")) {  // four CU-masked streams (each gets an HSA queue of its own) created after `pre` ordinary ones were used
+        const int pre = argc > 2 ? atoi(argv[2]) : 9;
+        const double us = 25.0;
+        const long long ticks = (long long)(us * rate / 1000.0);
+        std::vector<hipStream_t> st(pre), ms(4);
+        for (auto &s : st) CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        for (auto s : st) hipLaunchKernelGGL(spin, dim3(32), dim3(256), 0, s, ticks, nullptr);
+        CK(hipDeviceSynchronize());
+        const bool quarter = argc > 3 && !strcmp(argv[3], "quarter");
+        for (int l = 0; l < 4; ++l) {
+            uint32_t m[8];
+            for (int w = 0; w < 8; ++w) m[w] = quarter ? (w / 2 == l ? 0xFFFFFFFFu : 0u) : 0xFFFFFFFFu;
+            CK(hipExtStreamCreateWithCUMask(&ms[l], 8, m));
+        }
+        printf("GPU_MAX_HW_QUEUES=%s: %d ordinary streams used, then four CU-masked streams (%s mask)\n", env ? env : "(default)", pre, quarter ? "64 CUs each" : "full");
+        for (int i = 0; i < 4; ++i) {
+            printf("  masked %d against masked:", i);
+            for (int j = 0; j < 4; ++j) printf("  %s", j <= i ? "." : (run_set({ms[i], ms[j]}, 60, ticks, 32) < 1.5 * us ? "1" : "2"));
+            printf("   against ordinary 0-%d:", pre - 1);
+            for (int j = 0; j < pre; ++j) printf("  %s", run_set({ms[i], st[j]}, 60, ticks, 32) < 1.5 * us ? "1" : "2");
+            printf("\n");
+        }
+        for (int blocks : {32, 512}) {
+            const double t = run_set(ms, 200, ticks, blocks);
+            printf("  the four masked streams together, %d blocks: %.2f us per kernel of a chain -> %.2f in flight\n", blocks, t, 4 * us / t);
+        }
+        const double t1 = run_set({ms[0]}, 200, ticks, 32);
+        printf("  one masked stream alone: %.2f us per kernel\n", t1);
+        return 0;
+    }
     const int K = argc > 1 ? atoi(argv[1]) : 2000;
     const double us = argc > 2 ? atof(argv[2]) : 10.0;
     const long long ticks = (long long)(us * rate / 1000.0);
