@@ -31,8 +31,8 @@
 //             {n_overlap, |dlat|, rank copy, index of the best key, K x u16 exact occurrence counts} -- a block update
 //             reads and writes ONE line instead of four arrays; hidx[C] u8 behind hrank: the best key's index once more, dense (the search
 //             reads rank, key and index of a whole group from three dense arrays)
-//   ub      [C / GS]       u64     bound word (rank << 32 | tie_word >> 23) of the best entry of a group of GS consecutive slots; gtie its
-//                                  exact tie word, glow the highest value an update lowered in the group, gdirty "tie word unknown"
+//   grec    [C / GS]       32 B    per group of GS consecutive slots: bound word (rank << 32 | tie_word >> 23) of its best entry, the highest value an
+//                                  update lowered in the group (glow), the best entry's exact tie word, flag "tie word unknown" (GroupRec)
 //
 // The reference keeps a sorted table of all pairs with count >= 2, purges every entry touching the two
 // substituted rows and regenerates their pairs against ALL rows every iteration.  Here the counts are
@@ -283,6 +283,16 @@ struct CandEntry {  // a table entry by value: selection rank and tie word (id1,
 constexpr int CAND_CAP = DA_CAND_CAP, TOUCH_CAP = DA_CAND_CAP;
 
 // Per-chain descriptor in device memory.  Pointers are raw device addresses into the arena.
+// Per group of GS consecutive table slots (the search sweeps all of them every step):
+struct alignas(32) GroupRec {
+    unsigned long long ub;    // bound word (rank << 32 | tie_word >> 23) of the group's best entry: tight unless `glow` reaches it
+    unsigned long long glow;  // the highest bound word a block's best entry had before an update LOWERED it, since the group was last verified: reaching the
+                              // group's bound it says the bound is stale (group_note)
+    unsigned long long gtie;  // full tie word of the group's best entry (valid while the group is clean)
+    uint32_t dirty;           // 0: the tie word is exact (and the bound, unless glow reaches it); 1: an entry rose, the tie word is unknown
+    uint32_t pad;
+};
+static_assert(sizeof(GroupRec) == 32, "group record");
 struct ChainDev {
     // geometry (constant after set-up)
     int n_in, n_out, n_bits, K, Kpad, method, adder_size, carry_size;
@@ -306,12 +316,7 @@ struct ChainDev {
     uint32_t *hrank;
     unsigned char *hblk;  // [C] payload lines of (1 << pb_log2) bytes
     int pb_log2;
-    unsigned long long *ub;
-    unsigned long long *gtie;  // [n_groups] full tie word of the group's best entry (valid while the group is clean)
-    unsigned long long *glow;  // [n_groups] the highest bound word a block's best entry had before an update LOWERED it, since the group was last
-                               // verified: reaching the group's bound it says the bound is stale (group_note)
-    uint32_t *gdirty;          // [n_groups] 0: the tie word of the group's best entry is exact (and the bound, unless glow reaches it); 1: an entry rose,
-                               // the tie word is unknown
+    GroupRec *grec;  // [n_groups] one 32-byte record per group of slots (two 16-byte loads per group in the search's sweep; an update's marks of a group land in ONE line)
     // per-iteration hand-off select -> update
     int *mcol;
     uint16_t *cmap;    // [n_out] 1 + index of a column among the substituted columns of this step, 0 = not substituted
@@ -468,9 +473,7 @@ struct Ctx {
     DA_GLOBAL unsigned long long *hkey;
     DA_GLOBAL uint32_t *hrank;
     DA_GLOBAL unsigned char *hblk;
-    DA_GLOBAL unsigned long long *ub;
-    DA_GLOBAL unsigned long long *glow;
-    DA_GLOBAL uint32_t *gdirty;
+    DA_GLOBAL GroupRec *grec;
     const DA_GLOBAL RowInfo *rows;
     ChainDev *g;  // derived from the kernel argument: already known to be global
     unsigned long long tomb;  // this launch's tombstone value
@@ -495,9 +498,7 @@ __device__ __forceinline__ Ctx make_ctx_raw(ChainDev *g, int launch_id) {
     c.hkey = (DA_GLOBAL unsigned long long *)g->hkey;
     c.hrank = (DA_GLOBAL uint32_t *)g->hrank;
     c.hblk = (DA_GLOBAL unsigned char *)g->hblk;
-    c.ub = (DA_GLOBAL unsigned long long *)g->ub;
-    c.glow = (DA_GLOBAL unsigned long long *)g->glow;
-    c.gdirty = (DA_GLOBAL uint32_t *)g->gdirty;
+    c.grec = (DA_GLOBAL GroupRec *)g->grec;
     c.rows = (const DA_GLOBAL RowInfo *)g->rows;
     c.g = g;
     c.rword = 0;
@@ -580,17 +581,17 @@ __device__ int table_claim(const Ctx &c, unsigned long long key, uint32_t h) {
 __device__ __forceinline__ void group_note(const Ctx &c, int slot, unsigned long long w_old, unsigned long long w_new) {
     const int grp = slot >> c.gs_log2;
     if (w_new > w_old) {
-        atomicMax(gen(&c.ub[grp]), w_new);
+        atomicMax(gen(&c.grec[grp].ub), w_new);
 #ifdef DA_AB_PLAIN_FLAG
-        c.gdirty[grp] = 1u;
+        c.grec[grp].dirty = 1u;
 #else
-        atomicOr(gen(&c.gdirty[grp]), 1u);
+        atomicOr(gen(&c.grec[grp].dirty), 1u);
 #endif
     } else {
 #ifdef DA_AB_NO_GLOW  // (A/B: the lazy scheme -- still exact, stale bounds are found when the floor meets them)
-        c.gdirty[grp] = 1u;
+        c.grec[grp].dirty = 1u;
 #else
-        atomicMax(gen(&c.glow[grp]), w_old);
+        atomicMax(gen(&c.grec[grp].glow), w_old);
 #endif
     }
 }
@@ -781,9 +782,7 @@ __global__ void __launch_bounds__(256) k_init_state(ChainDev *chains) {
     fill16(ch.stamp, sizeof(uint32_t) * (size_t)ch.rcap, 0u, t0, stride);
     fill16(ch.hkey, sizeof(unsigned long long) * (size_t)ch.C, 0xFFFFFFFFu, t0, stride);
     fill16(ch.hrank, sizeof(uint32_t) * (size_t)ch.C, 0u, t0, stride);
-    fill16(ch.ub, sizeof(unsigned long long) * (size_t)ch.n_groups, 0u, t0, stride);
-    fill16(ch.glow, sizeof(unsigned long long) * (size_t)ch.n_groups, 0u, t0, stride);
-    fill16(ch.gdirty, sizeof(uint32_t) * (size_t)ch.n_groups, 1u, t0, stride);
+    for (size_t i = t0; i < (size_t)ch.n_groups; i += stride) ch.grec[i] = GroupRec{0ull, 0ull, 0ull, 1u, 0u};
     fill16(ch.colbits, sizeof(uint32_t) * (size_t)ch.n_out * ch.cb_words, 0u, t0, stride);
 }
 
@@ -994,13 +993,12 @@ template <class Cell> __device__ __forceinline__ void search_body(ChainDev *g, i
     unsigned long long sp_word = g->spec[par ^ 1].word, sp_tie = g->spec[par ^ 1].tie;
     unsigned int cn_prev = g->c_n[par ^ 1];
     Ctx c = make_ctx_raw(g, 2 * step);
-    DA_GLOBAL unsigned long long *gtie_arr = (DA_GLOBAL unsigned long long *)g->gtie;
     const DA_GLOBAL da_u2 *rowoff = (const DA_GLOBAL da_u2 *)g->rowoff;
     const DA_GLOBAL CandEntry *cl_prev = (const DA_GLOBAL CandEntry *)&g->c_list[par ^ 1][0];
     DA_GLOBAL CandEntry *ll_out = (DA_GLOBAL CandEntry *)&g->l_list[par][0];
     pin_sgpr(was_done, had_error, n_groups, sp_word, sp_tie, cn_prev);
-    pin_sgpr(c.gs_log2, c.cmask, c.hkey, c.hrank, c.ub, c.glow, c.gdirty, c.rows);
-    pin_sgpr(gtie_arr, rowoff, cl_prev, ll_out);
+    pin_sgpr(c.gs_log2, c.cmask, c.hkey, c.hrank, c.grec, c.rows);
+    pin_sgpr(rowoff, cl_prev, ll_out);
     if (was_done || had_error != E_OK) return;  // (the substitution block stops the chain)
     __shared__ unsigned long long q_floor, q_red_tie[NW], q_ub[GPL][SEL2_THREADS];
     __shared__ uint32_t q_work[MAX_GROUPS];  // groups still to be read after round 0: index into q_ub | dirty << 31
@@ -1073,10 +1071,12 @@ template <class Cell> __device__ __forceinline__ void search_body(ChainDev *g, i
             for (int u = 0; u < GPL; ++u) {
                 const int q = wid * GPW + lane + u * WAVE;
                 const int qc = (lane + u * WAVE < GPW && q < n_groups) ? q : 0;
-                ubv[u] = c.ub[qc];
-                dv[u] = c.gdirty[qc];
-                gtr[u] = gtie_arr[qc];
-                glv[u] = c.glow[qc];
+                const DA_GLOBAL da_i4 *rp = reinterpret_cast<const DA_GLOBAL da_i4 *>(&c.grec[qc]);  // the record as two 16-byte loads
+                const da_i4 r0 = rp[0], r1 = rp[1];
+                ubv[u] = ((unsigned long long)(uint32_t)r0.y << 32) | (uint32_t)r0.x;
+                glv[u] = ((unsigned long long)(uint32_t)r0.w << 32) | (uint32_t)r0.z;
+                gtr[u] = ((unsigned long long)(uint32_t)r1.y << 32) | (uint32_t)r1.x;
+                dv[u] = (uint32_t)r1.z;
             }
 #pragma unroll
             for (int u = 0; u < GPL; ++u) {
@@ -1174,10 +1174,10 @@ template <class Cell> __device__ __forceinline__ void search_body(ChainDev *g, i
             if (dirty) {  // the group's bound and tie word, exact again
                 gt = wave_max_u64(gt);
                 if (lane == 0) {
-                    c.ub[grp] = grank ? bound_word(grank, gt) : 0ull;
-                    gtie_arr[grp] = gt;
-                    c.gdirty[grp] = 0;
-                    c.glow[grp] = 0;
+                    const unsigned long long nbw = grank ? bound_word(grank, gt) : 0ull;
+                    DA_GLOBAL da_i4 *wp = reinterpret_cast<DA_GLOBAL da_i4 *>(&c.grec[grp]);  // {bound, glow = 0} | {tie word, flag = 0}: two 16-byte stores
+                    wp[0] = da_i4{(int)(uint32_t)nbw, (int)(uint32_t)(nbw >> 32), 0, 0};
+                    wp[1] = da_i4{(int)(uint32_t)gt, (int)(uint32_t)(gt >> 32), 0, 0};
                 }
             }
             ++rescans;
@@ -1891,7 +1891,7 @@ template <class Cell> __device__ __forceinline__ UpdStep<Cell> load_upd_step(Cha
     u.rl = (const DA_GLOBAL Entry *)gq->rlist;
     u.plist = (const DA_GLOBAL unsigned long long *)gq->plist;
     pin_sgpr(u.done, u.n_partners, iter, u.m, u.n_in, u.A, u.B, u.Nw, u.shift, u.sub, u.mcol, u.mA, u.cmap, u.rl, u.plist);
-    pin_sgpr(u.c.n_out, u.c.n_bits, u.c.K, u.c.Kpad, u.c.method, u.c.gs_log2, u.c.pb_log2, u.c.cmask, u.c.windows, u.c.hkey, u.c.hrank, u.c.hblk, u.c.ub, u.c.glow, u.c.gdirty, u.c.rows);
+    pin_sgpr(u.c.n_out, u.c.n_bits, u.c.K, u.c.Kpad, u.c.method, u.c.gs_log2, u.c.pb_log2, u.c.cmask, u.c.windows, u.c.hkey, u.c.hrank, u.c.hblk, u.c.grec, u.c.rows);
     pin_sgpr(u.c.rword, u.c.cn, u.c.cl);
     u.c.tomb = KEY_TOMB - (unsigned long long)((2 * iter - 1) & 3);
     ctx_finish(u.c);
@@ -2912,10 +2912,7 @@ size_t carve_chain(unsigned char *base, const ChainJob &job, const Geometry &g, 
     d.hkey = c.take<unsigned long long>(g.C);
     d.hrank = c.take<uint32_t>((size_t)g.C + ((size_t)g.C + 3) / 4);  // + the best-key indices, one byte per slot, right behind the ranks (hidx_ptr)
     d.hblk = c.take<unsigned char>((size_t)g.C << g.pb_log2);
-    d.ub = c.take<unsigned long long>(g.n_groups);
-    d.gtie = c.take<unsigned long long>(g.n_groups);
-    d.glow = c.take<unsigned long long>(g.n_groups);
-    d.gdirty = c.take<uint32_t>(g.n_groups);
+    d.grec = c.take<GroupRec>(g.n_groups);
     d.mcol = c.take<int>(n_out);
     d.cmap = c.take<uint16_t>(n_out);
     d.colbits = c.take<uint32_t>(n_out * (size_t)((g.rcap + 31) / 32));
@@ -3517,7 +3514,7 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
         im.timings.iterations += d.iter;
         im.timings.rescans += (long long)d.st_rescans;
         // + the search block: bound, flags, tie word and lowered-value mark of every group per step (28 B), and per re-read group its ranks and ~2 slots' key and index
-        im.timings.select_bytes += (double)d.st_sel_bytes + 28.0 * (double)d.n_groups * (double)d.iter + (double)d.st_rescans * ((double)(4u << d.gs_log2) + 24.0);
+        im.timings.select_bytes += (double)d.st_sel_bytes + 32.0 * (double)d.n_groups * (double)d.iter + (double)d.st_rescans * ((double)(4u << d.gs_log2) + 24.0);
         im.timings.partners += (long long)d.st_partners;
         im.timings.table_bytes += (double)d.C * (8.0 + 4.0 + (double)(1 << d.pb_log2));
     }
@@ -3630,9 +3627,7 @@ class HipShardEngine : public ShardEngine {
         HIP_CHECK(hipMemsetAsync(d_.stamp, 0, sizeof(uint32_t) * (size_t)g.rcap, st_));
         HIP_CHECK(hipMemsetAsync(d_.hkey, 0xFF, sizeof(unsigned long long) * (size_t)g.C, st_));
         HIP_CHECK(hipMemsetAsync(d_.hrank, 0, sizeof(uint32_t) * (size_t)g.C, st_));
-        HIP_CHECK(hipMemsetAsync(d_.ub, 0, sizeof(unsigned long long) * (size_t)g.n_groups, st_));
-        HIP_CHECK(hipMemsetAsync(d_.glow, 0, sizeof(unsigned long long) * (size_t)g.n_groups, st_));
-        HIP_CHECK(hipMemsetAsync(d_.gdirty, 1, sizeof(uint32_t) * (size_t)g.n_groups, st_));  // (any non-zero value: not verified)
+        HIP_CHECK(hipMemsetAsync(d_.grec, 0, sizeof(GroupRec) * (size_t)g.n_groups, st_));  // (bound 0 = nothing in the group: its flag is not looked at; the first entry that rises sets it)
         d_.cb_words = (g.rcap + 31) / 32;
         HIP_CHECK(hipMemsetAsync(d_.colbits, 0, sizeof(uint32_t) * (size_t)n_loc_ * d_.cb_words, st_));
         {
