@@ -520,6 +520,16 @@ def main():
             torch.cuda.synchronize()
         mg.barrier()
 
+    # One COUNTED pass outside the timed region (DA4ML_HIP_STATS=1: k_iter_update tallies the blocks it finds / creates -- instrumentation that costs
+    # 1.8 % of a step, so the product and the timed steps run without it): the same matrices, hence the same counts as every timed step.
+    # Skipped with --no-verify (the profiler runs of tools/collect_profiles.sh: only the product's kernels in their traces).
+    counted = None
+    if not args.no_verify:
+        os.environ['DA4ML_HIP_STATS'] = '1'
+        hip.timings(reset=True)
+        hip.solve_many_raw(kernels, **opts).free()
+        counted = hip.timings(reset=True)
+    os.environ['DA4ML_HIP_STATS'] = '0'
     for _ in range(args.warmup):
         hip.solve_many_raw(kernels, **opts).free()
     hip.timings(reset=True)
@@ -562,6 +572,9 @@ def main():
     #     partner ids / references, the hand-off stores, the six special-pair count vectors (st_sel_bytes in the kernel + the host's
     #     pricing of the search, HipBackend::run_chains)
     K = 2 * (2 * 8 - 1)
+    if counted and counted['iterations'] > 0:  # blocks found / created per greedy iteration, from the counted pass on the same matrices
+        tm['found'] = counted['found'] / counted['iterations'] * tm['iterations']
+        tm['inserts'] = counted['inserts'] / counted['iterations'] * tm['iterations']
     alg = {'k_iter_update': tm['cell_bytes'] + 16.0 * tm['partners'] + tm['found'] * (12.0 + 4.0 * K) + tm['inserts'] * (37.0 + 2.0 * K),
            'k_iter_select2': tm['select_bytes']}
     avg_us = {'k_iter_update': upd_avg_us, 'k_iter_select2': sel_avg_us}
@@ -627,7 +640,7 @@ def main():
                    # the few entries its update listed): no bounds, no arg-max in front of the substitution
                    'picks_known_a_step_ahead': tm['fast_steps'] / max(tm['iterations'], 1.0),
                    'group_rereads_per_chain_step': tm['rescans'] / max(tm['iterations'], 1.0),
-                   'source_digest': source_digest()},  # fmt: skip
+                   'blocks_found_created_from_counted_pass': bool(counted), 'source_digest': source_digest()},  # fmt: skip
         'check': check,
     }
     if args.cpu_seconds > 0 and world == 1:

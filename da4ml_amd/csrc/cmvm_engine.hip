@@ -1928,7 +1928,9 @@ template <class Cell> __device__ __forceinline__ void copy_handoff(const UpdStep
 // update_partners: ONE WAVEFRONT works through the partner rows first + q, first + stride + q, ... < limit of the step (q = its
 // four 16-lane groups); no block-level synchronisation inside.  `ref_next` = the (pre-fetched) reference of this group's first
 // partner, `rnew` the record of the new row.
-template <class Cell>
+// STATS: tally the blocks found / created / deleted (benchmark instrumentation and the "peak pair blocks" statistic, DA4ML_HIP_STATS=1); the ballots, population
+// counts and the scalar registers of the three counters are 1.8 % of the batch's step (measured: 27.9 -> 27.5 us, one chain 19.5 -> 19.0), so the product runs without them
+template <class Cell, bool STATS>
 __device__ __forceinline__ void update_partners(ChainDev *g, const UpdStep<Cell> &u, const UpdLds<Cell> &s, int first, int stride, int limit, unsigned long long ref_next,
                                                 const RowInfo &rnew, unsigned int &found, unsigned int &inserts, unsigned int &deletes) {
     using F = RowFmt<Cell>;
@@ -2106,7 +2108,7 @@ __device__ __forceinline__ void update_partners(ChainDev *g, const UpdStep<Cell>
             best = part_row_max_u64<HL>(best);  // all lanes take part (the DPP source lanes must be active); every lane of a block's HL holds its result
             const bool any_alive = (((uint32_t)(__ballot(alive != 0) >> (qsh + HL * half)) & HMASK) != 0);
             if (has && hl == HL - 1) block_commit(c, sX, keyX, BlkHdr{ov, dl, (uint32_t)hdX.z, (uint32_t)hdX.w}, best, any_alive, false);
-            deletes += (unsigned)__popcll(__ballot(has && hl == HL - 1 && !any_alive));  // (wave-uniform: the blocks this pass deleted, tallied once per workgroup)
+            if constexpr (STATS) deletes += (unsigned)__popcll(__ballot(has && hl == HL - 1 && !any_alive));  // (wave-uniform: the blocks this pass deleted, tallied once per workgroup)
         }
         UPD_TIMER_MARK(3)  // block updates
         // ---- block creation, ALL creating groups of the wavefront at once (a group = one new block (partner, new row)): the first bucket of the key
@@ -2182,11 +2184,11 @@ __device__ __forceinline__ void update_partners(ChainDev *g, const UpdStep<Cell>
                     fold_entry(c, rank, tie_word(pr, Nw, (int)bidx));
                 }
             }
-            inserts += (unsigned)__popcll(__ballot(made && l == 0));
+            if constexpr (STATS) inserts += (unsigned)__popcll(__ballot(made && l == 0));
         }
         // ---- rare: blocks beyond their first bucket (look-up, or creation in a full bucket) -- the whole wave, one group at a time
         const unsigned long long rare = __ballot(valid && (sA == SLOT_SLOW || sB == SLOT_SLOW || gslow));
-        found += (unsigned)__popcll(__ballot(l == 0 && sA >= 0)) + (unsigned)__popcll(__ballot(l == 0 && sB >= 0));
+        if constexpr (STATS) found += (unsigned)__popcll(__ballot(l == 0 && sA >= 0)) + (unsigned)__popcll(__ballot(l == 0 && sB >= 0));
         if (rare) {
 #pragma unroll 1
             for (int qq = 0; qq < QN; ++qq) {  // a plain loop: the wave-wide table functions are emitted once
@@ -2201,8 +2203,7 @@ __device__ __forceinline__ void update_partners(ChainDev *g, const UpdStep<Cell>
                     if (slot >= 0) {
                         int gone = 0;
                         table_update(c, slot, pack_pair(lo, hi), [&](int k, uint32_t old) { return old - rdA[k]; }, false, &gone);
-                        deletes += (unsigned)gone;
-                        ++found;
+                        if constexpr (STATS) deletes += (unsigned)gone, ++found;
                     }
                 }
                 if (rsB == SLOT_SLOW) {
@@ -2211,13 +2212,12 @@ __device__ __forceinline__ void update_partners(ChainDev *g, const UpdStep<Cell>
                     if (slot >= 0) {
                         int gone = 0;
                         table_update(c, slot, pack_pair(lo, hi), [&](int k, uint32_t old) { return old - rdB[k]; }, false, &gone);
-                        deletes += (unsigned)gone;
-                        ++found;
+                        if constexpr (STATS) deletes += (unsigned)gone, ++found;
                     }
                 }
                 if (rnewb) {
                     table_insert(c, rpr, Nw, load_row(c.rows, rpr), rnew, [&](int k) { return rcN[k]; }, nullptr, false);
-                    ++inserts;
+                    if constexpr (STATS) ++inserts;
                 }
             }
         }
@@ -2291,7 +2291,7 @@ template <class Cell> __device__ __forceinline__ void special_pairs(ChainDev *gq
 
 // update_body: the partner rows [block_y * NWV * QN + ..., stride grid_y * NWV * QN) of chain `gq`'s current step, by a
 // workgroup of NWV wavefronts (k_iter_update: 256-thread blocks, grid = chains x blocks per chain).
-template <class Cell, int NWV>
+template <class Cell, int NWV, bool STATS>
 __device__ __forceinline__ void update_body(ChainDev *gq, bool in_range, int block_y, int grid_y) {
     constexpr int NTHR = NWV * WAVE;
     // Grid (chains padded to a multiple of 8, blocks per chain): the chain index is the FAST grid dimension.  Workgroups go to
@@ -2318,11 +2318,13 @@ __device__ __forceinline__ void update_body(ChainDev *gq, bool in_range, int blo
     const unsigned long long ref0 = gw * QN + (lane >> QG_LOG2) < u.n_partners ? u.plist[gw * QN + (lane >> QG_LOG2)] : 0ull;
     const RowInfo rnew = load_row(u.c.rows, u.Nw);
     __shared__ unsigned int s_stat[3];
-    if (tid < 3) s_stat[tid] = 0;
+    if constexpr (STATS)
+        if (tid < 3) s_stat[tid] = 0;
     copy_handoff<Cell>(u, s, tid, NTHR);  // one pass, one barrier (the column map arrives ready-made)
     __syncthreads();
     unsigned int found = 0, inserts = 0, deletes = 0;
-    update_partners<Cell>(gq, u, s, gw * QN, total_waves * QN, u.n_partners, ref0, rnew, found, inserts, deletes);
+    update_partners<Cell, STATS>(gq, u, s, gw * QN, total_waves * QN, u.n_partners, ref0, rnew, found, inserts, deletes);
+    if constexpr (!STATS) return;
     // statistics: summed per block in LDS, then ONE pair of device atomics per block.  (Four atomics per wave on one line
     // of the chain descriptor -- 640 per chain and launch, from all XCDs -- serialise at ~12 ns each and every launch had
     // to wait for them; the partner / cell counts are added by k_iter_select, which knows them without counting.)
@@ -2338,7 +2340,7 @@ __device__ __forceinline__ void update_body(ChainDev *gq, bool in_range, int blo
         if (s_stat[1] != s_stat[2]) atomicAdd(&gq->n_live, s_stat[1] - s_stat[2]);  // blocks created less blocks deleted by this workgroup (modulo 2^32)
     }
 }
-template <class Cell>
+template <class Cell, bool STATS>
 __global__ void __launch_bounds__(UPD_THREADS, DA_UPD_OCC) __attribute__((amdgpu_num_sgpr(DA_UPD_SGPRS))) k_iter_update(ChainDev *chains, int n_chains) {
     // Grid (chains padded to a multiple of 8, blocks per chain): the chain index is the FAST grid dimension (see update_body)
 #ifdef DA_STEP_CLOCKS
@@ -2347,7 +2349,7 @@ __global__ void __launch_bounds__(UPD_THREADS, DA_UPD_OCC) __attribute__((amdgpu
     const int clk_par = (gk->iter - 1) & 1;
     if (clk_on && threadIdx.x == 0) CLK_MARK(gk, clk_par, 2, true);
 #endif
-    update_body<Cell, UPD_WAVES>(&chains[(int)blockIdx.x < n_chains ? blockIdx.x : 0], (int)blockIdx.x < n_chains, (int)blockIdx.y, (int)gridDim.y);  // clamped: the descriptor read is unconditional
+    update_body<Cell, UPD_WAVES, STATS>(&chains[(int)blockIdx.x < n_chains ? blockIdx.x : 0], (int)blockIdx.x < n_chains, (int)blockIdx.y, (int)gridDim.y);  // clamped: the descriptor read is unconditional
 #ifdef DA_STEP_CLOCKS
     __syncthreads();
     if (clk_on && threadIdx.x == 0) CLK_MARK(gk, clk_par, 3, false);
@@ -3209,6 +3211,10 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
     // One greedy iteration of one group = (select, update) on the group's stream.
     // `step` = the number of the lockstep iteration = the iteration count of every chain that has not finished (every launch pair advances
     // each of them by one): a kernel argument, because the search block of the selection must not read a field its sibling writes
+    // DA4ML_HIP_STATS=1: k_iter_update tallies the blocks it finds / creates / deletes (da_timings' found / inserts, the "peak pair blocks" of da_result_stats);
+    // read at every call, so that a benchmark can count on one pass and time the others
+    const char *stats_env = std::getenv("DA4ML_HIP_STATS");
+    const bool with_stats = stats_env && std::atoi(stats_env) != 0;
     auto launch_pair = [&](const Group &gr, hipEvent_t *se, int step) {
         ChainDev *base = d_desc + gr.first;
         const dim3 sel_grid((gr.count + 7) & ~7, 2);  // y = 0 search block, y = 1 substitution block
@@ -3219,10 +3225,15 @@ void HipBackend::run_chains(const ChainJob *jobs, ChainOut *outs, int n) {
             hipLaunchKernelGGL(k_iter_select2<uint64_t>, sel_grid, dim3(SEL2_THREADS), sel_lds[1], gr.stream, base, gr.count, im.d_done, step);
         if (se) HIP_CHECK(hipEventRecord(se[1], gr.stream));
         // (+ 2: the last two blocks of a chain write the six blocks of the pairs among the modified rows)
-        if (gr.w == 0)
-            hipLaunchKernelGGL(k_iter_update<uint32_t>, dim3((gr.count + 7) & ~7, upd_blocks[0] + 2), dim3(UPD_THREADS), upd_lds[0], gr.stream, base, gr.count);
+        const dim3 upd_grid((gr.count + 7) & ~7, upd_blocks[gr.w] + 2);
+        if (gr.w == 0 && !with_stats)
+            hipLaunchKernelGGL((k_iter_update<uint32_t, false>), upd_grid, dim3(UPD_THREADS), upd_lds[0], gr.stream, base, gr.count);
+        else if (gr.w == 0)
+            hipLaunchKernelGGL((k_iter_update<uint32_t, true>), upd_grid, dim3(UPD_THREADS), upd_lds[0], gr.stream, base, gr.count);
+        else if (!with_stats)
+            hipLaunchKernelGGL((k_iter_update<uint64_t, false>), upd_grid, dim3(UPD_THREADS), upd_lds[1], gr.stream, base, gr.count);
         else
-            hipLaunchKernelGGL(k_iter_update<uint64_t>, dim3((gr.count + 7) & ~7, upd_blocks[1] + 2), dim3(UPD_THREADS), upd_lds[1], gr.stream, base, gr.count);
+            hipLaunchKernelGGL((k_iter_update<uint64_t, true>), upd_grid, dim3(UPD_THREADS), upd_lds[1], gr.stream, base, gr.count);
         if (se) HIP_CHECK(hipEventRecord(se[2], gr.stream));
     };
     // Windows of up to WINDOW_ITERS iterations x all groups are queued eagerly; one event-bracketed iteration per window

@@ -122,7 +122,9 @@ int da_stage_info(const da_result *r, int stage, int64_t *info);
 int da_stage_copy(const da_result *r, int stage, int64_t *inp_shifts, int64_t *out_idxs, int64_t *out_shifts, int64_t *out_negs,
                   int64_t *ops_i, float *ops_f);
 /* stats[0..7] = greedy iterations, initial digits, -, selection rounds, peak pair blocks, re-read table slots,
- * partner rows updated, substituted digits -- summed over the chains run for this problem */
+ * partner rows updated, substituted digits -- summed over the chains run for this problem.  "Peak pair blocks" follows the
+ * table only when the environment variable DA4ML_HIP_STATS=1 is set at the call (the update kernel then tallies the blocks it
+ * creates and deletes: instrumentation, 1.8 % of a greedy step); without it the figure is the initial block count. */
 int da_result_stats(const da_result *r, int64_t *stats);
 /* Releases a result handle (NULL is ignored).  The op lists of the result are kept by the library for the next solve
  * (at most 1 GiB in total) instead of being returned to the allocator. */
@@ -156,7 +158,7 @@ int da_dais_run_on(const int32_t *program, int64_t n_words, const double *inputs
  * greedy iterations, table groups re-read, partner rows, chains, table bytes, arena bytes, sampled k_iter_select ms,
  * sampled k_iter_update ms, number of samples, count blocks found, count blocks inserted, partner cells read,
  * count-block bytes (2K per touched block), partner-cell bytes -- accumulated since the last reset */
-int da_timings(double *t, int reset);
+int da_timings(double *t, int reset);  /* (blocks found / created are tallied only under DA4ML_HIP_STATS=1, see da_result_stats) */
 /* Further engine counters, same accumulation and reset as da_timings (call BEFORE a resetting da_timings); writes min(n, 16) values:
  * out[0] algorithmic bytes of k_iter_select (device-counted), out[1] host ms spent queueing greedy-loop
  * launches, out[2..15] reserved (0); returns the number written */
