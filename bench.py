@@ -17,7 +17,10 @@ Extra objects on the JSON line:
                 bytes per launch (device-counted) / average launch duration measured with HIP events on
                 the launch stream inside the library; `traffic` (FETCH_SIZE x 2 as MI355X_MICROARCH.md prescribes for gfx950 +
                 WRITE_SIZE) and `valu` from the committed rocprofv3 PMC passes -- ONLY when those passes were taken on the very
-                sources that are loaded now (profiles/rNN_pmc_meta.json carries their digest), otherwise null + `stale_profiles`
+                sources that are loaded now (profiles/rNN_pmc_meta.json carries their digest), otherwise null + `stale_profiles`.
+                The update kernel's share of the byte model (blocks it finds / creates) is counted by ONE pass of the same matrices
+                outside the timed region, run under DA4ML_HIP_STATS=1: those tallies are instrumentation of this benchmark, touch no
+                result, and cost 4 % of a step -- the product, and therefore the timed steps, run the kernel without them
   cpu_baseline  the reference's own sources (oracle/_ref/libref.so) on the host cores, one single-threaded solver process per
                 core on its own matrix: a bounded prefix of every 256x256 chain scaled to full chains with the time curve of a
                 complete run (labelled extrapolated), plus two fully MEASURED pairs through the same pool with the GPU timed on
