@@ -1,5 +1,5 @@
 """Profiling workload: a batch of single greedy chains.  Usage: python tests/gpu_profile.py N BATCH"""
-import sys, time
+import os, sys, time
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import numpy as np
 from cases import int_matrix
@@ -21,7 +21,8 @@ if os.environ.get('TIMER_WINDOW_STEPS'):  # a phase-timer build restricted to a 
     print('window: select cycles/step', {k: round(v / w) for k, v in ph.items() if k.startswith('sel_')}, '| search', {k: round(tm[k] / max(tm['search_steps_timed'], 1)) for k in ('search_bounds', 'search_argmax', 'search_excluded')},
           '| update wave-cycles/step', {k: round(v / w) for k, v in ph.items() if k.startswith('upd_')})
 print('select cycles/iteration:', {k: round(v / its) for k, v in ph.items() if k.startswith('sel_')})
-print('update cycles/partner  :', {k: round(v / pa) for k, v in ph.items() if k.startswith('upd_')}, 'partners/iter', round(pa / its), 'found/partner %.2f' % (tm['found'] / pa), 'inserts/partner %.3f' % (tm['inserts'] / pa))
+print('update cycles/partner  :', {k: round(v / pa) for k, v in ph.items() if k.startswith('upd_')}, 'partners/iter', round(pa / its), 'found/partner %.2f' % (tm['found'] / pa), 'inserts/partner %.3f' % (tm['inserts'] / pa),
+      '' if os.environ.get('DA4ML_HIP_STATS', '0') not in ('', '0') else '(blocks found / created are tallied only under DA4ML_HIP_STATS=1)')
 sm = max(tm['samples'], 1)
 print('picks known a step ahead: %.1f %% of %d steps; group re-reads per step %.2f' % (100.0 * tm['fast_steps'] / its, its, tm['rescans'] / its))
 if tm['search_steps_timed']:
